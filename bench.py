@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's peak benchmark (runpeakbenchmark.sh) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): all 20 queries of allqueries.fasta against the simulated
+equal-length DB (`--pseudodb 1000000 512`: one mt19937(42) sequence replicated 10^6 times, resident
+in HBM), half2 kernel (kind f16x2), BLOSUM62, gop -11, gex -1, --top 0.
+A STEP is one pass of the whole query set over the resident DB (20 scans), the unit the reference's
+"Total time ... GCUPS" line is computed over (main.cu:257-260).  GCUPS = sum |q| * sum |s| / 1e9 / s
+with true lengths (cudasw4.cuh:2264-2271).
+
+Multi-GPU: the DB is sharded over the ranks (each rank holds --db-size subjects: weak scaling),
+no data-path collective; per-rank top-K lists are merged on the host (search.merge_topk).
+
+Prints ONE JSON line on rank 0 (see the driver contract), including `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+KIND_BY_NAME = {"half2": 0, "dpxs16": 1, "dpxs32": 2, "float": 3}
+DTYPE_BY_KIND = {0: "f16x2", 1: "i16x2", 2: "i32", 3: "f32"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--db-size", type=int, default=1_000_000, help="pseudo-DB subjects per GPU")
+    ap.add_argument("--db-length", type=int, default=512, help="pseudo-DB subject length")
+    ap.add_argument("--kernel", choices=sorted(KIND_BY_NAME), default="half2")
+    ap.add_argument("--top", type=int, default=0, help="top-K per query (reference benchmark uses 0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-subjects", type=int, default=1500)
+    return ap.parse_args()
+
+
+def cpu_baseline(queries, L, nsubj):
+    """Oracle's inter-sequence SIMD scan (kind 'port') on the host cores, bounded sample of the same
+    workload: all 20 queries x `nsubj` pseudo subjects of length L."""
+    import oracle_lib as O
+    codes = O.pseudodb_codes(L, 42)
+    chars, offsets, lengths = O.make_db([codes] * nsubj)
+    m = O.blosum21(62)
+    cores = O.max_threads()
+    O.scan(queries[0], chars, offsets, lengths, m21=m, simd=True)  # warm-up (threads, pages)
+    t0 = time.perf_counter()
+    for q in queries:
+        O.scan(q, chars, offsets, lengths, m21=m, simd=True)
+    dt = time.perf_counter() - t0
+    cells = float(sum(len(q) for q in queries)) * float(nsubj) * float(L)
+    return {"value": round(cells / 1e9 / dt, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": "20 queries x %d pseudo subjects of length %d, int16 inter-sequence SIMD oracle, %.1f s"
+                      % (nsubj, L, dt)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import oracle_lib as O  # query set + pseudo-DB residues (data only; the scan below is all HIP)
+    from cudasw4_amd import capi, search
+
+    _, queries = O.load_queries()
+    kind = KIND_BY_NAME[args.kernel]
+    L, num = args.db_length, args.db_size
+    codes = O.pseudodb_codes(L, 42)
+    db = search.DeviceDB.pseudo(num, L, codes, device=local_rank)
+    db.id_offset = rank * num  # global subject ids of this shard
+    big = capi.KIND_F32 if kind in (0, 3) else capi.KIND_I32
+    small = kind if kind in (0, 1) else (0 if kind == 3 else 1)
+    kt = search.KernelTypeConfig(single_pass=kind, many_pass_small=small, many_pass_large=big, overflow=big)
+    s = search.Searcher(device=local_rank, num_top=args.top, matrix=O.blosum21(62), kernel_types=kt)
+    s.set_database(db)
+    s.record_kernel_events = False
+
+    def one_step(collect=None):
+        tops = []
+        for q in queries:
+            res = s.scan(q, timed=False, sync=False)
+            if args.top > 0:
+                tops.append(res)
+        return tops
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    s.record_kernel_events = True
+    s.kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    s.record_kernel_events = False
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    # dominant kernel: the DP scan launch; durations from HIP events on the launch stream
+    kern_ms = [a.elapsed_time(b) for (a, b, _) in s.kernel_events]
+    kern_cells = [c for (_, _, c) in s.kernel_events]
+    sum_q = sum(len(q) for q in queries)
+    cells_per_step = float(sum_q) * float(num) * float(L)
+    total_cells = cells_per_step * args.steps * world
+    gcups = total_cells / 1e9 / dt_max
+
+    if rank == 0:
+        n_launch = max(len(kern_ms), 1)
+        avg_ms = sum(kern_ms) / n_launch
+        # algorithmic HBM bytes of one scan launch: chars + lengths + offsets + scores/ids + query
+        lpad = (L + 3) // 4 * 4
+        avg_q = sum_q / len(queries)
+        bytes_per_launch = num * lpad + 4 * num + 8 * (num + 1) + 8 * num + (avg_q + 3) // 4 * 4 + 128
+        hbm_gbs = bytes_per_launch / 1e9 / (avg_ms * 1e-3)
+        kern_gcups = (sum(kern_cells) / 1e9) / (sum(kern_ms) * 1e-3) if kern_ms else 0.0
+        packed = kind in (0, 1)
+        # VALU issue ceiling: 256 CU x 4 SIMD x 16 lanes... measured per-instruction rates are in DESIGN.md;
+        # planning figure 256 CU * 64 lanes/clk * 2.4 GHz lane-instr/s, 10 ops per cell(-pair)
+        valu_peak_gcups = 256 * 64 * 2.4e9 / 10 * (2 if packed else 1) / 1e9
+        out = {
+            "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_BY_KIND[kind], "data": "synthetic",
+            "config": {"workload": "allqueries.fasta (20 queries, 41752 residues) vs pseudo DB %d x %d per GPU, "
+                                   "%s kernel, blosum62, gop -11 gex -1, top %d" % (num, L, args.kernel, args.top),
+                       "db_subjects_per_gpu": num, "db_length": L, "queries": len(queries), "kernel": args.kernel,
+                       "parallelism": "db-shard x%d, host top-K merge" % world},
+            "roofline": {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(hbm_gbs / 8000.0, 6), "traffic": None,
+                         "kernel": "sw_scan_kernel<%s>" % DTYPE_BY_KIND[kind], "avg_launch_ms": round(avg_ms, 4),
+                         "launches": len(kern_ms), "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+            "valu_roofline": {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(valu_peak_gcups, 1),
+                              "unit": "GCUPS", "frac": round(kern_gcups / valu_peak_gcups, 4),
+                              "note": "binding bound: packed 16-bit VALU issue (10 ops per cell pair), see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(queries, L, args.cpu_sample_subjects)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

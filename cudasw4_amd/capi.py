@@ -1,0 +1,132 @@
+"""ctypes binding of the C ABI in include/cudasw4_amd.h (libcudasw4_amd.so).
+
+This is plumbing: every compute call goes to the HIP library.  There is no Python or CPU fallback —
+if the shared library is missing the import of this module raises, and without a GPU
+`Context()` raises `SwError` (SW_ERR_NO_DEVICE).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcudasw4_amd.so")
+
+KIND_F16X2, KIND_I16X2, KIND_I32, KIND_F32 = 0, 1, 2, 3
+KIND_NAMES = {"half2": KIND_F16X2, "f16x2": KIND_F16X2, "dpxs16": KIND_I16X2, "i16x2": KIND_I16X2,
+              "dpxs32": KIND_I32, "i32": KIND_I32, "float": KIND_F32, "f32": KIND_F32}
+MAX_ACC = {KIND_F16X2: 2048, KIND_I16X2: 25000}
+
+SW_OK = 0
+ERR_NAMES = {-1: "SW_ERR_INVALID", -2: "SW_ERR_HIP", -3: "SW_ERR_NO_QUERY", -4: "SW_ERR_NO_MATRIX",
+             -5: "SW_ERR_TEMP", -6: "SW_ERR_NO_DEVICE"}
+
+# every symbol include/cudasw4_amd.h declares
+EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "sw_ctx_destroy", "sw_set_matrix",
+           "sw_set_query", "sw_scan_temp_bytes", "sw_scan_partition", "sw_rescore_overflow", "sw_topk_temp_bytes",
+           "sw_topk", "sw_plan_query"]
+
+
+class SwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "SW_ERR"), code, msg))
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libcudasw4_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C cudasw4_amd/csrc`): %s" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+    L.sw_version.restype = ctypes.c_char_p
+    L.sw_last_error.restype = ctypes.c_char_p
+    L.sw_device_count.restype = ctypes.c_int
+    L.sw_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.sw_ctx_destroy.argtypes = [vp]
+    L.sw_set_matrix.argtypes = [vp, vp, ctypes.c_int]
+    L.sw_set_query.argtypes = [vp, vp, i32, vp]
+    L.sw_scan_temp_bytes.restype = sz
+    L.sw_scan_temp_bytes.argtypes = [vp, ctypes.c_int, i32]
+    L.sw_scan_partition.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, i32, ctypes.c_int,
+                                    ctypes.c_int, vp, vp, i64, vp, vp, ctypes.c_int, vp, sz, vp]
+    L.sw_rescore_overflow.argtypes = [vp, ctypes.c_int, vp, vp, i32, vp, vp, vp, i32, ctypes.c_int, ctypes.c_int,
+                                      vp, vp, i64, vp, sz, vp]
+    L.sw_topk_temp_bytes.restype = sz
+    L.sw_topk_temp_bytes.argtypes = [i64, ctypes.c_int]
+    L.sw_topk.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp, vp, sz, vp]
+    L.sw_plan_query.argtypes = [ctypes.c_int, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    return L
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != SW_OK:
+        raise SwError(rc, lib.sw_last_error().decode())
+
+
+def version():
+    return lib.sw_version().decode()
+
+
+def device_count():
+    return int(lib.sw_device_count())
+
+
+def plan_query(kind, qlen):
+    r, s = ctypes.c_int32(), ctypes.c_int32()
+    check(lib.sw_plan_query(kind, qlen, ctypes.byref(r), ctypes.byref(s)))
+    return r.value, s.value
+
+
+class Context:
+    """One per GPU (sw_ctx).  Pointers are passed as integers (tensor.data_ptr())."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        check(lib.sw_ctx_create(device, ctypes.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            lib.sw_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_matrix(self, m21):
+        import numpy as np
+        m = np.ascontiguousarray(m21, dtype=np.int8).reshape(-1)
+        dim = int(round(len(m) ** 0.5))
+        check(lib.sw_set_matrix(self.handle, m.ctypes.data, dim))
+
+    def set_query(self, codes, stream=0):
+        import numpy as np
+        q = np.ascontiguousarray(codes, dtype=np.int8)
+        check(lib.sw_set_query(self.handle, q.ctypes.data, len(q), stream))
+
+    def scan_temp_bytes(self, kind, max_subject_len):
+        return int(lib.sw_scan_temp_bytes(self.handle, kind, max_subject_len))
+
+    def scan_partition(self, kind, part_id, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex,
+                       scores, ids, id_offset=0, ovf_pos=0, ovf_count=0, ovf_check=0, temp=0, temp_bytes=0, stream=0):
+        check(lib.sw_scan_partition(self.handle, kind, part_id, chars, offsets, lengths, first_pos, n, max_subject_len,
+                                    gop, gex, scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
+                                    stream))
+
+    def rescore_overflow(self, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len, gop, gex,
+                         scores, ids, id_offset=0, temp=0, temp_bytes=0, stream=0):
+        check(lib.sw_rescore_overflow(self.handle, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths,
+                                      max_subject_len, gop, gex, scores, ids, id_offset, temp, temp_bytes, stream))
+
+    def topk(self, scores, ids, n, k, out_scores, out_ids, temp, temp_bytes, stream=0):
+        check(lib.sw_topk(self.handle, scores, ids, n, k, out_scores, out_ids, temp, temp_bytes, stream))
+
+
+def topk_temp_bytes(n, k):
+    return int(lib.sw_topk_temp_bytes(n, k))

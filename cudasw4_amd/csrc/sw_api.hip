@@ -1,0 +1,359 @@
+// sw_api.hip — the C ABI declared in include/cudasw4_amd.h.
+//
+// Host-side glue only: context state (matrix, query, per-kind profile), query planning (rows per
+// lane x stripes), launch-grid / scratch sizing, overflow re-score and top-K.  There is NO CPU
+// fallback anywhere: without a HIP device every entry point fails with SW_ERR_NO_DEVICE/SW_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cudasw4_amd.h"
+#include "sw_launch.hpp"
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define SW_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return fail(SW_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+    } while (0)
+
+const swk::KindLaunch* kind_launch(int kind) {
+    switch (kind) {
+        case SW_KIND_F16X2: return &swk::launch_f16x2();
+        case SW_KIND_I16X2: return &swk::launch_i16x2();
+        case SW_KIND_I32: return &swk::launch_i32();
+        case SW_KIND_F32: return &swk::launch_f32();
+    }
+    return nullptr;
+}
+
+bool kind_packed(int kind) { return kind == SW_KIND_F16X2 || kind == SW_KIND_I16X2; }
+
+struct QueryPlan {
+    int rows = 0;      // R: query rows per lane
+    int nstripes = 0;  // stripes of 16*R rows
+};
+
+// Pick (R, nstripes) with R a compiled value: fewest stripes first, then the smallest R that covers
+// the query.  Replaces the reference's subject-length -> (group_size, numRegs) table
+// (cudasw4.cuh:1764-1912); here the tile shape follows the QUERY length because the query is the
+// register-resident dimension.
+QueryPlan plan_query(int kind, int32_t qlen) {
+    const swk::KindLaunch* kl = kind_launch(kind);
+    QueryPlan pl;
+    if (!kl || qlen <= 0) return pl;
+    const int maxrows = kl->max_rows;
+    const int64_t stripe_max = (int64_t)swk::kGroup * maxrows;
+    pl.nstripes = (int)((qlen + stripe_max - 1) / stripe_max);
+    const int64_t per_lane = (qlen + (int64_t)swk::kGroup * pl.nstripes - 1) / ((int64_t)swk::kGroup * pl.nstripes);
+    int r = (int)((per_lane + swk::kRowsGranule - 1) / swk::kRowsGranule * swk::kRowsGranule);
+    pl.rows = std::min(std::max(r, swk::kRowsGranule), maxrows);
+    return pl;
+}
+
+struct Profile {
+    unsigned char* dev = nullptr;
+    size_t capacity = 0;
+    bool valid = false;
+    QueryPlan plan;
+    hipEvent_t ready = nullptr;  // recorded after the build; scans on other streams wait on it
+};
+
+}  // namespace
+
+struct sw_ctx {
+    int device = 0;
+    int num_cus = 0;
+    int8_t* d_matrix = nullptr;  // 21 x 21
+    bool have_matrix = false;
+    int8_t* d_query = nullptr;
+    size_t query_capacity = 0;
+    int32_t qlen = 0;
+    bool have_query = false;
+    Profile profiles[4];
+};
+
+namespace {
+
+int max_grid(const sw_ctx* ctx) { return std::max(1, ctx->num_cus) * 4; }
+
+int ensure_profile(sw_ctx* ctx, int kind, hipStream_t stream) {
+    Profile& pr = ctx->profiles[kind];
+    if (pr.valid) {
+        // built on another stream earlier in this query: order this stream after the build
+        SW_HIP(hipStreamWaitEvent(stream, pr.ready, 0));
+        return SW_OK;
+    }
+    const swk::KindLaunch* kl = kind_launch(kind);
+    const QueryPlan pl = plan_query(kind, ctx->qlen);
+    const size_t bytes = kl->tile_bytes(pl.rows) * (size_t)pl.nstripes;
+    if (bytes == 0) return fail(SW_ERR_INVALID, "no kernel compiled for this query plan");
+    if (bytes > pr.capacity) {
+        if (pr.dev) SW_HIP(hipFree(pr.dev));
+        pr.dev = nullptr;
+        pr.capacity = 0;
+        SW_HIP(hipMalloc(&pr.dev, bytes));
+        pr.capacity = bytes;
+    }
+    SW_HIP(kl->profile(pl.rows, ctx->d_query, ctx->qlen, ctx->d_matrix, pl.nstripes, pr.dev, stream));
+    if (!pr.ready) SW_HIP(hipEventCreateWithFlags(&pr.ready, hipEventDisableTiming));
+    SW_HIP(hipEventRecord(pr.ready, stream));
+    pr.plan = pl;
+    pr.valid = true;
+    return SW_OK;
+}
+
+// scratch words per (workgroup, group) array for subjects up to max_len
+int32_t border_capacity(int32_t max_len) {
+    int64_t steps = ((int64_t)max_len + swk::kGroup - 1 + 3) / 4 * 4;
+    steps = (steps + 15) / 16 * 16;
+    return (int32_t)(steps + 32);
+}
+
+int scan_common(sw_ctx* ctx, int kind, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
+                const int32_t* positions, const int32_t* count_ptr, int32_t first_pos, int32_t n,
+                int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
+                int32_t* ovf_pos, int32_t* ovf_count, int ovf_check, void* temp, size_t temp_bytes,
+                hipStream_t stream) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    const swk::KindLaunch* kl = kind_launch(kind);
+    if (!kl) return fail(SW_ERR_INVALID, "unknown kind");
+    if (n < 0 || max_subject_len < 0) return fail(SW_ERR_INVALID, "negative count or length");
+    if (gop > 0 || gex > 0) return fail(SW_ERR_INVALID, "gap scores must be <= 0");
+    if (kind_packed(kind) && (gop < -2000 || gex < -2000)) return fail(SW_ERR_INVALID, "gap score out of range for a 16-bit kind");
+    if (!ctx->have_matrix) return fail(SW_ERR_NO_MATRIX, "sw_set_matrix has not been called");
+    if (!ctx->have_query) return fail(SW_ERR_NO_QUERY, "sw_set_query has not been called");
+    if (n == 0) return SW_OK;
+    if (!chars || !offsets || !lengths || !scores || !ids) return fail(SW_ERR_INVALID, "null buffer");
+    if (ovf_check && kind_packed(kind) && (!ovf_pos || !ovf_count)) return fail(SW_ERR_INVALID, "overflow check without overflow buffers");
+    SW_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_profile(ctx, kind, stream);
+    if (rc != SW_OK) return rc;
+    const QueryPlan pl = ctx->profiles[kind].plan;
+    const bool multi = pl.nstripes > 1;
+
+    const int subj_per_batch = swk::kGroupsPerWg * (kind_packed(kind) ? 2 : 1);
+    const int nbatches = (n + subj_per_batch - 1) / subj_per_batch;
+    int grid = std::min(nbatches, max_grid(ctx));
+
+    swk::ScanParams p{};
+    p.chars = chars; p.offsets = offsets; p.lengths = lengths;
+    p.positions = positions; p.count_ptr = count_ptr;
+    p.first_pos = first_pos; p.n = n;
+    p.profile = ctx->profiles[kind].dev; p.nstripes = pl.nstripes;
+    switch (kind) {
+        case SW_KIND_F16X2: p.gop = swk::Arith<swk::F16X2>::encode_gap(gop); p.gex = swk::Arith<swk::F16X2>::encode_gap(gex); break;
+        case SW_KIND_I16X2: p.gop = swk::Arith<swk::I16X2>::encode_gap(gop); p.gex = swk::Arith<swk::I16X2>::encode_gap(gex); break;
+        case SW_KIND_I32: p.gop = swk::Arith<swk::I32>::encode_gap(gop); p.gex = swk::Arith<swk::I32>::encode_gap(gex); break;
+        default: p.gop = swk::Arith<swk::F32>::encode_gap(gop); p.gex = swk::Arith<swk::F32>::encode_gap(gex); break;
+    }
+    p.scores = scores; p.ids = ids; p.id_offset = id_offset;
+    p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;
+    p.scratch = nullptr; p.lcap = 0;
+    if (multi) {
+        p.lcap = border_capacity(max_subject_len);
+        const size_t per_wg = (size_t)swk::kGroupsPerWg * 2 * (size_t)p.lcap * sizeof(uint32_t);
+        if (!temp || temp_bytes < per_wg) return fail(SW_ERR_TEMP, "temp buffer too small for a multi-stripe query");
+        grid = (int)std::min<size_t>((size_t)grid, temp_bytes / per_wg);
+        p.scratch = static_cast<uint32_t*>(temp);
+    }
+    SW_HIP(kl->scan(pl.rows, multi, grid, stream, p));
+    return SW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sw_version(void) { return "cudasw4_amd 0.1 (gfx950)"; }
+
+const char* sw_last_error(void) { return g_last_error.c_str(); }
+
+int sw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sw_ctx_create(int device, sw_ctx** out) {
+    if (!out) return fail(SW_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SW_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(SW_ERR_INVALID, "device index out of range");
+    SW_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SW_HIP(hipGetDeviceProperties(&prop, device));
+    sw_ctx* ctx = new sw_ctx;
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);
+    if (e != hipSuccess) { delete ctx; return fail(SW_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    *out = ctx;
+    return SW_OK;
+}
+
+int sw_ctx_destroy(sw_ctx* ctx) {
+    if (!ctx) return SW_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_matrix) (void)hipFree(ctx->d_matrix);
+    if (ctx->d_query) (void)hipFree(ctx->d_query);
+    for (auto& pr : ctx->profiles) {
+        if (pr.dev) (void)hipFree(pr.dev);
+        if (pr.ready) (void)hipEventDestroy(pr.ready);
+    }
+    delete ctx;
+    return SW_OK;
+}
+
+int sw_set_matrix(sw_ctx* ctx, const int8_t* matrix_host, int dim) {
+    if (!ctx || !matrix_host) return fail(SW_ERR_INVALID, "null argument");
+    if (dim != swk::kLetters) return fail(SW_ERR_INVALID, "only 21 x 21 matrices (20 amino acids + other) are supported");
+    for (int i = 0; i < dim; i++)
+        if (matrix_host[swk::kPadLetter * dim + i] >= 0 || matrix_host[i * dim + swk::kPadLetter] >= 0)
+            return fail(SW_ERR_INVALID, "scores against the padding letter must be negative");
+    SW_HIP(hipSetDevice(ctx->device));
+    SW_HIP(hipMemcpy(ctx->d_matrix, matrix_host, dim * dim, hipMemcpyHostToDevice));
+    ctx->have_matrix = true;
+    for (auto& pr : ctx->profiles) pr.valid = false;
+    return SW_OK;
+}
+
+int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void* stream) {
+    if (!ctx || !query_codes_host) return fail(SW_ERR_INVALID, "null argument");
+    if (qlen <= 0) return fail(SW_ERR_INVALID, "query length must be positive");
+    for (int32_t i = 0; i < qlen; i++)
+        if (query_codes_host[i] < 0 || query_codes_host[i] >= swk::kLetters) return fail(SW_ERR_INVALID, "query code out of range");
+    SW_HIP(hipSetDevice(ctx->device));
+    if ((size_t)qlen > ctx->query_capacity) {
+        if (ctx->d_query) SW_HIP(hipFree(ctx->d_query));
+        ctx->d_query = nullptr;
+        ctx->query_capacity = 0;
+        const size_t cap = ((size_t)qlen + 4095) / 4096 * 4096;
+        SW_HIP(hipMalloc(&ctx->d_query, cap));
+        ctx->query_capacity = cap;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // profiles built from the previous query may still be in use on `s`: the copy is stream-ordered
+    SW_HIP(hipMemcpyAsync(ctx->d_query, query_codes_host, qlen, hipMemcpyHostToDevice, s));
+    SW_HIP(hipStreamSynchronize(s));  // host buffer may be reused by the caller immediately
+    ctx->qlen = qlen;
+    ctx->have_query = true;
+    for (auto& pr : ctx->profiles) pr.valid = false;
+    return SW_OK;
+}
+
+int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstripes) {
+    if (!kind_launch(kind) || qlen <= 0) return fail(SW_ERR_INVALID, "bad kind or query length");
+    const QueryPlan pl = plan_query(kind, qlen);
+    if (rows_per_lane) *rows_per_lane = pl.rows;
+    if (nstripes) *nstripes = pl.nstripes;
+    return SW_OK;
+}
+
+size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int32_t max_subject_len) {
+    if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0) return 0;
+    const QueryPlan pl = plan_query(kind, ctx->qlen);
+    if (pl.nstripes <= 1) return 0;
+    return (size_t)max_grid(ctx) * swk::kGroupsPerWg * 2 * (size_t)border_capacity(max_subject_len) * sizeof(uint32_t);
+}
+
+int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, const uint64_t* offsets,
+                      const int32_t* lengths, int32_t first_pos, int32_t n, int32_t max_subject_len, int gop, int gex,
+                      float* scores, int32_t* ids, int64_t id_offset, int32_t* ovf_pos, int32_t* ovf_count,
+                      int ovf_check, void* temp, size_t temp_bytes, void* stream) {
+    if (part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS) return fail(SW_ERR_INVALID, "partition id out of range");
+    return scan_common(ctx, kind, chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
+                       scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
+                       static_cast<hipStream_t>(stream));
+}
+
+int sw_rescore_overflow(sw_ctx* ctx, int kind, const int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
+                        const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
+                        int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp,
+                        size_t temp_bytes, void* stream) {
+    if (kind != SW_KIND_I32 && kind != SW_KIND_F32) return fail(SW_ERR_INVALID, "overflow re-score needs a 32-bit kind");
+    if (!ovf_pos || !ovf_count) return fail(SW_ERR_INVALID, "null overflow buffers");
+    if (max_count <= 0) return SW_OK;
+    // grid sized for max_count; the kernel reads the real count on the device (no host round trip,
+    // no device-side launch — cf. float_kernels.cuh:1206-1258)
+    return scan_common(ctx, kind, chars, offsets, lengths, ovf_pos, ovf_count, 0, max_count, max_subject_len, gop, gex,
+                       scores, ids, id_offset, nullptr, nullptr, 0, temp, temp_bytes, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------ top-K
+// v1: stable descending radix sort of (score, id) pairs, first k copied out.  Stability keeps the
+// input order among equal scores, i.e. ascending id for the driver's position-ordered result lists.
+
+namespace {
+struct TopkLayout {
+    size_t keys_off, vals_off, cub_off, total, cub_bytes;
+};
+TopkLayout topk_layout(int64_t n) {
+    TopkLayout L{};
+    size_t cub = 0;
+    hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const float*)nullptr, (float*)nullptr,
+                                                 (const int32_t*)nullptr, (int32_t*)nullptr, (int)std::max<int64_t>(n, 1));
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    L.keys_off = 0;
+    L.vals_off = al((size_t)n * sizeof(float));
+    L.cub_off = L.vals_off + al((size_t)n * sizeof(int32_t));
+    L.cub_bytes = cub;
+    L.total = L.cub_off + al(cub);
+    return L;
+}
+__global__ void topk_copy_kernel(const float* keys, const int32_t* vals, int64_t n, int k, float* out_s, int32_t* out_i) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) {
+        out_s[i] = i < n ? keys[i] : -1.0f;
+        out_i[i] = i < n ? vals[i] : -1;
+    }
+}
+}  // namespace
+
+size_t sw_topk_temp_bytes(int64_t n, int k) {
+    (void)k;
+    if (n <= 0) return 0;
+    return topk_layout(n).total;
+}
+
+int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int k, float* out_scores,
+            int32_t* out_ids, void* temp, size_t temp_bytes, void* stream) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    if (k <= 0) return SW_OK;
+    if (n < 0 || n > 0x7fffffffLL) return fail(SW_ERR_INVALID, "bad result count");
+    if (!out_scores || !out_ids) return fail(SW_ERR_INVALID, "null output");
+    SW_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* keys = nullptr;
+    int32_t* vals = nullptr;
+    if (n > 0) {
+        if (!scores || !ids) return fail(SW_ERR_INVALID, "null input");
+        const TopkLayout L = topk_layout(n);
+        if (!temp || temp_bytes < L.total) return fail(SW_ERR_TEMP, "temp buffer too small for top-K");
+        char* base = static_cast<char*>(temp);
+        keys = reinterpret_cast<float*>(base + L.keys_off);
+        vals = reinterpret_cast<int32_t*>(base + L.vals_off);
+        size_t cub = L.cub_bytes;
+        SW_HIP(hipcub::DeviceRadixSort::SortPairsDescending(base + L.cub_off, cub, scores, keys, ids, vals, (int)n, 0, 32, s));
+    }
+    hipLaunchKernelGGL(topk_copy_kernel, dim3((k + 255) / 256), dim3(256), 0, s, keys, vals, n, k, out_scores, out_ids);
+    SW_HIP(hipGetLastError());
+    return SW_OK;
+}
+
+}  // extern "C"

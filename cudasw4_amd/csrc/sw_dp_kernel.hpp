@@ -1,0 +1,496 @@
+// sw_dp_kernel.hpp — the Smith-Waterman DP-matrix fill for gfx950 (MI355X), all four arithmetic kinds.
+//
+// Replaces the reference's NW_local_affine_{single,multi}_pass_{half2,dpx_s16,dpx_s32,float}
+// kernels (half2_kernels.cuh:798-1125, dpx_s16_kernels.cuh:765-1056, dpx_s32_kernels.cuh:777-1017,
+// float_kernels.cuh:788-1023).  NOT a translation: the reference keeps the SUBJECT in registers and
+// streams the query through a 32-lane warp with a 37 KB pair table gathered from shared memory.
+// Here the orientation is transposed and built around CDNA4's DPP rows:
+//
+//   * one alignment group == one DPP row of 16 lanes; a wave64 runs 4 independent groups;
+//   * the QUERY is tiled in stripes of 16*R rows; lane l of a group owns R consecutive query rows
+//     and keeps their H (previous column) and E (horizontal gap) state in VGPRs;
+//   * subject letters stream through the row: at step t lane l works on subject column t-l
+//     (anti-diagonal wavefront).  H and F of a lane's bottom row go to lane l+1 with
+//     v_mov_b32_dpp row_shr:1 (lane 0 is fed by bound_ctrl zero-fill or by the previous stripe);
+//   * the substitution scores come from a per-query PROFILE tile in LDS: for subject letter c the
+//     lane reads its R scores as contiguous 16-byte chunks (ds_read_b128), laid out so that the
+//     bank of an access depends on the lane only -> conflict-free for any mix of letters;
+//   * packed kinds run two subjects per group in the two 16-bit halves (v_pk_add_u16 / v_pk_max_i16 /
+//     v_pk_sub_u16 clamp, or v_pk_add_f16 / v_pk_maximum3_f16);
+//   * queries longer than one stripe are processed stripe after stripe by the same group; the H/F
+//     row at the stripe border is spilled to a small global scratch (one coalesced 64-byte
+//     load/store per 16 columns), the analogue of the reference's devTempHcol2/devTempEcol2.
+//
+// Padding is self-neutralising exactly as in the reference: query rows >= Q and
+// subject columns >= len use letter code 20 whose scores are all negative.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace swk {
+
+typedef uint32_t u32;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kGroup = 16;        // lanes per alignment group (one DPP row)
+constexpr int kThreads = 256;     // workgroup size: 4 waves, 16 groups
+constexpr int kGroupsPerWg = kThreads / kGroup;
+constexpr int kPadLetter = 20;    // code used for padding rows / columns
+constexpr int kLetters = 21;
+
+enum { F16X2 = 0, I16X2 = 1, I32 = 2, F32 = 3 };
+
+// DPP controls (GFX9 encoding)
+constexpr int DPP_ROW_SHL1 = 0x101;  // lane i <- lane i+1 (within a row of 16)
+constexpr int DPP_ROW_SHR1 = 0x111;  // lane i <- lane i-1
+constexpr int DPP_ROW_ROR1 = 0x121;
+
+template <int CTRL, bool ZERO_FILL>
+__device__ __forceinline__ u32 dpp(u32 old, u32 src) {
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, 0xf, ZERO_FILL);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Arithmetic traits.  All state lives in 32-bit registers; E and F are kept CLAMPED at zero
+// (E' = max(E,0), F' = max(F,0)), which leaves H = max(diag+s, E', F') unchanged and makes the
+// explicit max(.,0) of the reference recurrence (half2_kernels.cuh:176) free.
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+struct Arith;
+
+template <>
+struct Arith<I16X2> {
+    static constexpr bool kPacked = true;
+    static constexpr int kSubjects = 2;
+    static constexpr int kLimit = 25000;  // kernels.cuh:5 MAX_ACC_SHORT
+    // gap scores are <= 0; the packed kernel subtracts magnitudes with unsigned saturation
+    static __host__ __device__ u32 encode_gap(int g) { u32 m = (u32)(-g) & 0xffffu; return m | (m << 16); }
+    static __host__ __device__ u32 encode_score(int s) { return (u32)(uint16_t)(int16_t)s; }
+    static __device__ __forceinline__ u32 add(u32 a, u32 b) {
+        return __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
+    }
+    static __device__ __forceinline__ u32 max2(u32 a, u32 b) {
+        return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+    }
+    static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 f) { return max2(max2(t, e), f); }
+    static __device__ __forceinline__ u32 gap(u32 a, u32 g) {  // max(a + gapscore, 0)
+        return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, g)));
+    }
+    static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return max2(ext, open); }
+    static __device__ __forceinline__ int score_lo(u32 v) { return (int)(int16_t)(v & 0xffffu); }
+    static __device__ __forceinline__ int score_hi(u32 v) { return (int)(int16_t)(v >> 16); }
+};
+
+template <>
+struct Arith<F16X2> {
+    static constexpr bool kPacked = true;
+    static constexpr int kSubjects = 2;
+    static constexpr int kLimit = 2048;  // kernels.cuh:4 MAX_ACC_HALF2
+    static __host__ __device__ u32 half_bits(int v) {
+        // exact conversion of a small integer |v| < 2048 to IEEE binary16 bits
+        if (v == 0) return 0;
+        u32 sign = v < 0 ? 0x8000u : 0u;
+        u32 a = (u32)(v < 0 ? -v : v);
+        int e = 0;
+        while ((a >> (e + 1)) != 0) e++;
+        u32 mant = (a << (10 - e)) & 0x3ffu;
+        return sign | ((u32)(e + 15) << 10) | mant;
+    }
+    static __host__ __device__ u32 encode_gap(int g) { u32 h = half_bits(g); return h | (h << 16); }
+    static __host__ __device__ u32 encode_score(int s) { return half_bits(s); }
+    static __device__ __forceinline__ u32 add(u32 a, u32 b) {
+        return __builtin_bit_cast(u32, (f16x2)(__builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b)));
+    }
+    static __device__ __forceinline__ u32 max3(u32 a, u32 b, u32 c) {
+        return __builtin_bit_cast(u32, __builtin_elementwise_maximum(
+            __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+            __builtin_bit_cast(f16x2, c)));
+    }
+    static __device__ __forceinline__ u32 max2(u32 a, u32 b) {
+        return __builtin_bit_cast(u32, __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)));
+    }
+    static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 f) { return max3(t, e, f); }
+    static __device__ __forceinline__ u32 gap(u32 a, u32 g) { return add(a, g); }  // not clamped yet
+    static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return max3(ext, open, 0u); }
+    static __device__ __forceinline__ int score_lo(u32 v) { return (int)(float)__builtin_bit_cast(f16x2, v).x; }
+    static __device__ __forceinline__ int score_hi(u32 v) { return (int)(float)__builtin_bit_cast(f16x2, v).y; }
+};
+
+template <>
+struct Arith<I32> {
+    static constexpr bool kPacked = false;
+    static constexpr int kSubjects = 1;
+    static constexpr int kLimit = 0x7fffffff;
+    static __host__ __device__ u32 encode_gap(int g) { return (u32)g; }
+    static __host__ __device__ u32 encode_score(int s) { return (u32)s; }
+    static __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+    static __device__ __forceinline__ u32 add(u32 a, u32 b) { return a + b; }
+    static __device__ __forceinline__ u32 max2(u32 a, u32 b) { return (u32)imax((int)a, (int)b); }
+    static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 f) { return (u32)imax(imax((int)t, (int)e), (int)f); }
+    static __device__ __forceinline__ u32 gap(u32 a, u32 g) { return a + g; }
+    static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return (u32)imax(imax((int)ext, (int)open), 0); }
+    static __device__ __forceinline__ int score_lo(u32 v) { return (int)v; }
+    static __device__ __forceinline__ int score_hi(u32) { return 0; }
+};
+
+template <>
+struct Arith<F32> {
+    static constexpr bool kPacked = false;
+    static constexpr int kSubjects = 1;
+    static constexpr int kLimit = 0x7fffffff;
+    static __host__ __device__ u32 encode_gap(int g) { return __builtin_bit_cast(u32, (float)g); }
+    static __host__ __device__ u32 encode_score(int s) { return __builtin_bit_cast(u32, (float)s); }
+    static __device__ __forceinline__ float f(u32 v) { return __builtin_bit_cast(float, v); }
+    static __device__ __forceinline__ u32 u(float v) { return __builtin_bit_cast(u32, v); }
+    static __device__ __forceinline__ u32 add(u32 a, u32 b) { return u(f(a) + f(b)); }
+    static __device__ __forceinline__ u32 max2(u32 a, u32 b) { return u(__builtin_fmaxf(f(a), f(b))); }
+    static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 ff) { return u(__builtin_fmaxf(__builtin_fmaxf(f(t), f(e)), f(ff))); }
+    static __device__ __forceinline__ u32 gap(u32 a, u32 g) { return u(f(a) + f(g)); }
+    static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return u(__builtin_fmaxf(__builtin_fmaxf(f(ext), f(open)), 0.0f)); }
+    static __device__ __forceinline__ int score_lo(u32 v) { return (int)f(v); }
+    static __device__ __forceinline__ int score_hi(u32) { return 0; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Profile tile geometry (shared by the profile builder and the kernel).
+//   NW     32-bit words a lane reads per letter per step (R/2 packed, R scalar)
+//   NCH    16-byte chunks per lane per letter
+//   letter row  = NCH chunks-rows of 256 bytes: chunk k of lane l at  k*256 + l*16
+//   tile        = 21 letter rows, preceded by 16 bytes (lane addresses carry a +16 bias, see Step)
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int R>
+struct Geometry {
+    static constexpr bool kPacked = Arith<KIND>::kPacked;
+    static_assert(!kPacked || (R % 2 == 0), "packed kinds need an even number of rows per lane");
+    static constexpr int NW = kPacked ? R / 2 : R;
+    static constexpr int NCH = (NW + 3) / 4;
+    static constexpr int kRowBytes = NCH * 256;
+    static constexpr int kTileBytes = kLetters * kRowBytes;
+    static constexpr int kStripeRows = kGroup * R;
+    static_assert(kPadLetter * NCH < 256, "letter offset must fit a byte");
+};
+
+struct ScanParams {
+    const int8_t* chars;
+    const uint64_t* offsets;
+    const int32_t* lengths;
+    const int32_t* positions;  // optional indirection list (overflow re-score); nullptr -> first_pos + i
+    const int32_t* count_ptr;  // optional device-side count; nullptr -> n
+    int32_t first_pos;
+    int32_t n;
+    const unsigned char* profile;  // nstripes tiles of Geometry::kTileBytes
+    int32_t nstripes;
+    u32 gop, gex;              // Arith<KIND>::encode_gap
+    float* scores;
+    int32_t* ids;
+    int64_t id_offset;
+    int32_t* ovf_pos;
+    int32_t* ovf_count;
+    int32_t ovf_check;
+    u32* scratch;              // stripe-border spill: per (workgroup, group): H[lcap], F[lcap]
+    int32_t lcap;
+};
+
+template <int NW>
+__device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned char* p) {
+    constexpr int N4 = NW / 4, REM = NW % 4;
+#pragma unroll
+    for (int k = 0; k < N4; k++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + k * 256);
+        dst[4 * k + 0] = v.x; dst[4 * k + 1] = v.y; dst[4 * k + 2] = v.z; dst[4 * k + 3] = v.w;
+    }
+    if constexpr (REM == 1) {
+        dst[4 * N4] = *reinterpret_cast<const u32*>(p + N4 * 256);
+    } else if constexpr (REM == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p + N4 * 256);
+        dst[4 * N4] = v.x; dst[4 * N4 + 1] = v.y;
+    } else if constexpr (REM == 3) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p + N4 * 256);
+        dst[4 * N4] = v.x; dst[4 * N4 + 1] = v.y;
+        dst[4 * N4 + 2] = *reinterpret_cast<const u32*>(p + N4 * 256 + 8);
+    }
+}
+
+// Per-group DP state that lives across the steps of one stripe.
+template <int KIND, int R>
+struct StripeState {
+    u32 H[R];      // H(row, column-1)
+    u32 E[R];      // horizontal gap state entering the current column (clamped)
+    u32 upH_prev;  // H(row0-1, column-1): diagonal input of the lane's first row
+    u32 Hlast;     // H of the lane's bottom row after the last step
+    u32 Fout;      // vertical gap state leaving the lane's bottom row after the last step
+    u32 yA, yB;    // LDS byte address (+16 bias) of the lane's chunk for the current letter(s)
+    u32 maxv;
+};
+
+// One anti-diagonal step of one lane: R cells (or R cell pairs).
+//   BYTE    which byte of the letter words feeds lane 0 in this step
+//   MULTI   stripe borders in play (lane 0 reads the previous stripe's row, lane 15 collects its own)
+template <int KIND, int R, int BYTE, bool MULTI>
+__device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned char* tile,
+                                        u32 lettersA, u32 lettersB, u32 gop, u32 gex,
+                                        u32& inH, u32& inF, u32& outH, u32& outF) {
+    using A = Arith<KIND>;
+    using G = Geometry<KIND, R>;
+    constexpr u32 kSel = 0x0c0c000cu | ((u32)BYTE << 8);  // letter byte BYTE -> bits 15:8 (= offset/256)
+
+    // subject letter(s): shift along the row, lane 0 takes the next letter of its subject
+    const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel);
+    st.yA = dpp<DPP_ROW_SHR1, false>(injA, st.yA) + 16u;
+    u32 wa[G::NW];
+    lds_read_words<G::NW>(wa, tile + st.yA);
+    u32 wb[G::NW];
+    if constexpr (A::kPacked) {
+        const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel);
+        st.yB = dpp<DPP_ROW_SHR1, false>(injB, st.yB) + 16u;
+        lds_read_words<G::NW>(wb, tile + st.yB);
+    }
+
+    // row above the lane's first row: from the neighbouring lane, or from the stripe border
+    u32 upH, F;
+    if constexpr (MULTI) {
+        upH = dpp<DPP_ROW_SHR1, false>(inH, st.Hlast);
+        F = dpp<DPP_ROW_SHR1, false>(inF, st.Fout);
+        inH = dpp<DPP_ROW_SHL1, true>(0u, inH);
+        inF = dpp<DPP_ROW_SHL1, true>(0u, inF);
+    } else {
+        upH = dpp<DPP_ROW_SHR1, true>(0u, st.Hlast);
+        F = dpp<DPP_ROW_SHR1, true>(0u, st.Fout);
+    }
+    u32 diag = st.upH_prev;
+    st.upH_prev = upH;
+
+    u32 maxv = st.maxv;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        u32 s;
+        if constexpr (A::kPacked) {
+            // (score of subject A, score of subject B) for query row r
+            s = __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+        } else {
+            s = wa[r];
+        }
+        const u32 t = A::add(diag, s);
+        diag = st.H[r];
+        const u32 h = A::cell_h(t, st.E[r], F);
+        const u32 hg = A::gap(h, gop);
+        st.E[r] = A::gap_state(A::gap(st.E[r], gex), hg);
+        F = A::gap_state(A::gap(F, gex), hg);
+        st.H[r] = h;
+        maxv = A::max2(maxv, h);
+    }
+    st.maxv = maxv;
+    st.Hlast = st.H[R - 1];
+    st.Fout = F;
+    if constexpr (MULTI) {
+        // lane 15 appends its border values; the 16-wide window slides towards lane 0
+        outH = dpp<DPP_ROW_SHL1, false>(st.Hlast, outH);
+        outF = dpp<DPP_ROW_SHL1, false>(st.Fout, outF);
+    }
+}
+
+// Copy one profile tile (global, L2-resident) into LDS.  The tile starts 16 bytes into the LDS
+// array because lane addresses carry a +16 bias (lane 0 injects `offset`, lanes >0 add 16 per hop).
+template <int TILE_BYTES>
+__device__ __forceinline__ void load_tile(unsigned char* lds, const unsigned char* gsrc) {
+    static_assert(TILE_BYTES % 16 == 0, "tile must be 16-byte granular");
+    const uint4* src = reinterpret_cast<const uint4*>(gsrc);
+    uint4* dst = reinterpret_cast<uint4*>(lds + 16);
+    for (int i = threadIdx.x; i < TILE_BYTES / 16; i += kThreads) dst[i] = src[i];
+}
+
+template <int KIND>
+__device__ __forceinline__ u32 row_max(u32 v) {
+    using A = Arith<KIND>;
+    v = A::max2(v, dpp<0x128, false>(v, v));  // row_ror:8
+    v = A::max2(v, dpp<0x124, false>(v, v));  // row_ror:4
+    v = A::max2(v, dpp<0x122, false>(v, v));  // row_ror:2
+    v = A::max2(v, dpp<0x121, false>(v, v));  // row_ror:1
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The scan kernel.  Persistent workgroups stride over batches of 16 groups (32 or 16 subjects),
+// longest subjects first.  MULTI == the query needs more than one stripe.
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int R, bool MULTI>
+__global__ void __launch_bounds__(kThreads) sw_scan_kernel(const ScanParams p) {
+    using A = Arith<KIND>;
+    using G = Geometry<KIND, R>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[16 + G::kTileBytes];
+
+    const int tid = threadIdx.x;
+    const int lane16 = tid & (kGroup - 1);
+    const int group = tid >> 4;
+    const int n = p.count_ptr ? *p.count_ptr : p.n;
+    constexpr int kSubjPerBatch = kGroupsPerWg * A::kSubjects;
+    const int nbatches = (n + kSubjPerBatch - 1) / kSubjPerBatch;
+    if ((int)blockIdx.x >= nbatches) return;  // workgroup-uniform (device-side count of the re-score path)
+
+    if constexpr (!MULTI) {
+        load_tile<G::kTileBytes>(lds, p.profile);
+        __syncthreads();
+    }
+
+    u32* const borderH = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroupsPerWg + group) * 2 * (size_t)p.lcap : nullptr;
+    u32* const borderF = MULTI ? borderH + p.lcap : nullptr;
+
+    for (int b = blockIdx.x; b < nbatches; b += gridDim.x) {
+        const int batch = nbatches - 1 - b;  // DB is length-sorted ascending: longest first
+        const int i0 = batch * kSubjPerBatch + group * A::kSubjects;
+        const int i1 = i0 + 1;
+        const bool valid0 = i0 < n;
+        const bool valid1 = A::kPacked && (i1 < n);
+        int pos0 = 0, pos1 = 0, len0 = 0, len1 = 0;
+        const int8_t* s0 = p.chars;
+        const int8_t* s1 = p.chars;
+        if (valid0) {
+            pos0 = p.positions ? p.positions[i0] : p.first_pos + i0;
+            len0 = p.lengths[pos0];
+            s0 = p.chars + (p.offsets[pos0] - p.offsets[0]);
+        }
+        if (valid1) {
+            pos1 = p.positions ? p.positions[i1] : p.first_pos + i1;
+            len1 = p.lengths[pos1];
+            s1 = p.chars + (p.offsets[pos1] - p.offsets[0]);
+        }
+        int lmax = len0 > len1 ? len0 : len1;
+        lmax = max(lmax, __shfl_xor(lmax, 16));
+        lmax = max(lmax, __shfl_xor(lmax, 32));
+        // lane 15 finishes column lmax-1 at step lmax+14
+        int nquads = (lmax + kGroup - 1 + 3) >> 2;
+        if constexpr (MULTI) nquads = (nquads + 3) & ~3;  // whole 16-step border blocks
+        const int len0pad = (len0 + 3) & ~3, len1pad = (len1 + 3) & ~3;
+
+        u32 maxv = 0;
+        for (int stripe = 0; stripe < p.nstripes; stripe++) {
+            const bool first = stripe == 0;
+            const bool last = stripe == p.nstripes - 1;
+            if constexpr (MULTI) {
+                __syncthreads();
+                load_tile<G::kTileBytes>(lds, p.profile + (size_t)stripe * G::kTileBytes);
+                __syncthreads();
+            }
+            StripeState<KIND, R> st;
+#pragma unroll
+            for (int r = 0; r < R; r++) { st.H[r] = 0; st.E[r] = 0; }
+            st.upH_prev = 0; st.Hlast = 0; st.Fout = 0; st.maxv = maxv;
+            st.yA = ((u32)(kPadLetter * G::NCH) << 8) + 16u * (u32)(lane16 + 1);
+            st.yB = st.yA;
+
+            // subject letters: lane l holds letters 64*blk + 4l .. +3 of each subject, premultiplied
+            // by NCH so that a byte is the letter row offset / 256
+            auto fetch = [&](const int8_t* s, int lenpad, int blk) -> u32 {
+                const int j = blk * 64 + lane16 * 4;
+                u32 w = 0x14141414u;
+                if (j < lenpad) w = *reinterpret_cast<const u32*>(s + j);
+                return w * (u32)G::NCH;
+            };
+            u32 nextA = fetch(s0, len0pad, 0);
+            u32 nextB = A::kPacked ? fetch(s1, len1pad, 0) : 0u;
+            u32 lettersA = 0, lettersB = 0;
+
+            // stripe-border windows (MULTI only)
+            u32 inH = 0, inF = 0, outH = 0, outF = 0, nextInH = 0, nextInF = 0;
+            const int written = nquads * 4 - (kGroup - 1);  // columns [0, written) were spilled by the previous stripe
+            auto fetch_border = [&](int blk16) {
+                const int col = blk16 * 16 + lane16;
+                nextInH = 0; nextInF = 0;
+                if (!first && col < written) { nextInH = borderH[col]; nextInF = borderF[col]; }
+            };
+            if constexpr (MULTI) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                fetch_border(0);
+            }
+
+            for (int q = 0; q < nquads; q++) {
+                if ((q & 15) == 0) {
+                    lettersA = nextA; lettersB = nextB;
+                    nextA = fetch(s0, len0pad, (q >> 4) + 1);
+                    if constexpr (A::kPacked) nextB = fetch(s1, len1pad, (q >> 4) + 1);
+                }
+                if constexpr (MULTI) {
+                    if ((q & 3) == 0) {
+                        inH = nextInH; inF = nextInF;
+                        fetch_border((q >> 2) + 1);
+                    }
+                }
+                dp_step<KIND, R, 0, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, inH, inF, outH, outF);
+                dp_step<KIND, R, 1, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, inH, inF, outH, outF);
+                dp_step<KIND, R, 2, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, inH, inF, outH, outF);
+                dp_step<KIND, R, 3, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, inH, inF, outH, outF);
+                lettersA = dpp<DPP_ROW_SHL1, true>(0u, lettersA);
+                if constexpr (A::kPacked) lettersB = dpp<DPP_ROW_SHL1, true>(0u, lettersB);
+                if constexpr (MULTI) {
+                    if ((q & 3) == 3 && !last) {
+                        // after step t (0-based) lane l holds column t + l - 30 ... here t = 4q+3
+                        const int col = 4 * q + 3 + lane16 - 2 * (kGroup - 1);
+                        if (col >= 0) { borderH[col] = outH; borderF[col] = outF; }
+                    }
+                }
+            }
+            maxv = st.maxv;
+            if constexpr (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
+
+        maxv = row_max<KIND>(maxv);
+        if (lane16 == 0) {
+            const int sc0 = A::score_lo(maxv);
+            const int sc1 = A::score_hi(maxv);
+            if (valid0) {
+                if (A::kPacked && p.ovf_check && sc0 >= A::kLimit) {
+                    p.ovf_pos[atomicAdd(p.ovf_count, 1)] = pos0;
+                } else {
+                    p.scores[pos0] = (float)sc0;
+                }
+                p.ids[pos0] = (int32_t)(p.id_offset + pos0);
+            }
+            if (valid1) {
+                if (p.ovf_check && sc1 >= A::kLimit) {
+                    p.ovf_pos[atomicAdd(p.ovf_count, 1)] = pos1;
+                } else {
+                    p.scores[pos1] = (float)sc1;
+                }
+                p.ids[pos1] = (int32_t)(p.id_offset + pos1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Profile builder: tile[stripe][letter][chunk][lane][4 words] from the encoded query and the matrix.
+// Replaces the per-block pair-table construction of the reference (half2_kernels.cuh:57-65).
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int R>
+__global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_t qlen,
+                                        const int8_t* __restrict__ matrix21, int32_t nstripes,
+                                        unsigned char* __restrict__ profile) {
+    using A = Arith<KIND>;
+    using G = Geometry<KIND, R>;
+    constexpr int kWordsPerRow = G::kRowBytes / 4;
+    const int total = nstripes * kLetters * kWordsPerRow;
+    u32* out = reinterpret_cast<u32*>(profile);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int word = i % kWordsPerRow;
+        const int letter = (i / kWordsPerRow) % kLetters;
+        const int stripe = i / (kWordsPerRow * kLetters);
+        const int chunk = word / 64, lane = (word % 64) / 4, sub = word % 4;
+        const int w = chunk * 4 + sub;  // word index within the lane's NW words
+        u32 v = 0;
+        if (w < G::NW) {
+            auto entry = [&](int row_in_lane) -> u32 {
+                const int row = stripe * G::kStripeRows + lane * R + row_in_lane;
+                const int qc = row < qlen ? (int)query[row] : kPadLetter;
+                return A::encode_score((int)matrix21[qc * kLetters + letter]);
+            };
+            if constexpr (A::kPacked) v = entry(2 * w) | (entry(2 * w + 1) << 16);
+            else v = entry(w);
+        }
+        out[i] = v;
+    }
+}
+
+}  // namespace swk

@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference's search driver (class CudaSW4, cudasw4.cuh:496-839) on top of
+the C ABI.  PyTorch is used only for device memory, streams and (in bench.py) torch.distributed.
+
+    db = DeviceDB.from_arrays(chars, offsets, lengths, device=0)      # setDatabase + prefetchDBToGpus
+    s = Searcher(device=0, num_top=10, matrix=blosum62_21x21)         # CudaSW4(...)
+    s.set_database(db)
+    res = s.scan(query_codes)                                         # CudaSW4::scan -> ScanResult
+
+Every score is computed by libcudasw4_amd.so; nothing here computes alignments on the CPU.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import capi
+
+# length_partitions.hpp:75-113 (restated; tests compare it with the reference's table)
+PARTITION_BOUNDARIES = np.array(
+    [48, 64] + list(range(80, 257, 16)) + list(range(288, 513, 32)) + list(range(576, 1281, 64)) + [8000, 2**31 - 2],
+    dtype=np.int64)
+NUM_PARTITIONS = len(PARTITION_BOUNDARIES)
+assert NUM_PARTITIONS == 36
+
+
+@dataclass
+class KernelTypeConfig:
+    """options.hpp:22-25 / cudasw4.cuh:841-855: which arithmetic kind handles which partitions."""
+    single_pass: int = capi.KIND_F16X2       # partitions 0..33
+    many_pass_small: int = capi.KIND_F16X2   # partition 34 (1281..8000)
+    many_pass_large: int = capi.KIND_F32     # partition 35 (> 8000)
+    overflow: int = capi.KIND_F32            # re-score of packed overflows
+
+    @staticmethod
+    def dpx():  # options.cpp:196-201 (--dpx)
+        return KernelTypeConfig(capi.KIND_I16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_I32)
+
+    def validate(self):
+        if self.many_pass_small not in (capi.KIND_F16X2, capi.KIND_I16X2):
+            raise ValueError("manyPassType_small must be Half2 or DPXs16 (cudasw4.cuh:847-849)")
+        if self.many_pass_large not in (capi.KIND_F32, capi.KIND_I32):
+            raise ValueError("manyPassType_large must be Float or DPXs32 (cudasw4.cuh:850-852)")
+        if self.overflow not in (capi.KIND_F32, capi.KIND_I32):
+            raise ValueError("overflowType must be Float or DPXs32 (cudasw4.cuh:853-855)")
+
+    def kind_for_partition(self, part_id):
+        if part_id < NUM_PARTITIONS - 2:
+            return self.single_pass
+        return self.many_pass_small if part_id == NUM_PARTITIONS - 2 else self.many_pass_large
+
+
+@dataclass
+class ScanResult:
+    """cudasw4.cuh:82-86 ScanResult + BenchmarkStats."""
+    scores: np.ndarray
+    reference_ids: np.ndarray
+    num_overflows: int = 0
+    seconds: float = 0.0
+    gcups: float = 0.0
+    stats: dict = field(default_factory=dict)
+
+
+def sort_db_by_length(chars, offsets, lengths):
+    """makedb.cpp:188-195 sorts subjects by length; returns (chars, offsets, lengths, original_ids)."""
+    lengths = np.asarray(lengths, dtype=np.int32)
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    order = np.argsort(lengths, kind="stable")
+    padded = (lengths.astype(np.int64) + 3) // 4 * 4
+    new_off = np.zeros(len(lengths) + 1, dtype=np.uint64)
+    new_off[1:] = np.cumsum(padded[order])
+    new_chars = np.full(int(new_off[-1]), 20, dtype=np.int8)
+    chars = np.asarray(chars, dtype=np.int8)
+    for k, i in enumerate(order):
+        a = int(offsets[i] - offsets[0])
+        new_chars[int(new_off[k]):int(new_off[k]) + int(lengths[i])] = chars[a:a + int(lengths[i])]
+    return new_chars, new_off, lengths[order].copy(), order.astype(np.int64)
+
+
+class DeviceDB:
+    """A DB (shard) resident in HBM, in dbdata layout, sorted by ascending length.
+
+    Mirrors GpuWorkingSet's cached-DB buffers (cudasw4.cuh:251-321) and the per-partition subject
+    counts of computeTotalNumSequencePerLengthPartition (cudasw4.cuh:904-926)."""
+
+    def __init__(self, chars_t, offsets_t, lengths_t, lengths_host, id_offset=0):
+        self.chars = chars_t
+        self.offsets = offsets_t
+        self.lengths = lengths_t
+        self.device = chars_t.device
+        self.num_sequences = int(lengths_t.numel())
+        self.id_offset = int(id_offset)
+        lh = np.asarray(lengths_host, dtype=np.int64)
+        if len(lh) > 1 and np.any(np.diff(lh) < 0):
+            raise ValueError("DB must be sorted by ascending length (makedb does this)")
+        self.lengths_host = lh
+        self.total_residues = int(lh.sum())
+        # partition i holds lengths in (b[i-1], b[i]]  (length_partitions.hpp:11)
+        ends = np.searchsorted(lh, PARTITION_BOUNDARIES, side="right")
+        self.part_begin = np.concatenate([[0], ends[:-1]]).astype(np.int64)
+        self.part_end = ends.astype(np.int64)
+        self.max_length = int(lh[-1]) if len(lh) else 0
+
+    @staticmethod
+    def from_arrays(chars, offsets, lengths, device=0, id_offset=0):
+        dev = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        chars = np.ascontiguousarray(chars, dtype=np.int8)
+        pad = (-len(chars)) % 16 + 16  # slack so 4-byte letter loads never leave the allocation
+        chars_t = torch.empty(len(chars) + pad, dtype=torch.int8, device=dev)
+        chars_t[:len(chars)].copy_(torch.from_numpy(chars))
+        chars_t[len(chars):].fill_(20)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        offsets_t = torch.from_numpy(offsets.view(np.int64).copy()).to(dev)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        lengths_t = torch.from_numpy(lengths.copy()).to(dev)
+        return DeviceDB(chars_t, offsets_t, lengths_t, lengths, id_offset)
+
+    @staticmethod
+    def pseudo(num, length, codes, device=0):
+        """PseudoDBdata (dbdata.hpp:222-272): `codes` (one sequence) replicated `num` times, built on
+        the device.  `codes` comes from the caller (the C++ driver / oracle generator)."""
+        dev = torch.device("cuda", device)
+        stride = (length + 3) // 4 * 4
+        one = torch.full((stride,), 20, dtype=torch.int8, device=dev)
+        one[:length].copy_(torch.from_numpy(np.ascontiguousarray(codes[:length], dtype=np.int8)))
+        chars_t = torch.empty(num * stride + 32, dtype=torch.int8, device=dev)
+        chars_t[:num * stride].view(num, stride).copy_(one.unsqueeze(0).expand(num, stride))
+        chars_t[num * stride:].fill_(20)
+        offsets_t = torch.arange(num + 1, dtype=torch.int64, device=dev) * stride
+        lengths_t = torch.full((num,), length, dtype=torch.int32, device=dev)
+        db = DeviceDB.__new__(DeviceDB)
+        db.chars, db.offsets, db.lengths, db.device = chars_t, offsets_t, lengths_t, dev
+        db.num_sequences, db.id_offset = num, 0
+        db.lengths_host = None
+        db.total_residues = num * length
+        pid = int(np.searchsorted(PARTITION_BOUNDARIES, length, side="left"))
+        db.part_begin = np.zeros(NUM_PARTITIONS, dtype=np.int64)
+        db.part_end = np.zeros(NUM_PARTITIONS, dtype=np.int64)
+        db.part_begin[pid + 1:] = num
+        db.part_end[pid:] = num
+        db.max_length = length
+        return db
+
+    def partition_max_length(self, part_id):
+        b, e = int(self.part_begin[part_id]), int(self.part_end[part_id])
+        if e <= b:
+            return 0
+        if self.lengths_host is None:
+            return self.max_length
+        return int(self.lengths_host[e - 1])
+
+
+class Searcher:
+    """CudaSW4 (cudasw4.cuh:496-839) for ONE GPU; multi-GPU = one Searcher per process + host merge."""
+
+    def __init__(self, device=0, num_top=10, matrix=None, kernel_types=None, gop=-11, gex=-1,
+                 max_temp_bytes=4 << 30, merge_partitions=True):
+        self.device = torch.device("cuda", device)
+        self.ctx = capi.Context(device)
+        self.num_top = int(num_top)
+        self.kernel_types = kernel_types or KernelTypeConfig()
+        self.kernel_types.validate()
+        self.gop, self.gex = int(gop), int(gex)
+        self.max_temp_bytes = int(max_temp_bytes)
+        self.merge_partitions = merge_partitions
+        self.db = None
+        if matrix is not None:
+            self.set_matrix(matrix)
+        self._temp = None
+        self._topk_temp = None
+        self.record_kernel_events = False  # bench.py: HIP events around every DP launch
+        self.kernel_events = []
+
+    # -- configuration -------------------------------------------------------------------------
+    def set_matrix(self, m21):  # setBlosum, cudasw4.cuh:570-572 / blosum.cu:21-119
+        self.ctx.set_matrix(m21)
+
+    def set_num_top(self, k):  # cudasw4.cuh:574-587
+        self.num_top = int(k)
+
+    def set_database(self, db):  # cudasw4.cuh:552-568
+        if db.device != self.device:
+            raise ValueError("DB is on %s, searcher on %s" % (db.device, self.device))
+        self.db = db
+        n = db.num_sequences
+        self.scores = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        self.ids = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        self.ovf_pos = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        self.ovf_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._plan = self._launch_plan()
+
+    def _launch_plan(self):
+        """Partition walk of runAlignmentKernels (cudasw4.cuh:1742-2103): largest partition first.
+        Adjacent partitions that use the same arithmetic kind are merged into one launch: the kernels
+        take any subject length, so the partition only decides the kind."""
+        db, kt = self.db, self.kernel_types
+        runs = []
+        for pid in range(NUM_PARTITIONS - 1, -1, -1):
+            b, e = int(db.part_begin[pid]), int(db.part_end[pid])
+            if e <= b:
+                continue
+            kind = kt.kind_for_partition(pid)
+            maxlen = db.partition_max_length(pid)
+            if self.merge_partitions and runs and runs[-1]["kind"] == kind and runs[-1]["begin"] == e:
+                runs[-1]["begin"] = b
+            else:
+                runs.append({"kind": kind, "part_id": pid, "begin": b, "end": e, "maxlen": maxlen})
+        return runs
+
+    def _ensure_temp(self, nbytes):
+        nbytes = min(int(nbytes), self.max_temp_bytes)
+        if nbytes <= 0:
+            return 0, 0
+        if self._temp is None or self._temp.numel() < nbytes:
+            self._temp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._temp.data_ptr(), self._temp.numel()
+
+    # -- the scan ------------------------------------------------------------------------------
+    def scan(self, query_codes, timed=True, sync=True):
+        """CudaSW4::scan (cudasw4.cuh:698-765): all subjects of the resident DB against one query.
+
+        sync=False enqueues the scan and returns without waiting (bench.py's timed region brackets
+        many scans with one synchronize); results are then read with `finish(result)`."""
+        db = self.db
+        if db is None:
+            raise RuntimeError("set_database first")
+        q = np.ascontiguousarray(query_codes, dtype=np.int8)
+        stream = torch.cuda.current_stream(self.device)
+        sp = stream.cuda_stream
+        timed = timed and sync
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+        self.ctx.set_query(q, sp)
+        self.ovf_count.zero_()
+        self.scores.fill_(-1.0)  # cudasw4.cuh:405-409
+        packed_used = False
+        for run in self._plan:
+            kind = run["kind"]
+            n = run["end"] - run["begin"]
+            tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(kind, run["maxlen"]))
+            ovf_check = 1 if kind in capi.MAX_ACC else 0
+            packed_used |= bool(ovf_check)
+            if self.record_kernel_events:
+                k0 = torch.cuda.Event(enable_timing=True)
+                k0.record(stream)
+            self.ctx.scan_partition(kind, run["part_id"], db.chars.data_ptr(), db.offsets.data_ptr(),
+                                    db.lengths.data_ptr(), run["begin"], n, run["maxlen"], self.gop, self.gex,
+                                    self.scores.data_ptr(), self.ids.data_ptr(), db.id_offset,
+                                    self.ovf_pos.data_ptr(), self.ovf_count.data_ptr(), ovf_check, tptr, tbytes, sp)
+            if self.record_kernel_events:
+                k1 = torch.cuda.Event(enable_timing=True)
+                k1.record(stream)
+                cells = float(len(q)) * (float(db.total_residues) if len(self._plan) == 1 else
+                                         float(db.lengths_host[run["begin"]:run["end"]].sum()))
+                self.kernel_events.append((k0, k1, cells))
+        if packed_used:  # cudasw4.cuh:2117-2172
+            okind = self.kernel_types.overflow
+            tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(okind, db.max_length))
+            self.ctx.rescore_overflow(okind, self.ovf_pos.data_ptr(), self.ovf_count.data_ptr(), db.num_sequences,
+                                      db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(),
+                                      db.max_length, self.gop, self.gex, self.scores.data_ptr(), self.ids.data_ptr(),
+                                      db.id_offset, tptr, tbytes, sp)
+        k = min(self.num_top, db.num_sequences)
+        top_scores = top_ids = None
+        if k > 0:  # cudasw4.cuh:1357-1401
+            need = capi.topk_temp_bytes(db.num_sequences, k)
+            if self._topk_temp is None or self._topk_temp.numel() < need:
+                self._topk_temp = torch.empty(need, dtype=torch.uint8, device=self.device)
+            out_s = torch.empty(k, dtype=torch.float32, device=self.device)
+            out_i = torch.empty(k, dtype=torch.int32, device=self.device)
+            self.ctx.topk(self.scores.data_ptr(), self.ids.data_ptr(), db.num_sequences, k, out_s.data_ptr(),
+                          out_i.data_ptr(), self._topk_temp.data_ptr(), self._topk_temp.numel(), sp)
+            top_scores, top_ids = out_s, out_i
+        cells = float(len(q)) * float(db.total_residues)
+        res = ScanResult(scores=np.zeros(0, np.int32), reference_ids=np.zeros(0, np.int64), num_overflows=-1)
+        res.stats = {"cells": cells, "launches": len(self._plan), "_top": (top_scores, top_ids)}
+        if not sync:
+            return res
+        if timed:
+            ev1.record(stream)
+            ev1.synchronize()
+            res.seconds = ev0.elapsed_time(ev1) * 1e-3
+            res.gcups = cells / 1e9 / res.seconds if res.seconds > 0 else 0.0  # cudasw4.cuh:2264-2271
+        else:
+            stream.synchronize()
+        return self.finish(res)
+
+    def finish(self, res):
+        """Copy the top-K of an enqueued scan to the host (D2H of cudasw4.cuh:1465-1487).  Only valid
+        before the next scan reuses the overflow counter."""
+        top_scores, top_ids = res.stats.pop("_top", (None, None))
+        if top_scores is not None:
+            res.scores = top_scores.cpu().numpy().astype(np.int32)
+            res.reference_ids = top_ids.cpu().numpy().astype(np.int64)
+        res.num_overflows = int(self.ovf_count.item())
+        return res
+
+    def all_scores(self):
+        """Every subject's score of the last scan (the CUDASW_DEBUG_CHECK_CORRECTNESS view,
+        cudasw4.cuh:728-756)."""
+        return self.scores[:self.db.num_sequences].cpu().numpy().astype(np.int32)
+
+
+def merge_topk(per_rank, k):
+    """Host-side merge of per-GPU top-K lists (replaces the peer-copy gather + sort on device 0,
+    cudasw4.cuh:1415-1463).  per_rank: list of (scores, global_ids); score desc, id asc on ties."""
+    if not per_rank:
+        return np.zeros(0, np.int32), np.zeros(0, np.int64)
+    s = np.concatenate([np.asarray(a, dtype=np.int64) for a, _ in per_rank])
+    i = np.concatenate([np.asarray(b, dtype=np.int64) for _, b in per_rank])
+    order = np.lexsort((i, -s))[:k]
+    return s[order].astype(np.int32), i[order]

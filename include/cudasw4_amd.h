@@ -1,0 +1,133 @@
+/* cudasw4_amd.h — C ABI of libcudasw4_amd.so: the MI355X (gfx950) Smith-Waterman DP hot path.
+ *
+ * Drop-in boundary for the kernel layer of CUDASW++4.0 (reference files cited per entry point;
+ * paths relative to the reference's src/).  The reference boundary is a C++ template API
+ * (kernels.cuh:31-164 — call_NW_local_affine_{single,multi}_pass_{half2,dpx_s16,dpx_s32,float} and
+ * the two overflow launchers) plus setProgramWideBlosum (blosum.hpp:26).  This library exposes the
+ * same operations with plain pointers and sizes:
+ *
+ *   - every pointer marked DEVICE is a device pointer on the context's device;
+ *   - the caller owns every buffer, nothing is allocated inside the scan entry points
+ *     (the context owns only the substitution matrix and the per-query profile);
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 on success, a negative SW_ERR_* otherwise; nothing throws across the ABI;
+ *   - one host thread per context; different contexts (devices) may be driven from one thread
+ *     in turn, exactly like the reference's cudaSetDevice loops (cudasw4.cuh:1509-1524).
+ *
+ * Scores are the reference's: affine-gap local alignment (H = max(0, diag+M, E, F)), score only,
+ * written as float next to the subject's global id (util.cuh:159-192 BatchResultList).
+ */
+#ifndef CUDASW4_AMD_H
+#define CUDASW4_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Arithmetic kinds == the reference's KernelType (types.hpp:11-16), same order. */
+enum {
+    SW_KIND_F16X2 = 0, /* Half2  : two subjects per lane group, packed fp16, exact below 2048  (half2_kernels.cuh)   */
+    SW_KIND_I16X2 = 1, /* DPXs16 : two subjects per lane group, packed int16, exact below 25000 (dpx_s16_kernels.cuh) */
+    SW_KIND_I32   = 2, /* DPXs32 : one subject per lane group, int32                            (dpx_s32_kernels.cuh) */
+    SW_KIND_F32   = 3  /* Float  : one subject per lane group, fp32, exact below 2^24           (float_kernels.cuh)   */
+};
+
+enum {
+    SW_OK = 0,
+    SW_ERR_INVALID = -1,   /* bad argument (null pointer, unknown kind, positive gap score, ...) */
+    SW_ERR_HIP = -2,       /* a HIP runtime call failed; sw_last_error() has the text */
+    SW_ERR_NO_QUERY = -3,  /* scan before sw_set_query */
+    SW_ERR_NO_MATRIX = -4, /* scan before sw_set_matrix */
+    SW_ERR_TEMP = -5,      /* temp buffer too small for this query/partition (see sw_scan_temp_bytes) */
+    SW_ERR_NO_DEVICE = -6  /* no usable HIP device: the library never falls back to a CPU path */
+};
+
+/* kernels.cuh:4-5 — MAX_ACC_HALF2 / MAX_ACC_SHORT: a packed score at or above these is an overflow. */
+#define SW_MAX_ACC_F16 2048
+#define SW_MAX_ACC_I16 25000
+
+/* length_partitions.hpp:75-113 */
+#define SW_NUM_LENGTH_PARTITIONS 36
+
+typedef struct sw_ctx sw_ctx;
+
+/* Library/version probe that needs no GPU. */
+const char* sw_version(void);
+/* Text of the last error on the calling thread (never NULL). */
+const char* sw_last_error(void);
+/* hipGetDeviceCount; 0 when there is no GPU. */
+int sw_device_count(void);
+
+/* Per-device context.  Replaces the reference's per-GPU program-wide state
+ * (__constant__ deviceBlosum, blosum.cu:9-11; d_query, cudasw4.cuh:305-306). */
+int sw_ctx_create(int device, sw_ctx** out);
+int sw_ctx_destroy(sw_ctx* ctx);
+
+/* setProgramWideBlosum (blosum.hpp:26, blosum.cu:21-119): install a dim x dim substitution matrix
+ * (HOST pointer, row-major int8; dim 21 = 20 amino acids + "other").  The last row/column must be
+ * negative: padding is scored with it (half2_kernels.cuh:251-257, cudasw4.cuh:1298). */
+int sw_set_matrix(sw_ctx* ctx, const int8_t* matrix_host, int dim);
+
+/* CudaSW4::setQuery (cudasw4.cuh:1280-1310): install the encoded query (HOST pointer, codes
+ * 0..dim-1).  Builds the device-side query profile the kernels read (lazily, per kind). */
+int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void* stream);
+
+/* Bytes of temp memory sw_scan_partition / sw_rescore_overflow need for the CURRENT query with
+ * subjects up to max_subject_len (0 when the query fits one stripe).  Replaces the reference's
+ * tempBytesPerBlockPerBuffer / tempBytesPerSubjectPerBuffer sizing (cudasw4.cuh:1928-1938,2028-2033). */
+size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int32_t max_subject_len);
+
+/* One length partition of one batch: replaces call_NW_local_affine_{single,multi}_pass_*
+ * (kernels.cuh:31-164; dispatch cudasw4.cuh:1764-1912,1920-2096).
+ *
+ *   kind            SW_KIND_*
+ *   part_id         reference length-partition index 0..35 (informational; any subject length works)
+ *   chars           DEVICE int8 codes, each subject padded to a multiple of 4 (dbdata layout)
+ *   offsets         DEVICE uint64[>= first_pos+n+1]; offsets[i]-offsets[0] = byte offset of subject i
+ *   lengths         DEVICE int32 true lengths
+ *   first_pos, n    subjects first_pos .. first_pos+n-1 (batch-local positions, the reference's
+ *                   counting PositionsIterator, kernels.cuh:28)
+ *   max_subject_len upper bound of lengths[first_pos .. first_pos+n)
+ *   gop, gex        gap open / extend scores, both <= 0 (reference: -11 / -1)
+ *   scores, ids     DEVICE, indexed by position: scores[pos] = score, ids[pos] = id_offset + pos
+ *   ovf_pos/count   DEVICE; when ovf_check != 0 a subject whose packed score reaches the kind's
+ *                   limit is appended to ovf_pos[atomicAdd(ovf_count,1)] and its score is left
+ *                   untouched (half2_kernels.cuh:1087-1109).  Ignored for the 32-bit kinds.
+ *   temp            DEVICE scratch of at least sw_scan_temp_bytes() (may be NULL when that is 0)
+ */
+int sw_scan_partition(sw_ctx* ctx, int kind, int part_id,
+                      const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
+                      int32_t first_pos, int32_t n, int32_t max_subject_len,
+                      int gop, int gex,
+                      float* scores, int32_t* ids, int64_t id_offset,
+                      int32_t* ovf_pos, int32_t* ovf_count, int ovf_check,
+                      void* temp, size_t temp_bytes, void* stream);
+
+/* launch_process_overflow_alignments_kernel_NW_local_affine_multi_pass_{float,dpx_s32}
+ * (float_kernels.cuh:1189-1318, dpx_s32_kernels.cuh:1182-1290; call site cudasw4.cuh:2134-2169):
+ * re-score the subjects listed in ovf_pos[0 .. *ovf_count) with a 32-bit kind.  The count is read
+ * on the device; no host round trip and no device-side launch. */
+int sw_rescore_overflow(sw_ctx* ctx, int kind /* SW_KIND_I32 | SW_KIND_F32 */,
+                        const int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
+                        const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
+                        int32_t max_subject_len, int gop, int gex,
+                        float* scores, int32_t* ids, int64_t id_offset,
+                        void* temp, size_t temp_bytes, void* stream);
+
+/* Per-GPU top-K (cudasw4.cuh:1357-1401): the k best (score desc, id asc on ties) of n results.
+ * out_scores/out_ids: DEVICE, k entries, padded with (-1, -1) when n < k.
+ * temp: DEVICE scratch of sw_topk_temp_bytes(n, k). */
+size_t sw_topk_temp_bytes(int64_t n, int k);
+int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int k,
+            float* out_scores, int32_t* out_ids, void* temp, size_t temp_bytes, void* stream);
+
+/* Introspection for tests / tuning: rows per lane and number of query stripes chosen for qlen. */
+int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstripes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDASW4_AMD_H */

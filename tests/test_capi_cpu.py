@@ -1,0 +1,97 @@
+"""CPU: the C-ABI library loads, exports every declared symbol and fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = O.ROOT
+
+
+def _lib_path():
+    return os.path.join(ROOT, "cudasw4_amd", "lib", "libcudasw4_amd.so")
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(_lib_path()):
+        import __graft_entry__ as g
+        g.build()
+    return _lib_path()
+
+
+def test_header_symbols_are_exported(built):
+    header = open(os.path.join(ROOT, "include", "cudasw4_amd.h")).read()
+    declared = set(re.findall(r"\b(sw_[a-z_0-9]+)\s*\(", header))
+    declared.discard("sw_ctx")
+    from cudasw4_amd import capi
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    lib = ctypes.CDLL(built)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_version_and_plan_without_gpu(built):
+    from cudasw4_amd import capi
+    assert "gfx950" in capi.version()
+    for kind in (capi.KIND_F16X2, capi.KIND_I16X2):
+        for q in (1, 63, 64, 65, 144, 512, 513, 5478, 40000):
+            r, s = capi.plan_query(kind, q)
+            assert r % 4 == 0 and 4 <= r <= 32 and 16 * r * s >= q
+            assert s == (q + 511) // 512
+    for kind in (capi.KIND_I32, capi.KIND_F32):
+        for q in (1, 256, 257, 5478):
+            r, s = capi.plan_query(kind, q)
+            assert r % 4 == 0 and 4 <= r <= 16 and 16 * r * s >= q
+    with pytest.raises(capi.SwError):
+        capi.plan_query(7, 100)
+
+
+def test_no_cpu_fallback(built):
+    """Without a GPU the product must fail loudly, never compute on the CPU."""
+    import torch
+    from cudasw4_amd import capi
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert capi.device_count() == 0
+    with pytest.raises(capi.SwError) as ei:
+        capi.Context(0)
+    assert ei.value.code == -6
+
+
+def test_partition_table_matches_reference():
+    from cudasw4_amd import search
+    g = O.golden("ref_tables.json")
+    assert search.PARTITION_BOUNDARIES.tolist() == g["partition_boundaries"]
+
+
+def test_kernel_type_validation():
+    from cudasw4_amd import search, capi
+    K = search.KernelTypeConfig
+    K().validate()
+    K.dpx().validate()
+    with pytest.raises(ValueError):
+        K(many_pass_small=capi.KIND_F32).validate()
+    with pytest.raises(ValueError):
+        K(many_pass_large=capi.KIND_F16X2).validate()
+    with pytest.raises(ValueError):
+        K(overflow=capi.KIND_I16X2).validate()
+    k = K()
+    assert k.kind_for_partition(0) == capi.KIND_F16X2 and k.kind_for_partition(35) == capi.KIND_F32
+
+
+def test_sort_db_and_merge_topk():
+    from cudasw4_amd import search
+    rng = np.random.default_rng(3)
+    seqs = [rng.integers(0, 20, int(l)).astype(np.int8) for l in (9, 3, 7, 3, 12)]
+    chars, offsets, lengths = O.make_db(seqs)
+    sc, so, sl, order = search.sort_db_by_length(chars, offsets, lengths)
+    assert sl.tolist() == [3, 3, 7, 9, 12] and order.tolist() == [1, 3, 2, 0, 4]
+    for k, i in enumerate(order):
+        np.testing.assert_array_equal(sc[int(so[k]):int(so[k]) + int(sl[k])], seqs[i])
+    assert all(int(o) % 4 == 0 for o in so)
+    s, i = search.merge_topk([([9, 5, 5], [4, 1, 7]), ([9, 6], [2, 11])], 4)
+    assert s.tolist() == [9, 9, 6, 5] and i.tolist() == [2, 4, 11, 1]

@@ -1,0 +1,164 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle / the reference's golden vectors.
+
+Bar: bit-exact integer scores for every kind (the half2/float kinds hold integers exactly below
+2048 / 2^24 and hand anything larger to the 32-bit re-score, so they are bit-exact too)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_util import gpu_modules, scan_all_scores, kinds_configs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_sees_gpu():
+    torch, capi, search = gpu_modules()
+    assert capi.device_count() >= 1
+    ctx = capi.Context(0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg", ["half2+float", "dpxs16+dpxs32", "dpxs32", "float"])
+def test_golden_pairs_all_kinds(cfg):
+    torch, capi, search = gpu_modules()
+    g = O.golden("ref_scores.json")
+    kt = kinds_configs(search, capi)[cfg]
+    for p in g["pairs"]:
+        q = np.array(p["q"], dtype=np.int8)
+        s = np.array(p["s"], dtype=np.int8)
+        db = O.make_db([s])
+        got, res, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, gop=p.get("gop", -11), gex=p.get("gex", -1))
+        assert got.tolist() == [p["score"]], (cfg, len(q), len(s), res.num_overflows)
+
+
+@pytest.mark.parametrize("cfg", ["half2+float", "dpxs16+dpxs32", "dpxs32", "float"])
+@pytest.mark.parametrize("merge", [True, False])
+def test_allvsall_matches_reference_dp(cfg, merge):
+    """20 x 20 of allqueries.fasta: single-stripe and multi-stripe queries, packed overflow
+    (>= 2048 fp16, >= 25000 int16) with 32-bit re-score, partitions 6..34."""
+    torch, capi, search = gpu_modules()
+    g = O.golden("ref_scores.json")
+    _, qs = O.load_queries()
+    db = O.make_db(qs)
+    kt = kinds_configs(search, capi)[cfg]
+    expect = np.array(g["allvsall"], dtype=np.int32)
+    for i, q in enumerate(qs):
+        got, res, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, merge=merge)
+        assert got.tolist() == expect[i].tolist(), (cfg, i)
+        if cfg == "half2+float":
+            assert res.num_overflows == int((expect[i] >= 2048).sum())
+        if cfg == "dpxs16+dpxs32":
+            assert res.num_overflows == int((expect[i] >= 25000).sum())
+
+
+@pytest.mark.parametrize("cfg", ["half2+float", "dpxs16+dpxs32", "dpxs32", "float"])
+def test_pseudo_db_matches_reference_dp(cfg):
+    torch, capi, search = gpu_modules()
+    g = O.golden("ref_scores.json")
+    _, qs = O.load_queries()
+    kt = kinds_configs(search, capi)[cfg]
+    s = search.Searcher(device=0, num_top=0, matrix=O.blosum21(62), kernel_types=kt)
+    for L, expect in g["pseudo"].items():
+        L = int(L)
+        db = search.DeviceDB.pseudo(999, L, O.pseudodb_codes(L, 42), device=0)  # odd count: tail handling
+        s.set_database(db)
+        for qi, q in enumerate(qs):
+            s.scan(q)
+            sc = s.all_scores()
+            assert sc.min() == sc.max() == expect[qi], (cfg, L, qi)
+
+
+def test_long_subject_partition35():
+    torch, capi, search = gpu_modules()
+    g = O.golden("ref_scores.json")["long_subject"]
+    _, qs = O.load_queries()
+    subj = np.concatenate([qs[i] for i in g["concat_of_queries"]])
+    db = O.make_db([qs[0], subj, qs[3]])
+    for cfg, kt in kinds_configs(search, capi).items():
+        for qi in (0, 7, 12, 19):
+            got, _, _ = scan_all_scores(search, capi, db, qs[qi], kernel_types=kt)
+            assert got[1] == g["scores"][qi], (cfg, qi)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_ragged_db_vs_oracle(seed):
+    """Ragged lengths incl. 1-residue and > 1280 subjects, unknown letters (code 20), odd subject
+    count, query lengths around the stripe borders, other matrices and gap scores."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(seed)
+    n = 777
+    lens = np.concatenate([rng.integers(1, 60, 200), rng.integers(60, 700, 500), rng.integers(700, 3000, 77)])
+    seqs = [rng.integers(0, 21 if i % 5 == 0 else 20, int(l)).astype(np.int8) for i, l in enumerate(lens)]
+    # plant homologs of the query so that scores are not all tiny
+    qlen = [16, 64, 65, 191, 192, 193, 500, 512, 513, 1025, 1500][seed * 3:seed * 3 + 5]
+    db = O.make_db(seqs)
+    assert len(seqs) == n
+    for ql in qlen:
+        q = rng.integers(0, 20, ql).astype(np.int8)
+        seqs2 = list(seqs)
+        seqs2[5] = np.concatenate([rng.integers(0, 20, 30).astype(np.int8), q, rng.integers(0, 20, 11).astype(np.int8)])
+        seqs2[6] = q[: max(1, ql // 2)].copy()
+        db = O.make_db(seqs2)
+        for which, gop, gex in ((62, -11, -1), (45, -13, -3), (80, -5, -2)):
+            m = O.blosum21(which)
+            expect = O.scan(q, *db, m21=m, gop=gop, gex=gex, simd=True)
+            for cfg, kt in kinds_configs(search, capi).items():
+                got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, gop=gop, gex=gex, matrix=m)
+                np.testing.assert_array_equal(got, expect, err_msg="%s q=%d blosum%d" % (cfg, ql, which))
+
+
+def test_empty_and_tiny_inputs():
+    torch, capi, search = gpu_modules()
+    q = np.array([3], dtype=np.int8)
+    db = O.make_db([np.array([3], dtype=np.int8)])
+    for cfg, kt in kinds_configs(search, capi).items():
+        got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt)
+        assert got.tolist() == [6]  # D-D in BLOSUM62
+    # n == 0 is a no-op through the ABI
+    ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    ctx.set_query(q)
+    ctx.scan_partition(capi.KIND_I16X2, 0, 0, 0, 0, 0, 0, 0, -11, -1, 0, 0)
+    with pytest.raises(capi.SwError):
+        ctx.scan_partition(capi.KIND_I16X2, 0, 0, 0, 0, 0, 5, 10, +1, -1, 0, 0)  # positive gap score
+    with pytest.raises(capi.SwError):
+        ctx.set_query(np.zeros(0, dtype=np.int8))
+    ctx2 = capi.Context(0)
+    with pytest.raises(capi.SwError):
+        ctx2.scan_partition(capi.KIND_I16X2, 0, 1, 1, 1, 0, 5, 10, -11, -1, 1, 1)  # no matrix / query yet
+
+
+def test_topk_matches_oracle_order():
+    torch, capi, search = gpu_modules()
+    _, qs = O.load_queries()
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(0, 20, int(l)).astype(np.int8) for l in np.sort(rng.integers(20, 400, 5000))]
+    db_arrays = O.make_db(seqs)
+    q = qs[2]
+    got_all, res, order = scan_all_scores(search, capi, db_arrays, q, num_top=25)
+    # ids refer to the sorted DB; tie order = ascending id
+    sorted_scores = got_all[order]
+    es, ei = O.topk(sorted_scores, 25)
+    assert res.scores.tolist() == es.tolist()
+    assert res.reference_ids.tolist() == ei.tolist()
+
+
+def test_full_size_peak_db_property():
+    """BASELINE config 2 at full size (10^6 x 512): every subject is the same sequence, so every
+    one of the 10^6 scores must equal the reference-DP golden score; a checksum covers all slots."""
+    torch, capi, search = gpu_modules()
+    g = O.golden("ref_scores.json")
+    _, qs = O.load_queries()
+    L, num = 512, 1_000_000
+    db = search.DeviceDB.pseudo(num, L, O.pseudodb_codes(L, 42), device=0)
+    for cfg in ("half2+float", "dpxs16+dpxs32"):
+        s = search.Searcher(device=0, num_top=10, matrix=O.blosum21(62), kernel_types=kinds_configs(search, capi)[cfg])
+        s.set_database(db)
+        for qi in (0, 9, 19):
+            res = s.scan(qs[qi])
+            exp = g["pseudo"]["512"][qi]
+            sc = s.scores[:num]
+            assert float(sc.min().item()) == float(sc.max().item()) == float(exp)
+            assert int(s.ids[:num].to(torch.int64).sum().item()) == num * (num - 1) // 2
+            assert res.scores.tolist() == [exp] * 10 and res.reference_ids.tolist() == list(range(10))
+            assert res.num_overflows == 0
