@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) runs into small text files for profiles/.
+
+    python tools/rocprof_summary.py stats  <results.db>            -> per-kernel calls / total / avg (ns)
+    python tools/rocprof_summary.py pmc    <results.db> [filter]   -> per-kernel counter sums and per-dispatch means
+"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def stats(path):
+    db = sqlite3.connect(path)
+    rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    print("%-78s %6s %14s %14s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+    for name, calls, total, avg, pct in rows:
+        print("%-78s %6d %14.0f %14.0f %7.2f" % (name[:78], calls, total, avg, pct))
+    print()
+    print("per-dispatch register/LDS use of the DP kernels:")
+    q = ("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x, count(*), avg(duration) "
+         "from kernels where name like '%sw_scan_kernel%' group by name, grid_x order by avg(duration) desc")
+    print("%-60s %5s %5s %5s %7s %8s %5s %6s %12s" % ("kernel", "vgpr", "agpr", "sgpr", "lds", "grid", "wg", "calls", "avg_ns"))
+    for r in db.execute(q):
+        print("%-60s %5d %5d %5d %7d %8d %5d %6d %12.0f" % ((r[0][:60],) + tuple(r[1:])))
+
+
+def pmc(path, flt="sw_scan_kernel"):
+    db = sqlite3.connect(path)
+    acc = defaultdict(lambda: [0, 0.0, 0.0])
+    for name, counter, value, dur in db.execute(
+            "select kernel_name, counter_name, value, duration from counters_collection"):
+        if flt and flt not in name:
+            continue
+        a = acc[(name, counter)]
+        a[0] += 1
+        a[1] += value
+        a[2] += dur
+    print("%-60s %-24s %6s %18s %18s %14s" % ("kernel", "counter", "calls", "sum", "mean/dispatch", "avg_ns"))
+    for (name, counter), (n, s, d) in sorted(acc.items()):
+        print("%-60s %-24s %6d %18.1f %18.1f %14.0f" % (name[:60], counter, n, s, s / n, d / n))
+
+
+if __name__ == "__main__":
+    mode, path = sys.argv[1], sys.argv[2]
+    if mode == "stats":
+        stats(path)
+    else:
+        pmc(path, sys.argv[3] if len(sys.argv) > 3 else "sw_scan_kernel")
