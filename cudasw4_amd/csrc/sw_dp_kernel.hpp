@@ -80,6 +80,7 @@ struct Arith<I16X2> {
         return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, g)));
     }
     static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return max2(ext, open); }
+    static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return max2(m, max2(a, b)); }
     static __device__ __forceinline__ int score_lo(u32 v) { return (int)(int16_t)(v & 0xffffu); }
     static __device__ __forceinline__ int score_hi(u32 v) { return (int)(int16_t)(v >> 16); }
 };
@@ -115,6 +116,7 @@ struct Arith<F16X2> {
     static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 f) { return max3(t, e, f); }
     static __device__ __forceinline__ u32 gap(u32 a, u32 g) { return add(a, g); }  // not clamped yet
     static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return max3(ext, open, 0u); }
+    static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return max3(m, a, b); }  // one v_pk_maximum3_f16 per two rows
     static __device__ __forceinline__ int score_lo(u32 v) { return (int)(float)__builtin_bit_cast(f16x2, v).x; }
     static __device__ __forceinline__ int score_hi(u32 v) { return (int)(float)__builtin_bit_cast(f16x2, v).y; }
 };
@@ -132,6 +134,7 @@ struct Arith<I32> {
     static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 f) { return (u32)imax(imax((int)t, (int)e), (int)f); }
     static __device__ __forceinline__ u32 gap(u32 a, u32 g) { return a + g; }
     static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return (u32)imax(imax((int)ext, (int)open), 0); }
+    static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return (u32)imax(imax((int)m, (int)a), (int)b); }  // v_max3_i32
     static __device__ __forceinline__ int score_lo(u32 v) { return (int)v; }
     static __device__ __forceinline__ int score_hi(u32) { return 0; }
 };
@@ -150,6 +153,7 @@ struct Arith<F32> {
     static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 ff) { return u(__builtin_fmaxf(__builtin_fmaxf(f(t), f(e)), f(ff))); }
     static __device__ __forceinline__ u32 gap(u32 a, u32 g) { return u(f(a) + f(g)); }
     static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return u(__builtin_fmaxf(__builtin_fmaxf(f(ext), f(open)), 0.0f)); }
+    static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return u(__builtin_fmaxf(__builtin_fmaxf(f(m), f(a)), f(b))); }  // v_max3_f32
     static __device__ __forceinline__ int score_lo(u32 v) { return (int)f(v); }
     static __device__ __forceinline__ int score_hi(u32) { return 0; }
 };
@@ -280,7 +284,12 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
         st.E[r] = A::gap_state(A::gap(st.E[r], gex), hg);
         F = A::gap_state(A::gap(F, gex), hg);
         st.H[r] = h;
-        maxv = A::max2(maxv, h);
+        // running maximum: folded two rows at a time (a 3-input max where the ISA has one)
+        if constexpr (R % 2 == 0) {
+            if (r & 1) maxv = A::fold2(maxv, st.H[r - 1], h);
+        } else {
+            maxv = A::max2(maxv, h);
+        }
     }
     st.maxv = maxv;
     st.Hlast = st.H[R - 1];
