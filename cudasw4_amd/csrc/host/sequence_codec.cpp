@@ -1,0 +1,45 @@
+#include "sequence_codec.hpp"
+
+namespace swh {
+namespace {
+
+#define SW_BLOSUM_TABLE(which, low, ...)                   \
+    constexpr int8_t kCore##which[400] = {__VA_ARGS__};    \
+    constexpr int8_t kLow##which = (low);
+#include "../blosum_tables.inc"
+#undef SW_BLOSUM_TABLE
+
+SubstitutionMatrix make(MatrixId id, const int8_t* core, int8_t low, int gop, int gex, const char* name) {
+    SubstitutionMatrix s{id, {}, gop, gex, name};
+    for (int i = 0; i < kAlphabet; i++)
+        for (int j = 0; j < kAlphabet; j++) s.m[i * kAlphabet + j] = (i < 20 && j < 20) ? core[i * 20 + j] : low;
+    return s;
+}
+
+}  // namespace
+
+const SubstitutionMatrix& substitution_matrix(MatrixId id) {
+    static const SubstitutionMatrix b45 = make(MatrixId::Blosum45, kCore45, kLow45, -13, -2, "blosum45");
+    static const SubstitutionMatrix b50 = make(MatrixId::Blosum50, kCore50, kLow50, -13, -2, "blosum50");
+    static const SubstitutionMatrix b62 = make(MatrixId::Blosum62, kCore62, kLow62, -11, -1, "blosum62");
+    static const SubstitutionMatrix b80 = make(MatrixId::Blosum80, kCore80, kLow80, -10, -1, "blosum80");
+    switch (id) {
+        case MatrixId::Blosum45: return b45;
+        case MatrixId::Blosum50: return b50;
+        case MatrixId::Blosum80: return b80;
+        default: return b62;
+    }
+}
+
+bool parse_matrix_name(const std::string& name, MatrixId& out) {
+    std::string n = name;
+    const std::string suffix = "_20";
+    if (n.size() > suffix.size() && n.compare(n.size() - suffix.size(), suffix.size(), suffix) == 0) n.resize(n.size() - suffix.size());
+    if (n == "blosum45") { out = MatrixId::Blosum45; return true; }
+    if (n == "blosum50") { out = MatrixId::Blosum50; return true; }
+    if (n == "blosum62") { out = MatrixId::Blosum62; return true; }
+    if (n == "blosum80") { out = MatrixId::Blosum80; return true; }
+    return false;
+}
+
+}  // namespace swh

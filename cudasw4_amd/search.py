@@ -301,6 +301,61 @@ class Searcher:
         return self.scores[:self.db.num_sequences].cpu().numpy().astype(np.int32)
 
 
+def shard_ranges(offsets, lengths, world):
+    """partitionDBAmongstGpus (cudasw4.cuh:928-1004) / shard_database (csrc/host/db_format.cpp): every length
+    partition of the (length-sorted) DB is cut into <= world contiguous, char-balanced subject ranges, so each
+    rank sees every length class.  Returns ranges[rank][partition] = (begin, end)."""
+    offsets = np.asarray(offsets, dtype=np.uint64).astype(np.int64)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    ends = np.searchsorted(lengths, PARTITION_BOUNDARIES, side="right")
+    begins = np.concatenate([[0], ends[:-1]])
+    out = [[(int(b), int(b)) for b in begins] for _ in range(world)]
+    for p in range(NUM_PARTITIONS):
+        pb, pe = int(begins[p]), int(ends[p])
+        if pe <= pb:
+            continue
+        quota = int(offsets[pe] - offsets[pb]) // world
+        cur = pb
+        for r in range(world):
+            if cur >= pe:
+                break
+            if r == world - 1:
+                end = pe
+            else:
+                target = int(offsets[cur]) + quota
+                end = int(np.searchsorted(offsets[cur:pe + 1], target, side="right")) + cur
+                end = min(max(end, cur + 1), pe)
+            out[r][p] = (cur, end)
+            cur = end
+        if cur < pe:
+            for r in range(world - 1, -1, -1):
+                if out[r][p][1] > out[r][p][0]:
+                    out[r][p] = (out[r][p][0], pe)
+                    break
+    return out
+
+
+def build_shard(chars, offsets, lengths, ranges):
+    """Concatenate the per-partition ranges of one rank into a dbdata-layout shard (still sorted by
+    length).  Returns (chars, offsets, lengths, global_ids)."""
+    chars = np.asarray(chars, dtype=np.int8)
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    lengths = np.asarray(lengths, dtype=np.int32)
+    c_parts, l_parts, ids = [], [], []
+    for (b, e) in ranges:
+        if e <= b:
+            continue
+        c_parts.append(chars[int(offsets[b] - offsets[0]):int(offsets[e] - offsets[0])])
+        l_parts.append(lengths[b:e])
+        ids.append(np.arange(b, e, dtype=np.int64))
+    if not l_parts:
+        return np.zeros(0, np.int8), np.zeros(1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.int64)
+    sl = np.concatenate(l_parts)
+    so = np.zeros(len(sl) + 1, dtype=np.uint64)
+    so[1:] = np.cumsum((sl.astype(np.int64) + 3) // 4 * 4)
+    return np.concatenate(c_parts), so, sl, np.concatenate(ids)
+
+
 def merge_topk(per_rank, k):
     """Host-side merge of per-GPU top-K lists (replaces the peer-copy gather + sort on device 0,
     cudasw4.cuh:1415-1463).  per_rank: list of (scores, global_ids); score desc, id asc on ties."""

@@ -1,0 +1,56 @@
+/* cudasw4_amd_driver.h — C ABI of libcudasw4_host.so: the C++ host driver (DB sharding over the GPUs
+ * of a node, residency / batch streaming, partition walk, overflow re-score, per-GPU top-K, host merge)
+ * for embedding and tests.  It mirrors the public surface of the reference's class CudaSW4
+ * (cudasw4.cuh:496-839) the way `align` uses it (main.cu:157-259):
+ *
+ *   swdrv_create       CudaSW4::CudaSW4(deviceIds, numTop, blosumType, KernelTypeConfig, MemoryConfig, verbose)
+ *   swdrv_open_db      loadDB(prefix) + setDatabase            (dbdata.cpp:207-222, cudasw4.cuh:552-568)
+ *   swdrv_pseudo_db    loadPseudoDB(num, length) + setDatabase (dbdata.hpp:222-272)
+ *   swdrv_upload       prefetchDBToGpus                        (cudasw4.cuh:651-696)
+ *   swdrv_scan         scan(query, length) -> ScanResult       (cudasw4.cuh:698-765)
+ *
+ * All calls return 0 on success, -1 on error (text from swdrv_last_error()).  Scores are computed only by
+ * libcudasw4_amd.so; there is no CPU path.
+ */
+#ifndef CUDASW4_AMD_DRIVER_H
+#define CUDASW4_AMD_DRIVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct swdrv swdrv;
+
+const char* swdrv_last_error(void);
+
+/* devices/ndev: HIP device ids; ndev = 0 -> all visible devices.
+ * matrix: 45 | 50 | 62 | 80.  kinds: SW_KIND_* for single / many_small / many_large / overflow.
+ * max_gpu_mem = 0 -> unlimited. */
+int swdrv_create(const int* devices, int ndev, int num_top, int matrix,
+                 int kind_single, int kind_many_small, int kind_many_large, int kind_overflow,
+                 size_t max_gpu_mem, size_t max_batch_bytes, size_t max_batch_sequences, size_t max_temp_bytes,
+                 int gop, int gex, int verbose, swdrv** out);
+int swdrv_destroy(swdrv* d);
+
+int swdrv_open_db(swdrv* d, const char* prefix, int prefetch);
+int swdrv_pseudo_db(swdrv* d, size_t num, int32_t length);
+int swdrv_upload(swdrv* d);
+int64_t swdrv_num_sequences(swdrv* d);
+int swdrv_num_gpus(swdrv* d);
+int swdrv_set_num_top(swdrv* d, int num_top);
+
+/* query: residue letters (not encoded).  scores/ids: capacity `cap`; *nres = number of results written. */
+int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64_t* ids, int cap,
+               int* nres, int* num_overflows, double* seconds, double* gcups);
+
+/* header / length of a subject by global id (getReferenceHeader / getReferenceLength) */
+int32_t swdrv_reference_length(swdrv* d, int64_t id);
+int swdrv_reference_header(swdrv* d, int64_t id, char* buf, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

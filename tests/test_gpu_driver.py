@@ -1,0 +1,129 @@
+"""GPU: the C++ host driver (libcudasw4_host.so) and the align command line, end to end."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN_DB = os.path.join(O.GOLDEN_DIR, "allqueries_db", "aq")
+FASTA = os.path.join(O.GOLDEN_DIR, "allqueries.fasta")
+
+
+def expected_top(row, k):
+    s, i = O.topk(np.asarray(row, dtype=np.int32), k)
+    return s.tolist(), i.tolist()
+
+
+@pytest.mark.parametrize("kinds", [(0, 0, 3, 3), (1, 1, 2, 2), (2, 1, 2, 2), (3, 0, 3, 3)])
+def test_driver_allvsall_resident(kinds):
+    from cudasw4_amd import driver
+    g = O.golden("ref_scores.json")
+    _, seqs = O.read_fasta(FASTA)
+    d = driver.Driver(devices=[0], num_top=20, kinds=kinds)
+    d.open_db(GOLDEN_DB)
+    d.upload()
+    assert d.num_sequences() == 20 and d.num_gpus() == 1
+    for qi, q in enumerate(seqs):
+        r = d.scan(q)
+        es, ei = expected_top(g["allvsall"][qi], 20)
+        assert r["scores"].tolist() == es, (kinds, qi)
+        assert r["ids"].tolist() == ei
+        if kinds[0] == 0:
+            assert r["num_overflows"] == sum(1 for x in g["allvsall"][qi] if x >= 2048)
+    assert d.reference_length(19) == 5478 and d.reference_header(0).startswith("sp|")
+
+
+def test_driver_streamed_batches_and_two_shards_on_one_gpu():
+    """--maxGpuMem below the DB size forces the batch-streaming path; devices=[0,0] runs two shards
+    (the multi-GPU code path: per-partition char-balanced ranges, local->global ids, host merge)."""
+    from cudasw4_amd import driver
+    g = O.golden("ref_scores.json")
+    _, seqs = O.read_fasta(FASTA)
+    for devices, kwargs in (([0], dict(max_gpu_mem=1, max_batch_bytes=6000)), ([0, 0], {}), ([0, 0, 0], dict(max_gpu_mem=1, max_batch_bytes=3000))):
+        d = driver.Driver(devices=devices, num_top=7, kinds=(0, 0, 3, 3), **kwargs)
+        d.open_db(GOLDEN_DB)
+        assert d.num_gpus() == len(devices)
+        for qi in (0, 4, 13, 19):
+            r = d.scan(seqs[qi])
+            es, ei = expected_top(g["allvsall"][qi], 7)
+            assert r["scores"].tolist() == es, (devices, qi)
+            assert r["ids"].tolist() == ei
+            assert r["num_overflows"] == sum(1 for x in g["allvsall"][qi] if x >= 2048)
+        d.close()
+
+
+def test_driver_pseudo_db():
+    from cudasw4_amd import driver
+    g = O.golden("ref_scores.json")
+    _, seqs = O.read_fasta(FASTA)
+    d = driver.Driver(devices=[0], num_top=3, kinds=(1, 1, 2, 2))
+    d.pseudo_db(5001, 256)
+    d.upload()
+    for qi in (0, 10, 19):
+        r = d.scan(seqs[qi])
+        assert r["scores"].tolist() == [g["pseudo"]["256"][qi]] * 3 and r["ids"].tolist() == [0, 1, 2]
+        assert r["gcups"] > 0
+
+
+def test_driver_random_db_from_makedb(tmp_path):
+    """makedb -> align path on a ragged random DB, all partitions incl. > 8000, vs the oracle."""
+    from cudasw4_amd import driver
+    rng = np.random.default_rng(17)
+    letters = "ARNDCQEGHILKMFPSTWYVX"
+    lens = list(rng.integers(1, 400, 900)) + list(rng.integers(400, 2500, 60)) + [8100, 9000]
+    recs = []
+    for i, L in enumerate(lens):
+        recs.append(">seq%d\n%s\n" % (i, "".join(letters[int(c)] for c in rng.integers(0, 21, int(L)))))
+    fasta = str(tmp_path / "db.fa")
+    open(fasta, "w").write("".join(recs))
+    prefix = str(tmp_path / "db")
+    subprocess.check_call([driver.MAKEDB, fasta, prefix], stdout=subprocess.DEVNULL)
+    chars = np.fromfile(prefix + "0chars", dtype=np.int8)
+    offsets = np.fromfile(prefix + "0offsets", dtype=np.uint64)
+    lengths = np.fromfile(prefix + "0lengths", dtype=np.int32)
+    q = "".join(letters[int(c)] for c in rng.integers(0, 20, 700))
+    expect = O.scan(O.encode(q), chars, offsets, lengths, simd=True)
+    es, ei = O.topk(expect, 50)
+    for kinds in ((0, 0, 3, 3), (1, 1, 2, 2)):
+        for devices in ([0], [0, 0]):
+            d = driver.Driver(devices=devices, num_top=50, kinds=kinds)
+            d.open_db(prefix)
+            r = d.scan(q)
+            assert r["scores"].tolist() == es.tolist() and r["ids"].tolist() == ei.tolist(), (kinds, devices)
+            d.close()
+
+
+def test_align_cli_tsv_and_plain(tmp_path):
+    from cudasw4_amd import driver
+    g = O.golden("ref_scores.json")
+    headers, seqs = O.read_fasta(FASTA)
+    of = str(tmp_path / "out.tsv")
+    p = subprocess.run([driver.ALIGN, "--query", FASTA, "--db", GOLDEN_DB, "--top", "3", "--tsv", "--of", of, "--verbose",
+                        "--uploadFull", "--prefetchDBFile", "--printLengthPartitions"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "Processing query file" in p.stdout and "Total time:" in p.stdout and "GCUPS" in p.stdout
+    assert "Processing query 19 ... Done. Scan time:" in p.stdout
+    lines = open(of).read().splitlines()
+    assert lines[0].split("\t") == ["Query number", "Query length", "Query header", "Result number", "Result score",
+                                    "Reference length", "Reference header", "Reference ID in DB"]
+    rows = [l.split("\t") for l in lines[1:]]
+    assert len(rows) == 20 * 3
+    for qi in range(20):
+        es, ei = expected_top(g["allvsall"][qi], 3)
+        for k in range(3):
+            row = rows[qi * 3 + k]
+            assert int(row[0]) == qi and int(row[1]) == len(seqs[qi]) and row[2] == headers[qi] and int(row[3]) == k
+            assert int(row[4]) == es[k] and int(row[7]) == ei[k] and int(row[5]) == len(seqs[ei[k]]) and row[6] == headers[ei[k]]
+    # plain output, dpx kernels, pseudo db
+    p = subprocess.run([driver.ALIGN, "--query", FASTA, "--pseudodb", "2000", "128", "--top", "2", "--dpx"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    exp = g["pseudo"]["128"]
+    for qi in range(20):
+        assert "Query %d, header%s, length %d, num overflows 0" % (qi, headers[qi], len(seqs[qi])) in p.stdout
+    assert "Result 0. Score: %d. Length: 128. Header H. referenceId 0" % exp[0] in p.stdout
+    assert "Result 1. Score: %d. Length: 128. Header H. referenceId 1" % exp[19] in p.stdout

@@ -1,0 +1,139 @@
+"""CPU: makedb / dbdata layout parity with the reference, CLI surface, driver library exports."""
+import ctypes
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = O.ROOT
+LIBDIR = os.path.join(ROOT, "cudasw4_amd", "lib")
+MAKEDB = os.path.join(LIBDIR, "makedb")
+ALIGN = os.path.join(LIBDIR, "align")
+REF_MAKEDB = os.path.join(ROOT, "oracle", "_ref", "makedb")
+DB_FILES = ["0chars", "0offsets", "0lengths", "0headers", "0headeroffsets", "0metadata", "metadata"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not (os.path.exists(MAKEDB) and os.path.exists(ALIGN)):
+        import __graft_entry__ as g
+        g.build()
+
+
+def run_makedb(exe, fasta, prefix):
+    subprocess.check_call([exe, fasta, prefix], stdout=subprocess.DEVNULL)
+    return {f: open(prefix + f, "rb").read() for f in DB_FILES}
+
+
+def test_makedb_matches_reference_golden_files(tmp_path, golden_dir):
+    """Byte-for-byte equality with the DB the reference's makedb wrote for allqueries.fasta."""
+    got = run_makedb(MAKEDB, os.path.join(golden_dir, "allqueries.fasta"), str(tmp_path / "aq"))
+    for f in DB_FILES:
+        ref = open(os.path.join(golden_dir, "allqueries_db", "aq" + f), "rb").read()
+        assert got[f] == ref, f
+    lengths = np.frombuffer(got["0lengths"], dtype=np.int32)
+    assert lengths.tolist() == sorted(lengths.tolist()) and len(lengths) == 20
+    meta = np.frombuffer(got["0metadata"][:4 + 36 * 4], dtype=np.int32)
+    assert meta[0] == 36 and meta[1:].tolist() == O.partition_boundaries().tolist()
+
+
+def _random_fasta(path, rng, n, crlf=False, fastq=False, gz=False):
+    letters = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVXBZ*acd", dtype=np.uint8)
+    out = []
+    nl = "\r\n" if crlf else "\n"
+    for i in range(n):
+        L = int(rng.integers(1, 90)) if i % 7 else int(rng.integers(90, 1500))
+        seq = bytes(rng.choice(letters, L)).decode()
+        if fastq:
+            out.append("@read%d some description%s%s%s+%s%s%s" % (i, nl, seq, nl, nl, "I" * L, nl))
+        else:
+            wrapped = nl.join(seq[k:k + 60] for k in range(0, L, 60))
+            out.append(">sp|P%05d|NAME_%d OS=Test organism%s%s%s" % (i, i, nl, wrapped, nl))
+            if i % 11 == 0:
+                out.append(nl)  # empty line between records
+    data = "".join(out).encode()
+    if gz:
+        with gzip.open(path, "wb") as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAKEDB), reason="reference makedb not built (oracle/_ref)")
+@pytest.mark.parametrize("variant", ["plain", "crlf", "gz", "fastq"])
+def test_makedb_equals_reference_makedb_live(tmp_path, variant):
+    """Same input through both binaries (length ties, unknown letters, wrapped lines, CRLF, gzip, FASTQ)."""
+    rng = np.random.default_rng(11)
+    fasta = str(tmp_path / ("in.fa.gz" if variant == "gz" else "in.fa"))
+    _random_fasta(fasta, rng, 400, crlf=variant == "crlf", fastq=variant == "fastq", gz=variant == "gz")
+    mine = run_makedb(MAKEDB, fasta, str(tmp_path / "mine"))
+    ref = run_makedb(REF_MAKEDB, fasta, str(tmp_path / "ref"))
+    for f in DB_FILES:
+        assert mine[f] == ref[f], (variant, f)
+
+
+def test_makedb_roundtrip_content(tmp_path):
+    """Without the reference: decoded DB content equals the input, sorted by length, padded to 4 with 20."""
+    rng = np.random.default_rng(5)
+    fasta = str(tmp_path / "in.fa")
+    _random_fasta(fasta, rng, 120)
+    headers, seqs = O.read_fasta(fasta)
+    db = run_makedb(MAKEDB, fasta, str(tmp_path / "db"))
+    lengths = np.frombuffer(db["0lengths"], dtype=np.int32)
+    offsets = np.frombuffer(db["0offsets"], dtype=np.uint64)
+    hoff = np.frombuffer(db["0headeroffsets"], dtype=np.uint64)
+    chars = np.frombuffer(db["0chars"], dtype=np.int8)
+    assert len(lengths) == len(seqs) and np.all(np.diff(lengths) >= 0) and np.all(offsets % 4 == 0)
+    by_header = {h: s for h, s in zip(headers, seqs)}
+    for i in range(len(lengths)):
+        h = db["0headers"][int(hoff[i]):int(hoff[i + 1])].decode()
+        s = by_header[h]
+        assert lengths[i] == len(s)
+        a = int(offsets[i])
+        np.testing.assert_array_equal(chars[a:a + len(s)], O.encode(s))
+        assert np.all(chars[a + len(s):int(offsets[i + 1])] == 20)
+
+
+def test_cli_surface_without_gpu():
+    out = subprocess.run([ALIGN, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0
+    for flag in ("--query", "--db", "--top", "--gop", "--gex", "--mat", "--maxGpuMem", "--maxTempBytes", "--maxBatchBytes",
+                 "--maxBatchSequences", "--dpx", "--of", "--tsv", "--verbose", "--printLengthPartitions", "--interactive",
+                 "--prefetchDBFile", "--uploadFull", "--pseudodb", "--singlePassType", "--manyPassType_small",
+                 "--manyPassType_large", "--overflowType"):
+        assert flag in out.stdout, flag
+    out = subprocess.run([ALIGN, "--db", "x"], capture_output=True, text=True)
+    assert "Query is missing" in out.stdout and out.returncode == 0
+    out = subprocess.run([ALIGN, "--query", "x"], capture_output=True, text=True)
+    assert "DB prefix is missing" in out.stdout
+    out = subprocess.run([MAKEDB], capture_output=True, text=True)
+    assert "Usage" in out.stdout and "--mem" in out.stdout and "--tempdir" in out.stdout
+
+
+def test_align_fails_loudly_without_gpu(golden_dir):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    out = subprocess.run([ALIGN, "--query", os.path.join(golden_dir, "allqueries.fasta"), "--db",
+                          os.path.join(golden_dir, "allqueries_db", "aq")], capture_output=True, text=True)
+    assert out.returncode != 0 and "No GPU found" in out.stderr
+
+
+def test_driver_header_symbols_exported():
+    header = open(os.path.join(ROOT, "include", "cudasw4_amd_driver.h")).read()
+    declared = set(re.findall(r"\b(swdrv_[a-z_0-9]+)\s*\(", header))
+    from cudasw4_amd import driver
+    assert declared == set(driver.EXPORTS), declared ^ set(driver.EXPORTS)
+    lib = ctypes.CDLL(os.path.join(LIBDIR, "libcudasw4_host.so"))
+    for name in declared:
+        assert hasattr(lib, name), name
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(driver.DriverError):
+            driver.Driver()
