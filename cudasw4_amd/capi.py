@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcudasw4_amd.so")
+LIB_PATH = os.environ.get("CUDASW4_AMD_LIB", os.path.join(_HERE, "lib", "libcudasw4_amd.so"))  # env override: A/B builds
 
 KIND_F16X2, KIND_I16X2, KIND_I32, KIND_F32 = 0, 1, 2, 3
 KIND_NAMES = {"half2": KIND_F16X2, "f16x2": KIND_F16X2, "dpxs16": KIND_I16X2, "i16x2": KIND_I16X2,

@@ -58,10 +58,18 @@ QueryPlan plan_query(int kind, int32_t qlen) {
     if (!kl || qlen <= 0) return pl;
     const int maxrows = kl->max_rows;
     const int64_t stripe_max = (int64_t)swk::kGroup * maxrows;
-    pl.nstripes = (int)((qlen + stripe_max - 1) / stripe_max);
-    const int64_t per_lane = (qlen + (int64_t)swk::kGroup * pl.nstripes - 1) / ((int64_t)swk::kGroup * pl.nstripes);
-    int r = (int)((per_lane + swk::kRowsGranule - 1) / swk::kRowsGranule * swk::kRowsGranule);
-    pl.rows = std::min(std::max(r, swk::kRowsGranule), maxrows);
+    const int ns_min = (int)((qlen + stripe_max - 1) / stripe_max);
+    // cost model: a step of a stripe with R rows per lane issues ~(R + 1.2) row-equivalents of VALU work
+    // (per-step DPP/address overhead) and every stripe pays its own pipeline fill; minimise ns * (R + 1.2).
+    double best = 1e300;
+    for (int ns = ns_min; ns <= ns_min + 2; ns++) {
+        const int64_t per_lane = (qlen + (int64_t)swk::kGroup * ns - 1) / ((int64_t)swk::kGroup * ns);
+        int r = (int)((per_lane + swk::kRowsGranule - 1) / swk::kRowsGranule * swk::kRowsGranule);
+        r = std::min(std::max(r, swk::kRowsGranule), maxrows);
+        if (ns > 1 && 2 * r <= maxrows) continue;  // multi-stripe kernels exist for R > max/2 only
+        const double cost = ns * (r + 1.2);
+        if (cost < best - 1e-9) { best = cost; pl.rows = r; pl.nstripes = ns; }
+    }
     return pl;
 }
 
@@ -79,6 +87,7 @@ struct sw_ctx {
     int device = 0;
     int num_cus = 0;
     int8_t* d_matrix = nullptr;  // 21 x 21
+    uint32_t* d_zeros = nullptr; // 256 bytes of zeros (first-stripe border)
     bool have_matrix = false;
     int8_t* d_query = nullptr;
     size_t query_capacity = 0;
@@ -119,9 +128,12 @@ int ensure_profile(sw_ctx* ctx, int kind, hipStream_t stream) {
 
 // scratch words per (workgroup, group) array for subjects up to max_len
 int32_t border_capacity(int32_t max_len) {
-    int64_t steps = ((int64_t)max_len + swk::kGroup - 1 + 3) / 4 * 4;
-    steps = (steps + 15) / 16 * 16;
-    return (int32_t)(steps + 32);
+    const int64_t steps = ((int64_t)max_len + swk::kGroup - 1 + 3) / 4 * 4;
+    return (int32_t)((steps + 15) / 16 * 16 + 16);  // + one prefetched quad past the end, rounded to 64 bytes
+}
+constexpr size_t kBorderJunkWords = 64;
+size_t border_bytes_per_wg(int32_t lcap) {
+    return (size_t)swk::kGroupsPerWg * 2 * ((size_t)lcap + kBorderJunkWords) * sizeof(uint32_t);
 }
 
 int scan_common(sw_ctx* ctx, int kind, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
@@ -163,10 +175,10 @@ int scan_common(sw_ctx* ctx, int kind, const int8_t* chars, const uint64_t* offs
     }
     p.scores = scores; p.ids = ids; p.id_offset = id_offset;
     p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;
-    p.scratch = nullptr; p.lcap = 0;
+    p.scratch = nullptr; p.lcap = 0; p.zeros = ctx->d_zeros;
     if (multi) {
         p.lcap = border_capacity(max_subject_len);
-        const size_t per_wg = (size_t)swk::kGroupsPerWg * 2 * (size_t)p.lcap * sizeof(uint32_t);
+        const size_t per_wg = border_bytes_per_wg(p.lcap);
         if (!temp || temp_bytes < per_wg) return fail(SW_ERR_TEMP, "temp buffer too small for a multi-stripe query");
         grid = (int)std::min<size_t>((size_t)grid, temp_bytes / per_wg);
         p.scratch = static_cast<uint32_t*>(temp);
@@ -202,6 +214,8 @@ int sw_ctx_create(int device, sw_ctx** out) {
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
+    if (e == hipSuccess) e = hipMemset(ctx->d_zeros, 0, 256);
     if (e != hipSuccess) { delete ctx; return fail(SW_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     *out = ctx;
     return SW_OK;
@@ -211,6 +225,7 @@ int sw_ctx_destroy(sw_ctx* ctx) {
     if (!ctx) return SW_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_matrix) (void)hipFree(ctx->d_matrix);
+    if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_query) (void)hipFree(ctx->d_query);
     for (auto& pr : ctx->profiles) {
         if (pr.dev) (void)hipFree(pr.dev);
@@ -269,7 +284,7 @@ size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0) return 0;
     const QueryPlan pl = plan_query(kind, ctx->qlen);
     if (pl.nstripes <= 1) return 0;
-    return (size_t)max_grid(ctx) * swk::kGroupsPerWg * 2 * (size_t)border_capacity(max_subject_len) * sizeof(uint32_t);
+    return (size_t)max_grid(ctx) * border_bytes_per_wg(border_capacity(max_subject_len));
 }
 
 int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, const uint64_t* offsets,

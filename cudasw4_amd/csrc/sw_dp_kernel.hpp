@@ -194,8 +194,9 @@ struct ScanParams {
     int32_t* ovf_pos;
     int32_t* ovf_count;
     int32_t ovf_check;
-    u32* scratch;              // stripe-border spill: per (workgroup, group): H[lcap], F[lcap]
+    u32* scratch;              // stripe-border spill: per (workgroup, group): [64 junk][H lcap][64 junk][F lcap]
     int32_t lcap;
+    const u32* zeros;          // >= 64 bytes of zeros (border of the first stripe)
 };
 
 template <int NW>
@@ -232,11 +233,11 @@ struct StripeState {
 
 // One anti-diagonal step of one lane: R cells (or R cell pairs).
 //   BYTE    which byte of the letter words feeds lane 0 in this step
-//   MULTI   stripe borders in play (lane 0 reads the previous stripe's row, lane 15 collects its own)
+//   MULTI   stripe borders in play: lane 0 takes (inH, inF) — the previous stripe's bottom row at this
+//           column — instead of the zero boundary; the caller stores lane 15's (Hlast, Fout) afterwards
 template <int KIND, int R, int BYTE, bool MULTI>
 __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned char* tile,
-                                        u32 lettersA, u32 lettersB, u32 gop, u32 gex,
-                                        u32& inH, u32& inF, u32& outH, u32& outF) {
+                                        u32 lettersA, u32 lettersB, u32 gop, u32 gex, u32 inH, u32 inF) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R>;
     constexpr u32 kSel = 0x0c0c000cu | ((u32)BYTE << 8);  // letter byte BYTE -> bits 15:8 (= offset/256)
@@ -256,10 +257,8 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
     // row above the lane's first row: from the neighbouring lane, or from the stripe border
     u32 upH, F;
     if constexpr (MULTI) {
-        upH = dpp<DPP_ROW_SHR1, false>(inH, st.Hlast);
+        upH = dpp<DPP_ROW_SHR1, false>(inH, st.Hlast);  // lane 0 keeps `old` == the border value
         F = dpp<DPP_ROW_SHR1, false>(inF, st.Fout);
-        inH = dpp<DPP_ROW_SHL1, true>(0u, inH);
-        inF = dpp<DPP_ROW_SHL1, true>(0u, inF);
     } else {
         upH = dpp<DPP_ROW_SHR1, true>(0u, st.Hlast);
         F = dpp<DPP_ROW_SHR1, true>(0u, st.Fout);
@@ -294,11 +293,6 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
     st.maxv = maxv;
     st.Hlast = st.H[R - 1];
     st.Fout = F;
-    if constexpr (MULTI) {
-        // lane 15 appends its border values; the 16-wide window slides towards lane 0
-        outH = dpp<DPP_ROW_SHL1, false>(st.Hlast, outH);
-        outF = dpp<DPP_ROW_SHL1, false>(st.Fout, outF);
-    }
 }
 
 // Copy one profile tile (global, L2-resident) into LDS.  The tile starts 16 bytes into the LDS
@@ -325,8 +319,11 @@ __device__ __forceinline__ u32 row_max(u32 v) {
 // The scan kernel.  Persistent workgroups stride over batches of 16 groups (32 or 16 subjects),
 // longest subjects first.  MULTI == the query needs more than one stripe.
 // ------------------------------------------------------------------------------------------------
+#ifndef SWK_MIN_WAVES
+#define SWK_MIN_WAVES 1  // minimum waves per SIMD the register allocator must leave room for (tuning knob)
+#endif
 template <int KIND, int R, bool MULTI>
-__global__ void __launch_bounds__(kThreads) sw_scan_kernel(const ScanParams p) {
+__global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const ScanParams p) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[16 + G::kTileBytes];
@@ -344,8 +341,12 @@ __global__ void __launch_bounds__(kThreads) sw_scan_kernel(const ScanParams p) {
         __syncthreads();
     }
 
-    u32* const borderH = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroupsPerWg + group) * 2 * (size_t)p.lcap : nullptr;
-    u32* const borderF = MULTI ? borderH + p.lcap : nullptr;
+    // Stripe-border spill of this group: H[lcap] and F[lcap], each preceded by 64 junk words.  The loop
+    // is kept branch-free: EVERY lane loads and stores each step, but only lane 0's load address and
+    // lane 15's store address walk the real arrays; the other lanes hit the junk words (lane 15's stores
+    // for columns t-15 < 0 land there too).
+    u32* const borderH = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroupsPerWg + group) * 2 * ((size_t)p.lcap + 64) + 64 : nullptr;
+    u32* const borderF = MULTI ? borderH + p.lcap + 64 : nullptr;
 
     for (int b = blockIdx.x; b < nbatches; b += gridDim.x) {
         const int batch = nbatches - 1 - b;  // DB is length-sorted ascending: longest first
@@ -370,8 +371,7 @@ __global__ void __launch_bounds__(kThreads) sw_scan_kernel(const ScanParams p) {
         lmax = max(lmax, __shfl_xor(lmax, 16));
         lmax = max(lmax, __shfl_xor(lmax, 32));
         // lane 15 finishes column lmax-1 at step lmax+14
-        int nquads = (lmax + kGroup - 1 + 3) >> 2;
-        if constexpr (MULTI) nquads = (nquads + 3) & ~3;  // whole 16-step border blocks
+        const int nquads = (lmax + kGroup - 1 + 3) >> 2;
         const int len0pad = (len0 + 3) & ~3, len1pad = (len1 + 3) & ~3;
 
         u32 maxv = 0;
@@ -402,17 +402,19 @@ __global__ void __launch_bounds__(kThreads) sw_scan_kernel(const ScanParams p) {
             u32 nextB = A::kPacked ? fetch(s1, len1pad, 0) : 0u;
             u32 lettersA = 0, lettersB = 0;
 
-            // stripe-border windows (MULTI only)
-            u32 inH = 0, inF = 0, outH = 0, outF = 0, nextInH = 0, nextInF = 0;
-            const int written = nquads * 4 - (kGroup - 1);  // columns [0, written) were spilled by the previous stripe
-            auto fetch_border = [&](int blk16) {
-                const int col = blk16 * 16 + lane16;
-                nextInH = 0; nextInF = 0;
-                if (!first && col < written) { nextInH = borderH[col]; nextInF = borderF[col]; }
-            };
+            // stripe border (MULTI only): lane 0 reads the previous stripe's bottom row four columns per
+            // quad, one quad ahead (2 x 16-byte loads); lane 15 stores its own bottom row every step.
+            uint4 curH = make_uint4(0, 0, 0, 0), curF = curH, nextH = curH, nextF = curH;
+            const int walkIn = (lane16 == 0 && !first) ? 4 : 0;       // words per quad the load address advances
+            const int walkOut = (lane16 == kGroup - 1) ? 4 : 0;
+            const u32* inH = (lane16 == 0 && !first) ? borderH : p.zeros;
+            const u32* inF = (lane16 == 0 && !first) ? borderF : p.zeros;
+            u32* outH = (lane16 == kGroup - 1) ? borderH - (kGroup - 1) : borderH - 64 + 4 * lane16;
+            u32* outF = (lane16 == kGroup - 1) ? borderF - (kGroup - 1) : borderF - 64 + 4 * lane16;
             if constexpr (MULTI) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                fetch_border(0);
+                nextH = *reinterpret_cast<const uint4*>(inH);
+                nextF = *reinterpret_cast<const uint4*>(inF);
             }
 
             for (int q = 0; q < nquads; q++) {
@@ -422,23 +424,27 @@ __global__ void __launch_bounds__(kThreads) sw_scan_kernel(const ScanParams p) {
                     if constexpr (A::kPacked) nextB = fetch(s1, len1pad, (q >> 4) + 1);
                 }
                 if constexpr (MULTI) {
-                    if ((q & 3) == 0) {
-                        inH = nextInH; inF = nextInF;
-                        fetch_border((q >> 2) + 1);
-                    }
+                    curH = nextH; curF = nextF;
+                    inH += walkIn; inF += walkIn;  // prefetch the next quad (the array has slack past the last one)
+                    nextH = *reinterpret_cast<const uint4*>(inH);
+                    nextF = *reinterpret_cast<const uint4*>(inF);
                 }
-                dp_step<KIND, R, 0, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, inH, inF, outH, outF);
-                dp_step<KIND, R, 1, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, inH, inF, outH, outF);
-                dp_step<KIND, R, 2, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, inH, inF, outH, outF);
-                dp_step<KIND, R, 3, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, inH, inF, outH, outF);
+                dp_step<KIND, R, 0, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x);
+                if constexpr (MULTI) { outH[0] = st.Hlast; outF[0] = st.Fout; }
+                dp_step<KIND, R, 1, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y);
+                if constexpr (MULTI) { outH[1] = st.Hlast; outF[1] = st.Fout; }
+                dp_step<KIND, R, 2, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z);
+                if constexpr (MULTI) { outH[2] = st.Hlast; outF[2] = st.Fout; }
+                dp_step<KIND, R, 3, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w);
+                if constexpr (MULTI) { outH[3] = st.Hlast; outF[3] = st.Fout; outH += walkOut; outF += walkOut; }
                 lettersA = dpp<DPP_ROW_SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<DPP_ROW_SHL1, true>(0u, lettersB);
-                if constexpr (MULTI) {
-                    if ((q & 3) == 3 && !last) {
-                        // after step t (0-based) lane l holds column t + l - 30 ... here t = 4q+3
-                        const int col = 4 * q + 3 + lane16 - 2 * (kGroup - 1);
-                        if (col >= 0) { borderH[col] = outH; borderF[col] = outF; }
-                    }
+            }
+            if constexpr (MULTI) {
+                // lane 15 reached column 4*nquads-16; the next stripe reads up to 4*nquads-1: zero the rest
+                if (lane16 < kGroup - 1) {
+                    borderH[4 * nquads - (kGroup - 1) + lane16] = 0;
+                    borderF[4 * nquads - (kGroup - 1) + lane16] = 0;
                 }
             }
             maxv = st.maxv;

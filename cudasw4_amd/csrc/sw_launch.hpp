@@ -6,7 +6,7 @@
 namespace swk {
 
 // Rows-per-lane values that are compiled.  The query planner (sw_api.hip: plan_query) only picks these.
-constexpr int kRowsGranule = 4;
+constexpr int kRowsGranule = 2;
 constexpr int kMaxRowsPacked = 32;  // stripe = 512 query rows
 constexpr int kMaxRowsScalar = 16;  // stripe = 256 query rows (32-bit profile entries)
 
@@ -27,8 +27,14 @@ const KindLaunch& launch_f32();
 // ---- helpers used by the kind TUs ----
 template <int KIND, int R>
 hipError_t launch_scan_r(bool multi, int grid, hipStream_t stream, const ScanParams& p) {
-    if (multi) hipLaunchKernelGGL((sw_scan_kernel<KIND, R, true>), dim3(grid), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL((sw_scan_kernel<KIND, R, false>), dim3(grid), dim3(kThreads), 0, stream, p);
+    // a query that needs more than one stripe always gets R > max/2 from the planner
+    constexpr int kMaxR = Arith<KIND>::kPacked ? kMaxRowsPacked : kMaxRowsScalar;
+    if (multi) {
+        if constexpr (2 * R > kMaxR) hipLaunchKernelGGL((sw_scan_kernel<KIND, R, true>), dim3(grid), dim3(kThreads), 0, stream, p);
+        else return hipErrorInvalidValue;
+    } else {
+        hipLaunchKernelGGL((sw_scan_kernel<KIND, R, false>), dim3(grid), dim3(kThreads), 0, stream, p);
+    }
     return hipGetLastError();
 }
 
@@ -42,8 +48,8 @@ hipError_t launch_profile_r(const int8_t* query, int32_t qlen, const int8_t* mat
     return hipGetLastError();
 }
 
-#define SWK_FOR_EACH_R_PACKED(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32)
-#define SWK_FOR_EACH_R_SCALAR(X) X(4) X(8) X(12) X(16)
+#define SWK_FOR_EACH_R_PACKED(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+#define SWK_FOR_EACH_R_SCALAR(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 
 #define SWK_DEFINE_KIND(FN, KIND, FOR_EACH_R, MAXR)                                                          \
     static hipError_t FN##_scan(int R, bool multi, int grid, hipStream_t stream, const ScanParams& p) {       \
