@@ -45,7 +45,7 @@ def _load():
     L.sw_set_matrix.argtypes = [vp, vp, ctypes.c_int]
     L.sw_set_query.argtypes = [vp, vp, i32, vp]
     L.sw_scan_temp_bytes.restype = sz
-    L.sw_scan_temp_bytes.argtypes = [vp, ctypes.c_int, i32]
+    L.sw_scan_temp_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int, i32, i32]
     L.sw_scan_partition.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, i32, ctypes.c_int,
                                     ctypes.c_int, vp, vp, i64, vp, vp, ctypes.c_int, vp, sz, vp]
     L.sw_rescore_overflow.argtypes = [vp, ctypes.c_int, vp, vp, i32, vp, vp, vp, i32, ctypes.c_int, ctypes.c_int,
@@ -110,8 +110,8 @@ class Context:
         q = np.ascontiguousarray(codes, dtype=np.int8)
         check(lib.sw_set_query(self.handle, q.ctypes.data, len(q), stream))
 
-    def scan_temp_bytes(self, kind, max_subject_len):
-        return int(lib.sw_scan_temp_bytes(self.handle, kind, max_subject_len))
+    def scan_temp_bytes(self, kind, part_id, n, max_subject_len):
+        return int(lib.sw_scan_temp_bytes(self.handle, kind, part_id, n, max_subject_len))
 
     def scan_partition(self, kind, part_id, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex,
                        scores, ids, id_offset=0, ovf_pos=0, ovf_count=0, ovf_check=0, temp=0, temp_bytes=0, stream=0):

@@ -101,8 +101,13 @@ struct SearchDriver::Gpu {
     int32_t* d_ids = nullptr;
     int32_t* d_ovfPos = nullptr;
     int32_t* d_ovfCount = nullptr;   // [0] per batch, [1] running total of the query
-    void* d_temp = nullptr;
-    size_t tempBytes = 0;
+    // Launches that run concurrently need their own stripe-border scratch: slot 0 = work stream,
+    // slots 1.. = auxiliary streams (the reference round-robins 10 work streams, cudasw4.cuh:293,1745-1748)
+    static constexpr int kAux = 2;
+    hipStream_t aux[kAux] = {nullptr, nullptr};
+    hipEvent_t forkEvent = nullptr, joinEvent[kAux] = {nullptr, nullptr};
+    void* d_temp[kAux + 1] = {nullptr, nullptr, nullptr};
+    size_t tempBytes[kAux + 1] = {0, 0, 0};
     void* d_topkTemp = nullptr;
     size_t topkTempBytes = 0;
     float* d_topS = nullptr;
@@ -140,6 +145,11 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), kAlphabet));
         HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&g->forkEvent, hipEventDisableTiming));
+        for (int i = 0; i < Gpu::kAux; i++) {
+            HIPCHECK(hipStreamCreateWithFlags(&g->aux[i], hipStreamNonBlocking));
+            HIPCHECK(hipEventCreateWithFlags(&g->joinEvent[i], hipEventDisableTiming));
+        }
         HIPCHECK(hipMalloc(&g->d_ovfCount, 2 * sizeof(int32_t)));
         HIPCHECK(hipHostMalloc(&g->h_ovf, 2 * sizeof(int32_t)));
         HIPCHECK(hipHostMalloc(&g->h_ovfSlot, 2 * sizeof(int32_t)));
@@ -161,7 +171,13 @@ SearchDriver::~SearchDriver() {
             if (g.stagingReady[i]) (void)hipEventDestroy(g.stagingReady[i]);
         }
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos); (void)hipFree(g.d_ovfCount);
-        (void)hipFree(g.d_temp); (void)hipFree(g.d_topkTemp); (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
+        for (int i = 0; i <= Gpu::kAux; i++) (void)hipFree(g.d_temp[i]);
+        for (int i = 0; i < Gpu::kAux; i++) {
+            if (g.aux[i]) (void)hipStreamDestroy(g.aux[i]);
+            if (g.joinEvent[i]) (void)hipEventDestroy(g.joinEvent[i]);
+        }
+        if (g.forkEvent) (void)hipEventDestroy(g.forkEvent);
+        (void)hipFree(g.d_topkTemp); (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
         (void)hipHostFree(g.h_topS); (void)hipHostFree(g.h_topI); (void)hipHostFree(g.h_ovf); (void)hipHostFree(g.h_ovfSlot);
         if (g.stream) (void)hipStreamDestroy(g.stream);
         if (g.copyStream) (void)hipStreamDestroy(g.copyStream);
@@ -269,7 +285,9 @@ std::vector<Run> plan_runs(const KernelTypeConfig& kt,
         if (e <= b) continue;
         const KernelType kind = kt.for_partition(p);
         const int32_t maxlen = db.length(ranges[p].begin + (e - 1 - localBegin[p]));
-        if (!runs.empty() && runs.back().kind == kind && runs.back().begin == e) {
+        // partitions 34/35 (long subjects) use the wave-wide group shape: never merged with 0..33
+        const bool sameShape = !runs.empty() && (runs.back().part_id >= kNumLengthPartitions - 2) == (p >= kNumLengthPartitions - 2);
+        if (!runs.empty() && runs.back().kind == kind && runs.back().begin == e && sameShape) {
             runs.back().begin = b;
         } else {
             runs.push_back(Run{kind, p, b, e, maxlen});
@@ -280,34 +298,71 @@ std::vector<Run> plan_runs(const KernelTypeConfig& kt,
 
 }  // namespace
 
-// Enqueue the scan of subjects [begin, end) (shard-local) whose data sits in `batch` starting at
-// batch-local position 0.
-static void enqueue_batch(sw_ctx* ctx, hipStream_t stream, const DeviceBatch& batch, size_t batchBegin,
-                          const std::vector<Run>& runs, const KernelTypeConfig& kt, int gop, int gex, float* d_scores,
-                          int32_t* d_ids, int32_t* d_ovfPos, int32_t* d_ovfCount, void* d_temp, size_t tempBytes,
-                          int32_t maxLen) {
+// Enqueue the scan of the runs of one batch whose data sits in `batch` starting at batch-local
+// position 0 (shard-local position batchBegin).  The run with the most subjects goes to the work
+// stream; the others (few long subjects) are launched FIRST on auxiliary streams so that they hold
+// their handful of workgroups while the bulk run fills the rest of the GPU.
+static void* ensure_temp(void*& ptr, size_t& have, size_t need, size_t cap) {
+    need = std::min(need, cap);
+    if (need > have) {
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        have = 0;
+        HIPCHECK(hipMalloc(&ptr, need));
+        have = need;
+    }
+    return ptr;
+}
+
+template <class GpuT>
+static void enqueue_batch(GpuT& g, const DeviceBatch& batch, size_t batchBegin, const std::vector<Run>& runs,
+                          const KernelTypeConfig& kt, const MemoryConfig& mem, int gop, int gex, int32_t maxLen) {
     bool packedUsed = false;
-    HIPCHECK(hipMemsetAsync(d_ovfCount, 0, sizeof(int32_t), stream));
-    for (const Run& r : runs) {
+    HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, sizeof(int32_t), g.stream));
+    size_t mainIdx = 0;
+    for (size_t i = 1; i < runs.size(); i++)
+        if (runs[i].end - runs[i].begin > runs[mainIdx].end - runs[mainIdx].begin) mainIdx = i;
+    const bool fork = runs.size() > 1;
+    if (fork) HIPCHECK(hipEventRecord(g.forkEvent, g.stream));
+    auto launch = [&](const Run& r, hipStream_t stream, int slot) {
         packedUsed |= is_packed(r.kind);
-        SWCHECK(sw_scan_partition(ctx, int(r.kind), r.part_id, batch.chars, batch.offsets, batch.lengths,
-                                  int32_t(r.begin - batchBegin), int32_t(r.end - r.begin), r.maxlen, gop, gex,
-                                  d_scores + batchBegin, d_ids + batchBegin, int64_t(batchBegin), d_ovfPos, d_ovfCount,
-                                  is_packed(r.kind) ? 1 : 0, d_temp, tempBytes, stream));
+        const int32_t n = int32_t(r.end - r.begin);
+        const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, r.maxlen);
+        void* temp = ensure_temp(g.d_temp[slot], g.tempBytes[slot], need, mem.maxTempBytes);
+        SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, batch.chars, batch.offsets, batch.lengths,
+                                  int32_t(r.begin - batchBegin), n, r.maxlen, gop, gex, g.d_scores + batchBegin,
+                                  g.d_ids + batchBegin, int64_t(batchBegin), g.d_ovfPos, g.d_ovfCount,
+                                  is_packed(r.kind) ? 1 : 0, temp, g.tempBytes[slot], stream));
+    };
+    int auxUsed = 0;
+    bool auxBusy[GpuT::kAux] = {};
+    for (size_t i = 0; i < runs.size(); i++) {
+        if (i == mainIdx) continue;
+        const int a = auxUsed++ % GpuT::kAux;
+        if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], g.forkEvent, 0));
+        auxBusy[a] = true;
+        launch(runs[i], g.aux[a], a + 1);
+    }
+    if (!runs.empty()) launch(runs[mainIdx], g.stream, 0);
+    for (int a = 0; a < GpuT::kAux; a++) {
+        if (!auxBusy[a]) continue;
+        HIPCHECK(hipEventRecord(g.joinEvent[a], g.aux[a]));
+        HIPCHECK(hipStreamWaitEvent(g.stream, g.joinEvent[a], 0));
     }
     if (packedUsed) {
         size_t n = 0;
         for (const Run& r : runs) n += r.end - r.begin;
-        SWCHECK(sw_rescore_overflow(ctx, int(kt.overflowType), d_ovfPos, d_ovfCount, int32_t(n), batch.chars, batch.offsets,
-                                    batch.lengths, maxLen, gop, gex, d_scores + batchBegin, d_ids + batchBegin,
-                                    int64_t(batchBegin), d_temp, tempBytes, stream));
+        const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, int32_t(n), maxLen);
+        void* temp = ensure_temp(g.d_temp[0], g.tempBytes[0], need, mem.maxTempBytes);
+        SWCHECK(sw_rescore_overflow(g.ctx, int(kt.overflowType), g.d_ovfPos, g.d_ovfCount, int32_t(n), batch.chars,
+                                    batch.offsets, batch.lengths, maxLen, gop, gex, g.d_scores + batchBegin,
+                                    g.d_ids + batchBegin, int64_t(batchBegin), temp, g.tempBytes[0], g.stream));
     }
 }
 
 void SearchDriver::scanResident(Gpu& g, int32_t /*qlen*/) {
     const auto runs = plan_runs(kernels_, g.localBegin, 0, g.numLocal, *db_, g.ranges);
-    enqueue_batch(g.ctx, g.stream, g.residentDb, 0, runs, kernels_, gop_, gex_, g.d_scores, g.d_ids, g.d_ovfPos,
-                  g.d_ovfCount, g.d_temp, g.tempBytes, g.maxLen);
+    enqueue_batch(g, g.residentDb, 0, runs, kernels_, memory_, gop_, gex_, g.maxLen);
     // running total of the query (addKernel, cudasw4.cuh:46-49,2175): a single batch -> copy
     HIPCHECK(hipMemcpyAsync(g.d_ovfCount + 1, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToDevice, g.stream));
 }
@@ -368,8 +423,7 @@ void SearchDriver::scanStreamed(Gpu& g, int32_t /*qlen*/) {
             HIPCHECK(hipStreamWaitEvent(g.stream, g.stagingReady[slot], 0));
             const KernelType kind = kernels_.for_partition(p);
             std::vector<Run> runs{Run{kind, p, localBegin, localBegin + nseq, db_->length(e - 1)}};
-            enqueue_batch(g.ctx, g.stream, b, localBegin, runs, kernels_, gop_, gex_, g.d_scores, g.d_ids, g.d_ovfPos,
-                          g.d_ovfCount, g.d_temp, g.tempBytes, db_->length(e - 1));
+            enqueue_batch(g, b, localBegin, runs, kernels_, memory_, gop_, gex_, db_->length(e - 1));
             HIPCHECK(hipMemcpyAsync(g.h_ovfSlot + slot, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
             HIPCHECK(hipEventRecord(g.stagingFree[slot], g.stream));
             slotUsed[slot] = true;
@@ -402,15 +456,6 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
         if (g.numLocal == 0) continue;
         if (g.wantResident && !g.resident) uploadShard(g);  // first query pays the upload unless --uploadFull
         SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
-        // temp for the stripe borders (reference: maxTempBytes, cudasw4.cuh:1928-1968)
-        size_t need = 0;
-        for (int kind = 0; kind < 4; kind++) need = std::max(need, sw_scan_temp_bytes(g.ctx, kind, g.maxLen));
-        need = std::min(need, memory_.maxTempBytes);
-        if (need > g.tempBytes) {
-            (void)hipFree(g.d_temp);
-            HIPCHECK(hipMalloc(&g.d_temp, need));
-            g.tempBytes = need;
-        }
         // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
         if (g.resident) scanResident(g, queryLength);
         else scanStreamed(g, queryLength);

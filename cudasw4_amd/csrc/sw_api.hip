@@ -45,25 +45,27 @@ bool kind_packed(int kind) { return kind == SW_KIND_F16X2 || kind == SW_KIND_I16
 
 struct QueryPlan {
     int rows = 0;      // R: query rows per lane
-    int nstripes = 0;  // stripes of 16*R rows
+    int nstripes = 0;  // stripes of lanes*R rows
+    int lanes = 16;    // lanes per alignment group: 16 (DPP row) or 64 (whole wave, long subjects)
 };
 
-// Pick (R, nstripes) with R a compiled value: fewest stripes first, then the smallest R that covers
-// the query.  Replaces the reference's subject-length -> (group_size, numRegs) table
-// (cudasw4.cuh:1764-1912); here the tile shape follows the QUERY length because the query is the
-// register-resident dimension.
-QueryPlan plan_query(int kind, int32_t qlen) {
+// Pick (R, nstripes) with R a compiled value.  Replaces the reference's subject-length ->
+// (group_size, numRegs) table (cudasw4.cuh:1764-1912); here the tile shape follows the QUERY length
+// because the query is the register-resident dimension, and the subject length only selects the group
+// width: 16 lanes for the bulk of a DB, the whole wave for the long partitions 34/35.
+// Cost model: a step of a stripe with R rows per lane issues ~(R + 1.2) row-equivalents of VALU work
+// (per-step DPP/address overhead) and every stripe pays its own pipeline fill; minimise ns * (R + 1.2).
+QueryPlan plan_query(int kind, int32_t qlen, int lanes) {
     const swk::KindLaunch* kl = kind_launch(kind);
     QueryPlan pl;
+    pl.lanes = lanes;
     if (!kl || qlen <= 0) return pl;
-    const int maxrows = kl->max_rows;
-    const int64_t stripe_max = (int64_t)swk::kGroup * maxrows;
+    const int maxrows = swk::max_rows(kl->packed, lanes);
+    const int64_t stripe_max = (int64_t)lanes * maxrows;
     const int ns_min = (int)((qlen + stripe_max - 1) / stripe_max);
-    // cost model: a step of a stripe with R rows per lane issues ~(R + 1.2) row-equivalents of VALU work
-    // (per-step DPP/address overhead) and every stripe pays its own pipeline fill; minimise ns * (R + 1.2).
     double best = 1e300;
     for (int ns = ns_min; ns <= ns_min + 2; ns++) {
-        const int64_t per_lane = (qlen + (int64_t)swk::kGroup * ns - 1) / ((int64_t)swk::kGroup * ns);
+        const int64_t per_lane = (qlen + (int64_t)lanes * ns - 1) / ((int64_t)lanes * ns);
         int r = (int)((per_lane + swk::kRowsGranule - 1) / swk::kRowsGranule * swk::kRowsGranule);
         r = std::min(std::max(r, swk::kRowsGranule), maxrows);
         if (ns > 1 && 2 * r <= maxrows) continue;  // multi-stripe kernels exist for R > max/2 only
@@ -83,33 +85,51 @@ struct Profile {
 
 }  // namespace
 
+constexpr uint32_t kWorkSlots = 4096;
+
 struct sw_ctx {
     int device = 0;
     int num_cus = 0;
     int8_t* d_matrix = nullptr;  // 21 x 21
     uint32_t* d_zeros = nullptr; // 256 bytes of zeros (first-stripe border)
+    uint32_t* d_work = nullptr;  // kWorkSlots batch counters (dynamic batch distribution), one per launch in flight
+    uint32_t work_next = 0;
     bool have_matrix = false;
     int8_t* d_query = nullptr;
     size_t query_capacity = 0;
     int32_t qlen = 0;
     bool have_query = false;
-    Profile profiles[4];
+    Profile profiles[4][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups]
 };
 
 namespace {
 
 int max_grid(const sw_ctx* ctx) { return std::max(1, ctx->num_cus) * 4; }
 
-int ensure_profile(sw_ctx* ctx, int kind, hipStream_t stream) {
-    Profile& pr = ctx->profiles[kind];
+// Reference partitions 34 (1281..8000) and 35 (> 8000) hold the long subjects.  When there are only a few
+// of them (the tail of a real DB) they get the wave-wide group shape: 4x the lanes per alignment, so the
+// giants finish 4x sooner.  When the partition alone can fill the GPU several times (e.g. the L=2048
+// peak DB) the 16-lane shape is more efficient (more rows per lane, less per-step overhead).
+// overflowed subjects can have any length: long ones would dominate a 16-lane launch
+int rescore_lanes(int32_t max_subject_len) { return max_subject_len > 1280 ? 64 : 16; }
+
+int lanes_for_partition(const sw_ctx* ctx, int part_id, int32_t n) {
+    if (part_id < SW_NUM_LENGTH_PARTITIONS - 2) return 16;
+    const int64_t fills_gpu_twice = (int64_t)2 * std::max(1, ctx->num_cus) * 4 * 32;
+    return n >= fills_gpu_twice ? 16 : 64;
+}
+
+
+int ensure_profile(sw_ctx* ctx, int kind, int lanes, hipStream_t stream) {
+    Profile& pr = ctx->profiles[kind][lanes == 64];
     if (pr.valid) {
         // built on another stream earlier in this query: order this stream after the build
         SW_HIP(hipStreamWaitEvent(stream, pr.ready, 0));
         return SW_OK;
     }
     const swk::KindLaunch* kl = kind_launch(kind);
-    const QueryPlan pl = plan_query(kind, ctx->qlen);
-    const size_t bytes = kl->tile_bytes(pl.rows) * (size_t)pl.nstripes;
+    const QueryPlan pl = plan_query(kind, ctx->qlen, lanes);
+    const size_t bytes = kl->tile_bytes(pl.rows, lanes) * (size_t)pl.nstripes;
     if (bytes == 0) return fail(SW_ERR_INVALID, "no kernel compiled for this query plan");
     if (bytes > pr.capacity) {
         if (pr.dev) SW_HIP(hipFree(pr.dev));
@@ -118,7 +138,7 @@ int ensure_profile(sw_ctx* ctx, int kind, hipStream_t stream) {
         SW_HIP(hipMalloc(&pr.dev, bytes));
         pr.capacity = bytes;
     }
-    SW_HIP(kl->profile(pl.rows, ctx->d_query, ctx->qlen, ctx->d_matrix, pl.nstripes, pr.dev, stream));
+    SW_HIP(kl->profile(pl.rows, lanes, ctx->d_query, ctx->qlen, ctx->d_matrix, pl.nstripes, pr.dev, stream));
     if (!pr.ready) SW_HIP(hipEventCreateWithFlags(&pr.ready, hipEventDisableTiming));
     SW_HIP(hipEventRecord(pr.ready, stream));
     pr.plan = pl;
@@ -127,16 +147,16 @@ int ensure_profile(sw_ctx* ctx, int kind, hipStream_t stream) {
 }
 
 // scratch words per (workgroup, group) array for subjects up to max_len
-int32_t border_capacity(int32_t max_len) {
-    const int64_t steps = ((int64_t)max_len + swk::kGroup - 1 + 3) / 4 * 4;
+int32_t border_capacity(int32_t max_len, int lanes) {
+    const int64_t steps = ((int64_t)max_len + lanes - 1 + 3) / 4 * 4;
     return (int32_t)((steps + 15) / 16 * 16 + 16);  // + one prefetched quad past the end, rounded to 64 bytes
 }
-constexpr size_t kBorderJunkWords = 64;
-size_t border_bytes_per_wg(int32_t lcap) {
-    return (size_t)swk::kGroupsPerWg * 2 * ((size_t)lcap + kBorderJunkWords) * sizeof(uint32_t);
+size_t border_bytes_per_wg(int32_t lcap, int lanes) {
+    const size_t junk = lanes == 16 ? swk::border_junk_words<16>() : swk::border_junk_words<64>();
+    return (size_t)(swk::kThreads / lanes) * 2 * ((size_t)lcap + junk) * sizeof(uint32_t);
 }
 
-int scan_common(sw_ctx* ctx, int kind, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
+int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
                 const int32_t* positions, const int32_t* count_ptr, int32_t first_pos, int32_t n,
                 int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
                 int32_t* ovf_pos, int32_t* ovf_count, int ovf_check, void* temp, size_t temp_bytes,
@@ -153,12 +173,13 @@ int scan_common(sw_ctx* ctx, int kind, const int8_t* chars, const uint64_t* offs
     if (!chars || !offsets || !lengths || !scores || !ids) return fail(SW_ERR_INVALID, "null buffer");
     if (ovf_check && kind_packed(kind) && (!ovf_pos || !ovf_count)) return fail(SW_ERR_INVALID, "overflow check without overflow buffers");
     SW_HIP(hipSetDevice(ctx->device));
-    int rc = ensure_profile(ctx, kind, stream);
+    int rc = ensure_profile(ctx, kind, lanes, stream);
     if (rc != SW_OK) return rc;
-    const QueryPlan pl = ctx->profiles[kind].plan;
+    const Profile& prof = ctx->profiles[kind][lanes == 64];
+    const QueryPlan pl = prof.plan;
     const bool multi = pl.nstripes > 1;
 
-    const int subj_per_batch = swk::kGroupsPerWg * (kind_packed(kind) ? 2 : 1);
+    const int subj_per_batch = (swk::kThreads / lanes) * (kind_packed(kind) ? 2 : 1);
     const int nbatches = (n + subj_per_batch - 1) / subj_per_batch;
     int grid = std::min(nbatches, max_grid(ctx));
 
@@ -166,7 +187,7 @@ int scan_common(sw_ctx* ctx, int kind, const int8_t* chars, const uint64_t* offs
     p.chars = chars; p.offsets = offsets; p.lengths = lengths;
     p.positions = positions; p.count_ptr = count_ptr;
     p.first_pos = first_pos; p.n = n;
-    p.profile = ctx->profiles[kind].dev; p.nstripes = pl.nstripes;
+    p.profile = prof.dev; p.nstripes = pl.nstripes;
     switch (kind) {
         case SW_KIND_F16X2: p.gop = swk::Arith<swk::F16X2>::encode_gap(gop); p.gex = swk::Arith<swk::F16X2>::encode_gap(gex); break;
         case SW_KIND_I16X2: p.gop = swk::Arith<swk::I16X2>::encode_gap(gop); p.gex = swk::Arith<swk::I16X2>::encode_gap(gex); break;
@@ -177,13 +198,17 @@ int scan_common(sw_ctx* ctx, int kind, const int8_t* chars, const uint64_t* offs
     p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;
     p.scratch = nullptr; p.lcap = 0; p.zeros = ctx->d_zeros;
     if (multi) {
-        p.lcap = border_capacity(max_subject_len);
-        const size_t per_wg = border_bytes_per_wg(p.lcap);
+        p.lcap = border_capacity(max_subject_len, lanes);
+        const size_t per_wg = border_bytes_per_wg(p.lcap, lanes);
         if (!temp || temp_bytes < per_wg) return fail(SW_ERR_TEMP, "temp buffer too small for a multi-stripe query");
         grid = (int)std::min<size_t>((size_t)grid, temp_bytes / per_wg);
         p.scratch = static_cast<uint32_t*>(temp);
     }
-    SW_HIP(kl->scan(pl.rows, multi, grid, stream, p));
+    // batches are handed out through an atomic counter (longest subjects first): workgroups that start late
+    // because another launch still holds the CUs simply take fewer batches
+    p.work_counter = ctx->d_work + (ctx->work_next++ % kWorkSlots);
+    SW_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream));
+    SW_HIP(kl->scan(pl.rows, lanes, multi, grid, stream, p));
     return SW_OK;
 }
 
@@ -215,6 +240,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     ctx->num_cus = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(ctx->d_zeros, 0, 256);
     if (e != hipSuccess) { delete ctx; return fail(SW_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     *out = ctx;
@@ -226,11 +252,13 @@ int sw_ctx_destroy(sw_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->d_matrix) (void)hipFree(ctx->d_matrix);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_query) (void)hipFree(ctx->d_query);
-    for (auto& pr : ctx->profiles) {
-        if (pr.dev) (void)hipFree(pr.dev);
-        if (pr.ready) (void)hipEventDestroy(pr.ready);
-    }
+    for (auto& row : ctx->profiles)
+        for (auto& pr : row) {
+            if (pr.dev) (void)hipFree(pr.dev);
+            if (pr.ready) (void)hipEventDestroy(pr.ready);
+        }
     delete ctx;
     return SW_OK;
 }
@@ -244,7 +272,8 @@ int sw_set_matrix(sw_ctx* ctx, const int8_t* matrix_host, int dim) {
     SW_HIP(hipSetDevice(ctx->device));
     SW_HIP(hipMemcpy(ctx->d_matrix, matrix_host, dim * dim, hipMemcpyHostToDevice));
     ctx->have_matrix = true;
-    for (auto& pr : ctx->profiles) pr.valid = false;
+    for (auto& row : ctx->profiles)
+        for (auto& pr : row) pr.valid = false;
     return SW_OK;
 }
 
@@ -268,23 +297,28 @@ int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void
     SW_HIP(hipStreamSynchronize(s));  // host buffer may be reused by the caller immediately
     ctx->qlen = qlen;
     ctx->have_query = true;
-    for (auto& pr : ctx->profiles) pr.valid = false;
+    for (auto& row : ctx->profiles)
+        for (auto& pr : row) pr.valid = false;
     return SW_OK;
 }
 
 int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstripes) {
     if (!kind_launch(kind) || qlen <= 0) return fail(SW_ERR_INVALID, "bad kind or query length");
-    const QueryPlan pl = plan_query(kind, qlen);
+    const QueryPlan pl = plan_query(kind, qlen, 16);
     if (rows_per_lane) *rows_per_lane = pl.rows;
     if (nstripes) *nstripes = pl.nstripes;
     return SW_OK;
 }
 
-size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int32_t max_subject_len) {
-    if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0) return 0;
-    const QueryPlan pl = plan_query(kind, ctx->qlen);
+size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
+    if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0 || n <= 0) return 0;
+    const int lanes = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, part_id, n);
+    const QueryPlan pl = plan_query(kind, ctx->qlen, lanes);
     if (pl.nstripes <= 1) return 0;
-    return (size_t)max_grid(ctx) * border_bytes_per_wg(border_capacity(max_subject_len));
+    const int subj_per_batch = (swk::kThreads / lanes) * (kind_packed(kind) ? 2 : 1);
+    const int64_t nbatches = ((int64_t)n + subj_per_batch - 1) / subj_per_batch;
+    const int64_t grid = std::min<int64_t>(nbatches, max_grid(ctx));
+    return (size_t)grid * border_bytes_per_wg(border_capacity(max_subject_len, lanes), lanes);
 }
 
 int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, const uint64_t* offsets,
@@ -292,7 +326,8 @@ int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, c
                       float* scores, int32_t* ids, int64_t id_offset, int32_t* ovf_pos, int32_t* ovf_count,
                       int ovf_check, void* temp, size_t temp_bytes, void* stream) {
     if (part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS) return fail(SW_ERR_INVALID, "partition id out of range");
-    return scan_common(ctx, kind, chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    return scan_common(ctx, kind, lanes_for_partition(ctx, part_id, n), chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
                        scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
                        static_cast<hipStream_t>(stream));
 }
@@ -306,7 +341,8 @@ int sw_rescore_overflow(sw_ctx* ctx, int kind, const int32_t* ovf_pos, const int
     if (max_count <= 0) return SW_OK;
     // grid sized for max_count; the kernel reads the real count on the device (no host round trip,
     // no device-side launch — cf. float_kernels.cuh:1206-1258)
-    return scan_common(ctx, kind, chars, offsets, lengths, ovf_pos, ovf_count, 0, max_count, max_subject_len, gop, gex,
+    const int lanes = rescore_lanes(max_subject_len);
+    return scan_common(ctx, kind, lanes, chars, offsets, lengths, ovf_pos, ovf_count, 0, max_count, max_subject_len, gop, gex,
                        scores, ids, id_offset, nullptr, nullptr, 0, temp, temp_bytes, static_cast<hipStream_t>(stream));
 }
 

@@ -35,8 +35,8 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kGroup = 16;        // lanes per alignment group (one DPP row)
-constexpr int kThreads = 256;     // workgroup size: 4 waves, 16 groups
+constexpr int kGroup = 16;        // lanes per alignment group in the standard shape (one DPP row)
+constexpr int kThreads = 256;     // workgroup size: 4 waves = 16 row groups or 4 wave-wide groups
 constexpr int kGroupsPerWg = kThreads / kGroup;
 constexpr int kPadLetter = 20;    // code used for padding rows / columns
 constexpr int kLetters = 21;
@@ -44,9 +44,21 @@ constexpr int kLetters = 21;
 enum { F16X2 = 0, I16X2 = 1, I32 = 2, F32 = 3 };
 
 // DPP controls (GFX9 encoding)
-constexpr int DPP_ROW_SHL1 = 0x101;  // lane i <- lane i+1 (within a row of 16)
-constexpr int DPP_ROW_SHR1 = 0x111;  // lane i <- lane i-1
+constexpr int DPP_ROW_SHL1 = 0x101;   // lane i <- lane i+1 (within a row of 16)
+constexpr int DPP_ROW_SHR1 = 0x111;   // lane i <- lane i-1
 constexpr int DPP_ROW_ROR1 = 0x121;
+constexpr int DPP_WAVE_SHL1 = 0x130;  // the same across all 64 lanes of the wave
+constexpr int DPP_WAVE_SHR1 = 0x138;
+
+// The group shape: LANES = 16 (one DPP row per alignment group, 4 groups per wave: the bulk of a DB) or
+// LANES = 64 (the whole wave is one anti-diagonal pipeline: long subjects, 4x the lanes per alignment so
+// that the few giant sequences of a real DB do not become the tail of the scan).
+template <int LANES>
+struct Shift {
+    static_assert(LANES == 16 || LANES == 64, "group = DPP row or whole wave");
+    static constexpr int kShr1 = LANES == 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
+    static constexpr int kShl1 = LANES == 16 ? DPP_ROW_SHL1 : DPP_WAVE_SHL1;
+};
 
 template <int CTRL, bool ZERO_FILL>
 __device__ __forceinline__ u32 dpp(u32 old, u32 src) {
@@ -165,16 +177,20 @@ struct Arith<F32> {
 //   letter row  = NCH chunks-rows of 256 bytes: chunk k of lane l at  k*256 + l*16
 //   tile        = 21 letter rows, preceded by 16 bytes (lane addresses carry a +16 bias, see Step)
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int R>
+template <int KIND, int R, int LANES = kGroup>
 struct Geometry {
     static constexpr bool kPacked = Arith<KIND>::kPacked;
     static_assert(!kPacked || (R % 2 == 0), "packed kinds need an even number of rows per lane");
     static constexpr int NW = kPacked ? R / 2 : R;
     static constexpr int NCH = (NW + 3) / 4;
-    static constexpr int kRowBytes = NCH * 256;
+    static constexpr int kChunkRowBytes = LANES * 16;            // chunk k of lane l at k*kChunkRowBytes + l*16
+    static constexpr int kRowBytes = NCH * kChunkRowBytes;
     static constexpr int kTileBytes = kLetters * kRowBytes;
-    static constexpr int kStripeRows = kGroup * R;
-    static_assert(kPadLetter * NCH < 256, "letter offset must fit a byte");
+    static constexpr int kStripeRows = LANES * R;
+    // a letter travels as (letter * kLetterUnits) in one byte; its row offset is that byte << kLetterShift
+    static constexpr int kLetterShift = LANES == 16 ? 8 : 10;
+    static constexpr int kLetterUnits = kRowBytes >> kLetterShift;
+    static_assert(kPadLetter * kLetterUnits < 256, "letter offset must fit a byte");
 };
 
 struct ScanParams {
@@ -197,25 +213,26 @@ struct ScanParams {
     u32* scratch;              // stripe-border spill: per (workgroup, group): [64 junk][H lcap][64 junk][F lcap]
     int32_t lcap;
     const u32* zeros;          // >= 64 bytes of zeros (border of the first stripe)
+    u32* work_counter;         // zeroed before the launch: next batch to hand out
 };
 
-template <int NW>
+template <int NW, int CHUNK_ROW_BYTES>
 __device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned char* p) {
     constexpr int N4 = NW / 4, REM = NW % 4;
 #pragma unroll
     for (int k = 0; k < N4; k++) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p + k * 256);
+        const uint4 v = *reinterpret_cast<const uint4*>(p + k * CHUNK_ROW_BYTES);
         dst[4 * k + 0] = v.x; dst[4 * k + 1] = v.y; dst[4 * k + 2] = v.z; dst[4 * k + 3] = v.w;
     }
     if constexpr (REM == 1) {
-        dst[4 * N4] = *reinterpret_cast<const u32*>(p + N4 * 256);
+        dst[4 * N4] = *reinterpret_cast<const u32*>(p + N4 * CHUNK_ROW_BYTES);
     } else if constexpr (REM == 2) {
-        const uint2 v = *reinterpret_cast<const uint2*>(p + N4 * 256);
+        const uint2 v = *reinterpret_cast<const uint2*>(p + N4 * CHUNK_ROW_BYTES);
         dst[4 * N4] = v.x; dst[4 * N4 + 1] = v.y;
     } else if constexpr (REM == 3) {
-        const uint2 v = *reinterpret_cast<const uint2*>(p + N4 * 256);
+        const uint2 v = *reinterpret_cast<const uint2*>(p + N4 * CHUNK_ROW_BYTES);
         dst[4 * N4] = v.x; dst[4 * N4 + 1] = v.y;
-        dst[4 * N4 + 2] = *reinterpret_cast<const u32*>(p + N4 * 256 + 8);
+        dst[4 * N4 + 2] = *reinterpret_cast<const u32*>(p + N4 * CHUNK_ROW_BYTES + 8);
     }
 }
 
@@ -235,33 +252,35 @@ struct StripeState {
 //   BYTE    which byte of the letter words feeds lane 0 in this step
 //   MULTI   stripe borders in play: lane 0 takes (inH, inF) — the previous stripe's bottom row at this
 //           column — instead of the zero boundary; the caller stores lane 15's (Hlast, Fout) afterwards
-template <int KIND, int R, int BYTE, bool MULTI>
+template <int KIND, int R, int LANES, int BYTE, bool MULTI>
 __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned char* tile,
                                         u32 lettersA, u32 lettersB, u32 gop, u32 gex, u32 inH, u32 inF) {
     using A = Arith<KIND>;
-    using G = Geometry<KIND, R>;
-    constexpr u32 kSel = 0x0c0c000cu | ((u32)BYTE << 8);  // letter byte BYTE -> bits 15:8 (= offset/256)
+    using G = Geometry<KIND, R, LANES>;
+    constexpr int SHR1 = Shift<LANES>::kShr1;
+    constexpr u32 kSel = 0x0c0c000cu | ((u32)BYTE << 8);  // letter byte BYTE -> bits 15:8
+    constexpr int kPostShift = G::kLetterShift - 8;        // row offset = byte << kLetterShift
 
-    // subject letter(s): shift along the row, lane 0 takes the next letter of its subject
-    const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel);
-    st.yA = dpp<DPP_ROW_SHR1, false>(injA, st.yA) + 16u;
+    // subject letter(s): shift along the group, lane 0 takes the next letter of its subject
+    const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel) << kPostShift;
+    st.yA = dpp<SHR1, false>(injA, st.yA) + 16u;
     u32 wa[G::NW];
-    lds_read_words<G::NW>(wa, tile + st.yA);
+    lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + st.yA);
     u32 wb[G::NW];
     if constexpr (A::kPacked) {
-        const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel);
-        st.yB = dpp<DPP_ROW_SHR1, false>(injB, st.yB) + 16u;
-        lds_read_words<G::NW>(wb, tile + st.yB);
+        const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel) << kPostShift;
+        st.yB = dpp<SHR1, false>(injB, st.yB) + 16u;
+        lds_read_words<G::NW, G::kChunkRowBytes>(wb, tile + st.yB);
     }
 
     // row above the lane's first row: from the neighbouring lane, or from the stripe border
     u32 upH, F;
     if constexpr (MULTI) {
-        upH = dpp<DPP_ROW_SHR1, false>(inH, st.Hlast);  // lane 0 keeps `old` == the border value
-        F = dpp<DPP_ROW_SHR1, false>(inF, st.Fout);
+        upH = dpp<SHR1, false>(inH, st.Hlast);  // lane 0 keeps `old` == the border value
+        F = dpp<SHR1, false>(inF, st.Fout);
     } else {
-        upH = dpp<DPP_ROW_SHR1, true>(0u, st.Hlast);
-        F = dpp<DPP_ROW_SHR1, true>(0u, st.Fout);
+        upH = dpp<SHR1, true>(0u, st.Hlast);
+        F = dpp<SHR1, true>(0u, st.Fout);
     }
     u32 diag = st.upH_prev;
     st.upH_prev = upH;
@@ -305,34 +324,46 @@ __device__ __forceinline__ void load_tile(unsigned char* lds, const unsigned cha
     for (int i = threadIdx.x; i < TILE_BYTES / 16; i += kThreads) dst[i] = src[i];
 }
 
-template <int KIND>
-__device__ __forceinline__ u32 row_max(u32 v) {
+template <int KIND, int LANES>
+__device__ __forceinline__ u32 group_max(u32 v) {
     using A = Arith<KIND>;
     v = A::max2(v, dpp<0x128, false>(v, v));  // row_ror:8
     v = A::max2(v, dpp<0x124, false>(v, v));  // row_ror:4
     v = A::max2(v, dpp<0x122, false>(v, v));  // row_ror:2
     v = A::max2(v, dpp<0x121, false>(v, v));  // row_ror:1
+    if constexpr (LANES == 64) {
+        v = A::max2(v, (u32)__shfl_xor((int)v, 16));
+        v = A::max2(v, (u32)__shfl_xor((int)v, 32));
+    }
     return v;
 }
 
 // ------------------------------------------------------------------------------------------------
-// The scan kernel.  Persistent workgroups stride over batches of 16 groups (32 or 16 subjects),
-// longest subjects first.  MULTI == the query needs more than one stripe.
+// The scan kernel.  Persistent workgroups stride over batches of groups (LANES = 16: 16 groups, 32 or 16
+// subjects per batch; LANES = 64: 4 groups), longest subjects first.  MULTI == the query needs more than
+// one stripe.
 // ------------------------------------------------------------------------------------------------
+template <int LANES>
+constexpr int border_junk_words() { return LANES == 16 ? 128 : 320; }  // >= 4*(LANES-1) + LANES, multiple of 64
+
 #ifndef SWK_MIN_WAVES
 #define SWK_MIN_WAVES 1  // minimum waves per SIMD the register allocator must leave room for (tuning knob)
 #endif
-template <int KIND, int R, bool MULTI>
+template <int KIND, int R, int LANES, bool MULTI>
 __global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const ScanParams p) {
     using A = Arith<KIND>;
-    using G = Geometry<KIND, R>;
+    using G = Geometry<KIND, R, LANES>;
+    constexpr int kGroups = kThreads / LANES;
+    constexpr int kJunk = border_junk_words<LANES>();
+    constexpr int SHL1 = Shift<LANES>::kShl1;
+    constexpr int kQuadsPerLetterBlock = LANES;  // a lane holds 4 letters: LANES quads per reload
     __shared__ __attribute__((aligned(16))) unsigned char lds[16 + G::kTileBytes];
 
     const int tid = threadIdx.x;
-    const int lane16 = tid & (kGroup - 1);
-    const int group = tid >> 4;
+    const int lane = tid & (LANES - 1);  // position in the alignment group
+    const int group = tid / LANES;
     const int n = p.count_ptr ? *p.count_ptr : p.n;
-    constexpr int kSubjPerBatch = kGroupsPerWg * A::kSubjects;
+    constexpr int kSubjPerBatch = kGroups * A::kSubjects;
     const int nbatches = (n + kSubjPerBatch - 1) / kSubjPerBatch;
     if ((int)blockIdx.x >= nbatches) return;  // workgroup-uniform (device-side count of the re-score path)
 
@@ -341,14 +372,21 @@ __global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const 
         __syncthreads();
     }
 
-    // Stripe-border spill of this group: H[lcap] and F[lcap], each preceded by 64 junk words.  The loop
-    // is kept branch-free: EVERY lane loads and stores each step, but only lane 0's load address and
-    // lane 15's store address walk the real arrays; the other lanes hit the junk words (lane 15's stores
-    // for columns t-15 < 0 land there too).
-    u32* const borderH = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroupsPerWg + group) * 2 * ((size_t)p.lcap + 64) + 64 : nullptr;
-    u32* const borderF = MULTI ? borderH + p.lcap + 64 : nullptr;
+    // Stripe-border spill of this group: H[lcap] and F[lcap], each preceded by kJunk junk words.  The loop
+    // is kept branch-free: EVERY lane loads and stores each step, but only lane 0's load address and the
+    // last lane's store address walk the real arrays; the other lanes hit the junk words (the last lane's
+    // stores for columns t-(LANES-1) < 0 land there too).
+    u32* const borderH = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroups + group) * 2 * ((size_t)p.lcap + kJunk) + kJunk : nullptr;
+    u32* const borderF = MULTI ? borderH + p.lcap + kJunk : nullptr;
 
-    for (int b = blockIdx.x; b < nbatches; b += gridDim.x) {
+    __shared__ int next_batch;
+    for (;;) {
+        // dynamic batch distribution: one atomic per workgroup per batch
+        __syncthreads();
+        if (tid == 0) next_batch = (int)atomicAdd(p.work_counter, 1u);
+        __syncthreads();
+        const int b = next_batch;
+        if (b >= nbatches) break;
         const int batch = nbatches - 1 - b;  // DB is length-sorted ascending: longest first
         const int i0 = batch * kSubjPerBatch + group * A::kSubjects;
         const int i1 = i0 + 1;
@@ -368,16 +406,17 @@ __global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const 
             s1 = p.chars + (p.offsets[pos1] - p.offsets[0]);
         }
         int lmax = len0 > len1 ? len0 : len1;
-        lmax = max(lmax, __shfl_xor(lmax, 16));
-        lmax = max(lmax, __shfl_xor(lmax, 32));
-        // lane 15 finishes column lmax-1 at step lmax+14
-        const int nquads = (lmax + kGroup - 1 + 3) >> 2;
+        if constexpr (LANES == 16) {  // the 4 groups of a wave run in lock-step
+            lmax = max(lmax, __shfl_xor(lmax, 16));
+            lmax = max(lmax, __shfl_xor(lmax, 32));
+        }
+        // the last lane finishes column lmax-1 at step lmax+LANES-2
+        const int nquads = (lmax + LANES - 1 + 3) >> 2;
         const int len0pad = (len0 + 3) & ~3, len1pad = (len1 + 3) & ~3;
 
         u32 maxv = 0;
         for (int stripe = 0; stripe < p.nstripes; stripe++) {
             const bool first = stripe == 0;
-            const bool last = stripe == p.nstripes - 1;
             if constexpr (MULTI) {
                 __syncthreads();
                 load_tile<G::kTileBytes>(lds, p.profile + (size_t)stripe * G::kTileBytes);
@@ -387,30 +426,30 @@ __global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const 
 #pragma unroll
             for (int r = 0; r < R; r++) { st.H[r] = 0; st.E[r] = 0; }
             st.upH_prev = 0; st.Hlast = 0; st.Fout = 0; st.maxv = maxv;
-            st.yA = ((u32)(kPadLetter * G::NCH) << 8) + 16u * (u32)(lane16 + 1);
+            st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
             st.yB = st.yA;
 
-            // subject letters: lane l holds letters 64*blk + 4l .. +3 of each subject, premultiplied
-            // by NCH so that a byte is the letter row offset / 256
+            // subject letters: lane l holds letters 4*LANES*blk + 4l .. +3 of each subject, premultiplied
+            // by kLetterUnits so that a byte << kLetterShift is the byte offset of the letter's profile row
             auto fetch = [&](const int8_t* s, int lenpad, int blk) -> u32 {
-                const int j = blk * 64 + lane16 * 4;
+                const int j = blk * (4 * LANES) + lane * 4;
                 u32 w = 0x14141414u;
                 if (j < lenpad) w = *reinterpret_cast<const u32*>(s + j);
-                return w * (u32)G::NCH;
+                return w * (u32)G::kLetterUnits;
             };
             u32 nextA = fetch(s0, len0pad, 0);
             u32 nextB = A::kPacked ? fetch(s1, len1pad, 0) : 0u;
             u32 lettersA = 0, lettersB = 0;
 
             // stripe border (MULTI only): lane 0 reads the previous stripe's bottom row four columns per
-            // quad, one quad ahead (2 x 16-byte loads); lane 15 stores its own bottom row every step.
+            // quad, one quad ahead (2 x 16-byte loads); the last lane stores its own bottom row every step.
             uint4 curH = make_uint4(0, 0, 0, 0), curF = curH, nextH = curH, nextF = curH;
-            const int walkIn = (lane16 == 0 && !first) ? 4 : 0;       // words per quad the load address advances
-            const int walkOut = (lane16 == kGroup - 1) ? 4 : 0;
-            const u32* inH = (lane16 == 0 && !first) ? borderH : p.zeros;
-            const u32* inF = (lane16 == 0 && !first) ? borderF : p.zeros;
-            u32* outH = (lane16 == kGroup - 1) ? borderH - (kGroup - 1) : borderH - 64 + 4 * lane16;
-            u32* outF = (lane16 == kGroup - 1) ? borderF - (kGroup - 1) : borderF - 64 + 4 * lane16;
+            const int walkIn = (lane == 0 && !first) ? 4 : 0;  // words per quad the load address advances
+            const int walkOut = (lane == LANES - 1) ? 4 : 0;
+            const u32* inH = (lane == 0 && !first) ? borderH : p.zeros;
+            const u32* inF = (lane == 0 && !first) ? borderF : p.zeros;
+            u32* outH = (lane == LANES - 1) ? borderH - (LANES - 1) : borderH - kJunk + 4 * lane;
+            u32* outF = (lane == LANES - 1) ? borderF - (LANES - 1) : borderF - kJunk + 4 * lane;
             if constexpr (MULTI) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 nextH = *reinterpret_cast<const uint4*>(inH);
@@ -418,10 +457,10 @@ __global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const 
             }
 
             for (int q = 0; q < nquads; q++) {
-                if ((q & 15) == 0) {
+                if ((q & (kQuadsPerLetterBlock - 1)) == 0) {
                     lettersA = nextA; lettersB = nextB;
-                    nextA = fetch(s0, len0pad, (q >> 4) + 1);
-                    if constexpr (A::kPacked) nextB = fetch(s1, len1pad, (q >> 4) + 1);
+                    nextA = fetch(s0, len0pad, q / kQuadsPerLetterBlock + 1);
+                    if constexpr (A::kPacked) nextB = fetch(s1, len1pad, q / kQuadsPerLetterBlock + 1);
                 }
                 if constexpr (MULTI) {
                     curH = nextH; curF = nextF;
@@ -429,30 +468,30 @@ __global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const 
                     nextH = *reinterpret_cast<const uint4*>(inH);
                     nextF = *reinterpret_cast<const uint4*>(inF);
                 }
-                dp_step<KIND, R, 0, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x);
+                dp_step<KIND, R, LANES, 0, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x);
                 if constexpr (MULTI) { outH[0] = st.Hlast; outF[0] = st.Fout; }
-                dp_step<KIND, R, 1, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y);
+                dp_step<KIND, R, LANES, 1, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y);
                 if constexpr (MULTI) { outH[1] = st.Hlast; outF[1] = st.Fout; }
-                dp_step<KIND, R, 2, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z);
+                dp_step<KIND, R, LANES, 2, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z);
                 if constexpr (MULTI) { outH[2] = st.Hlast; outF[2] = st.Fout; }
-                dp_step<KIND, R, 3, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w);
+                dp_step<KIND, R, LANES, 3, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w);
                 if constexpr (MULTI) { outH[3] = st.Hlast; outF[3] = st.Fout; outH += walkOut; outF += walkOut; }
-                lettersA = dpp<DPP_ROW_SHL1, true>(0u, lettersA);
-                if constexpr (A::kPacked) lettersB = dpp<DPP_ROW_SHL1, true>(0u, lettersB);
+                lettersA = dpp<SHL1, true>(0u, lettersA);
+                if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
             }
             if constexpr (MULTI) {
-                // lane 15 reached column 4*nquads-16; the next stripe reads up to 4*nquads-1: zero the rest
-                if (lane16 < kGroup - 1) {
-                    borderH[4 * nquads - (kGroup - 1) + lane16] = 0;
-                    borderF[4 * nquads - (kGroup - 1) + lane16] = 0;
+                // the last lane reached column 4*nquads-LANES; the next stripe reads up to 4*nquads-1: zero the rest
+                if (lane < LANES - 1) {
+                    borderH[4 * nquads - (LANES - 1) + lane] = 0;
+                    borderF[4 * nquads - (LANES - 1) + lane] = 0;
                 }
             }
             maxv = st.maxv;
             if constexpr (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
 
-        maxv = row_max<KIND>(maxv);
-        if (lane16 == 0) {
+        maxv = group_max<KIND, LANES>(maxv);
+        if (lane == 0) {
             const int sc0 = A::score_lo(maxv);
             const int sc1 = A::score_hi(maxv);
             if (valid0) {
@@ -479,20 +518,21 @@ __global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const 
 // Profile builder: tile[stripe][letter][chunk][lane][4 words] from the encoded query and the matrix.
 // Replaces the per-block pair-table construction of the reference (half2_kernels.cuh:57-65).
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int R>
+template <int KIND, int R, int LANES>
 __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_t qlen,
                                         const int8_t* __restrict__ matrix21, int32_t nstripes,
                                         unsigned char* __restrict__ profile) {
     using A = Arith<KIND>;
-    using G = Geometry<KIND, R>;
+    using G = Geometry<KIND, R, LANES>;
     constexpr int kWordsPerRow = G::kRowBytes / 4;
+    constexpr int kWordsPerChunkRow = G::kChunkRowBytes / 4;
     const int total = nstripes * kLetters * kWordsPerRow;
     u32* out = reinterpret_cast<u32*>(profile);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int word = i % kWordsPerRow;
         const int letter = (i / kWordsPerRow) % kLetters;
         const int stripe = i / (kWordsPerRow * kLetters);
-        const int chunk = word / 64, lane = (word % 64) / 4, sub = word % 4;
+        const int chunk = word / kWordsPerChunkRow, lane = (word % kWordsPerChunkRow) / 4, sub = word % 4;
         const int w = chunk * 4 + sub;  // word index within the lane's NW words
         u32 v = 0;
         if (w < G::NW) {

@@ -165,7 +165,9 @@ class Searcher:
         self.db = None
         if matrix is not None:
             self.set_matrix(matrix)
-        self._temp = None
+        self._temps = {}           # one border scratch per concurrently running launch
+        self._side_streams = []
+        self.concurrent_runs = True  # launch the small long-subject runs on side streams next to the bulk run
         self._topk_temp = None
         self.record_kernel_events = False  # bench.py: HIP events around every DP launch
         self.kernel_events = []
@@ -200,19 +202,23 @@ class Searcher:
                 continue
             kind = kt.kind_for_partition(pid)
             maxlen = db.partition_max_length(pid)
-            if self.merge_partitions and runs and runs[-1]["kind"] == kind and runs[-1]["begin"] == e:
+            # partitions 34/35 (long subjects) run with wave-wide groups: never merged with 0..33
+            same_shape = bool(runs) and (runs[-1]["part_id"] >= NUM_PARTITIONS - 2) == (pid >= NUM_PARTITIONS - 2)
+            if self.merge_partitions and runs and runs[-1]["kind"] == kind and runs[-1]["begin"] == e and same_shape:
                 runs[-1]["begin"] = b
             else:
                 runs.append({"kind": kind, "part_id": pid, "begin": b, "end": e, "maxlen": maxlen})
         return runs
 
-    def _ensure_temp(self, nbytes):
+    def _ensure_temp(self, nbytes, slot=0):
         nbytes = min(int(nbytes), self.max_temp_bytes)
         if nbytes <= 0:
             return 0, 0
-        if self._temp is None or self._temp.numel() < nbytes:
-            self._temp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._temp.data_ptr(), self._temp.numel()
+        t = self._temps.get(slot)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._temps[slot] = t
+        return t.data_ptr(), t.numel()
 
     # -- the scan ------------------------------------------------------------------------------
     def scan(self, query_codes, timed=True, sync=True):
@@ -234,28 +240,55 @@ class Searcher:
         self.ovf_count.zero_()
         self.scores.fill_(-1.0)  # cudasw4.cuh:405-409
         packed_used = False
-        for run in self._plan:
+        # The reference round-robins partition launches over 10 work streams (cudasw4.cuh:293,1745-1748) so
+        # that small partitions overlap.  Here: the run with the most subjects stays on the caller's stream,
+        # the (few, long-subject) others go to side streams and are launched FIRST so that they hold their
+        # handful of workgroups while the bulk run fills the rest of the GPU.
+        plan = self._plan
+        main_idx = max(range(len(plan)), key=lambda i: plan[i]["end"] - plan[i]["begin"]) if plan else 0
+        use_side = self.concurrent_runs and len(plan) > 1
+        order = [i for i in range(len(plan)) if i != main_idx] + ([main_idx] if plan else [])
+        if use_side:
+            while len(self._side_streams) < len(plan) - 1:
+                self._side_streams.append(torch.cuda.Stream(device=self.device))
+            fork = torch.cuda.Event()
+            fork.record(stream)
+        joins = []
+        for slot, i in enumerate(order):
+            run = plan[i]
             kind = run["kind"]
             n = run["end"] - run["begin"]
-            tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(kind, run["maxlen"]))
+            on_side = use_side and i != main_idx
+            st = self._side_streams[slot] if on_side else stream
+            if on_side:
+                st.wait_event(fork)
+            tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(kind, run["part_id"], n, run["maxlen"]),
+                                             slot + 1 if on_side else 0)
             ovf_check = 1 if kind in capi.MAX_ACC else 0
             packed_used |= bool(ovf_check)
             if self.record_kernel_events:
                 k0 = torch.cuda.Event(enable_timing=True)
-                k0.record(stream)
+                k0.record(st)
             self.ctx.scan_partition(kind, run["part_id"], db.chars.data_ptr(), db.offsets.data_ptr(),
                                     db.lengths.data_ptr(), run["begin"], n, run["maxlen"], self.gop, self.gex,
                                     self.scores.data_ptr(), self.ids.data_ptr(), db.id_offset,
-                                    self.ovf_pos.data_ptr(), self.ovf_count.data_ptr(), ovf_check, tptr, tbytes, sp)
+                                    self.ovf_pos.data_ptr(), self.ovf_count.data_ptr(), ovf_check, tptr, tbytes,
+                                    st.cuda_stream)
             if self.record_kernel_events:
                 k1 = torch.cuda.Event(enable_timing=True)
-                k1.record(stream)
-                cells = float(len(q)) * (float(db.total_residues) if len(self._plan) == 1 else
+                k1.record(st)
+                cells = float(len(q)) * (float(db.total_residues) if len(plan) == 1 else
                                          float(db.lengths_host[run["begin"]:run["end"]].sum()))
                 self.kernel_events.append((k0, k1, cells))
+            if on_side:
+                j = torch.cuda.Event()
+                j.record(st)
+                joins.append(j)
+        for j in joins:
+            stream.wait_event(j)
         if packed_used:  # cudasw4.cuh:2117-2172
             okind = self.kernel_types.overflow
-            tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(okind, db.max_length))
+            tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(okind, -1, db.num_sequences, db.max_length))
             self.ctx.rescore_overflow(okind, self.ovf_pos.data_ptr(), self.ovf_count.data_ptr(), db.num_sequences,
                                       db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(),
                                       db.max_length, self.gop, self.gex, self.scores.data_ptr(), self.ids.data_ptr(),

@@ -75,16 +75,20 @@ int sw_set_matrix(sw_ctx* ctx, const int8_t* matrix_host, int dim);
  * 0..dim-1).  Builds the device-side query profile the kernels read (lazily, per kind). */
 int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void* stream);
 
-/* Bytes of temp memory sw_scan_partition / sw_rescore_overflow need for the CURRENT query with
- * subjects up to max_subject_len (0 when the query fits one stripe).  Replaces the reference's
- * tempBytesPerBlockPerBuffer / tempBytesPerSubjectPerBuffer sizing (cudasw4.cuh:1928-1938,2028-2033). */
-size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int32_t max_subject_len);
+/* Bytes of temp memory the sw_scan_partition call with the same (kind, part_id, n, max_subject_len) needs
+ * for the CURRENT query (0 when the query fits one stripe).  sw_rescore_overflow: pass part_id = -1 and
+ * n = max_count.  Replaces the reference's tempBytesPerBlockPerBuffer / tempBytesPerSubjectPerBuffer
+ * sizing (cudasw4.cuh:1928-1938,2028-2033).  Launches that run concurrently on different streams need
+ * separate temp buffers. */
+size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len);
 
 /* One length partition of one batch: replaces call_NW_local_affine_{single,multi}_pass_*
  * (kernels.cuh:31-164; dispatch cudasw4.cuh:1764-1912,1920-2096).
  *
  *   kind            SW_KIND_*
- *   part_id         reference length-partition index 0..35 (informational; any subject length works)
+ *   part_id         reference length-partition index 0..35.  Any subject length works with any id; ids 34/35
+ *                   (the long partitions) select the wave-wide group shape when n is small, so that a few
+ *                   giant subjects do not become the tail of the scan
  *   chars           DEVICE int8 codes, each subject padded to a multiple of 4 (dbdata layout)
  *   offsets         DEVICE uint64[>= first_pos+n+1]; offsets[i]-offsets[0] = byte offset of subject i
  *   lengths         DEVICE int32 true lengths
