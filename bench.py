@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--kernel", choices=sorted(KIND_BY_NAME), default="half2")
     ap.add_argument("--top", type=int, default=0, help="top-K per query (reference benchmark uses 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-subjects", type=int, default=1500)
+    ap.add_argument("--cpu-sample-subjects", type=int, default=40000)
     return ap.parse_args()
 
 
@@ -76,10 +76,18 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # test hooks (1-GPU boxes): BENCH_FORCE_DEVICE maps every rank onto one device, BENCH_DIST_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one GPU).  The driver's multi-GPU runs use neither.
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import oracle_lib as O  # query set + pseudo-DB residues (data only; the scan below is all HIP)
     from cudasw4_amd import capi, search
@@ -97,13 +105,24 @@ def main():
     s.set_database(db)
     s.record_kernel_events = False
 
-    def one_step(collect=None):
-        tops = []
-        for q in queries:
-            res = s.scan(q, timed=False, sync=False)
-            if args.top > 0:
-                tops.append(res)
-        return tops
+    merged_last = []
+
+    def one_step():
+        """20 scans.  With --top K > 0 every query also pays the per-rank top-K, its copy to the host and the
+        host-side merge over ranks (the only cross-rank step of the path: K (score, id) pairs per rank)."""
+        pending = [s.scan(q, timed=False, sync=False) for q in queries]
+        if args.top > 0:
+            merged_last.clear()
+            for res in pending:
+                s.finish(res)
+                mine = (res.scores.tolist(), res.reference_ids.tolist())
+                if distributed:
+                    gathered = [None] * world if rank == 0 else None
+                    dist.gather_object(mine, gathered, dst=0)
+                    if rank == 0:
+                        merged_last.append(search.merge_topk(gathered, args.top))
+                else:
+                    merged_last.append(search.merge_topk([mine], args.top))
 
     def barrier():
         if distributed:
@@ -122,7 +141,7 @@ def main():
     dt = time.perf_counter() - t0
     s.record_kernel_events = False
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
@@ -145,9 +164,21 @@ def main():
         hbm_gbs = bytes_per_launch / 1e9 / (avg_ms * 1e-3)
         kern_gcups = (sum(kern_cells) / 1e9) / (sum(kern_ms) * 1e-3) if kern_ms else 0.0
         packed = kind in (0, 1)
-        # VALU issue ceiling: 256 CU x 4 SIMD x 16 lanes... measured per-instruction rates are in DESIGN.md;
-        # planning figure 256 CU * 64 lanes/clk * 2.4 GHz lane-instr/s, 10 ops per cell(-pair)
-        valu_peak_gcups = 256 * 64 * 2.4e9 / 10 * (2 if packed else 1) / 1e9
+        # VALU issue ceiling (tools/ubench/valu_rate.hip): every op of the loop issues at one
+        # wave64 instruction per 4 cycles per SIMD = 64 lanes/clk/CU; 256 CUs at 2.4 GHz.
+        valu_peak_instr = 256 * 64 * 2.4e9
+        # VALU instructions the kernel issues per cell (pair), static count from the gfx950 ISA of the
+        # R=32 / R=16 loop bodies incl. per-step overhead
+        instr_per_unit = {0: 9.0, 1: 10.5, 2: 8.9, 3: 8.0}[kind]
+        units_per_s = kern_gcups * 1e9 / (2 if packed else 1)
+        achieved_instr = units_per_s * instr_per_unit
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "bench_traffic.json")
+        if os.path.exists(tpath) and kind == 0 and num == 1_000_000 and L == 512:
+            try:
+                traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+            except Exception:
+                traffic = None
         out = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True,
@@ -157,17 +188,23 @@ def main():
                        "db_subjects_per_gpu": num, "db_length": L, "queries": len(queries), "kernel": args.kernel,
                        "parallelism": "db-shard x%d, host top-K merge" % world},
             "roofline": {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(hbm_gbs / 8000.0, 6), "traffic": None,
+                         "frac": round(hbm_gbs / 8000.0, 6), "traffic": traffic,
                          "kernel": "sw_scan_kernel<%s>" % DTYPE_BY_KIND[kind], "avg_launch_ms": round(avg_ms, 4),
                          "launches": len(kern_ms), "algorithmic_bytes_per_launch": int(bytes_per_launch)},
-            "valu_roofline": {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(valu_peak_gcups, 1),
-                              "unit": "GCUPS", "frac": round(kern_gcups / valu_peak_gcups, 4),
-                              "note": "binding bound: packed 16-bit VALU issue (10 ops per cell pair), see DESIGN.md"},
+            "valu_roofline": {"bound": "valu-issue", "achieved": round(achieved_instr / 1e12, 3),
+                              "peak": round(valu_peak_instr / 1e12, 3), "unit": "T lane-instr/s",
+                              "frac": round(achieved_instr / valu_peak_instr, 4), "kernel_gcups": round(kern_gcups, 1),
+                              "instr_per_cell_pair" if packed else "instr_per_cell": instr_per_unit,
+                              "note": "the binding bound of this path (DESIGN.md §3): the DP recurrence is VALU-issue "
+                                      "bound, not HBM bound; roofline.frac above is the HBM view the contract asks for"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(queries, L, args.cpu_sample_subjects)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
+        if args.top > 0 and merged_last:
+            out["config"]["top_merged_example"] = {"query": len(queries) - 1, "scores": merged_last[-1][0].tolist(),
+                                                   "ids": merged_last[-1][1].tolist()}
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

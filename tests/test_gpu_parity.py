@@ -162,3 +162,72 @@ def test_full_size_peak_db_property():
             assert int(s.ids[:num].to(torch.int64).sum().item()) == num * (num - 1) // 2
             assert res.scores.tolist() == [exp] * 10 and res.reference_ids.tolist() == list(range(10))
             assert res.num_overflows == 0
+
+
+def test_temp_sizing_and_too_small_temp():
+    """sw_scan_temp_bytes is 0 for single-stripe queries, > 0 for longer ones; a temp buffer smaller than
+    one workgroup's border scratch is refused (SW_ERR_TEMP), a smaller-than-ideal one only shrinks the grid."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(4)
+    seqs = [rng.integers(0, 20, int(l)).astype(np.int8) for l in np.sort(rng.integers(100, 600, 4000))]
+    chars, offsets, lengths = O.make_db(seqs)
+    db = search.DeviceDB.from_arrays(chars, offsets, lengths, device=0)
+    ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    n = len(seqs)
+    scores = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+    ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    q_short = rng.integers(0, 20, 300).astype(np.int8)
+    q_long = rng.integers(0, 20, 1300).astype(np.int8)
+    ctx.set_query(q_short)
+    assert ctx.scan_temp_bytes(capi.KIND_F16X2, 20, n, 600) == 0
+    ctx.set_query(q_long)
+    need = ctx.scan_temp_bytes(capi.KIND_F16X2, 20, n, 600)
+    assert need > 0
+    args = (capi.KIND_F16X2, 20, db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(), 0, n, 600, -11, -1,
+            scores.data_ptr(), ids.data_ptr(), 0, ovf_pos.data_ptr(), ovf_cnt.data_ptr(), 1)
+    with pytest.raises(capi.SwError) as ei:
+        ctx.scan_partition(*args, 0, 0, 0)
+    assert ei.value.code == -5
+    expect = O.scan(q_long, chars, offsets, lengths, simd=True)
+    for frac in (1.0, 0.1):
+        temp = torch.empty(int(need * frac), dtype=torch.uint8, device="cuda")
+        scores.fill_(-1.0)
+        ctx.scan_partition(*args, temp.data_ptr(), temp.numel(), 0)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect)
+        assert ids.cpu().numpy().tolist() == list(range(n))
+
+
+def test_group_shapes_agree_on_long_subjects():
+    """Partitions 34/35 run with wave-wide (64-lane) groups when they hold few subjects and with 16-lane
+    groups when they hold many: both shapes must give the oracle's scores."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(8)
+    seqs = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1281, 2600, 150))]
+    chars, offsets, lengths = O.make_db(seqs)
+    db = search.DeviceDB.from_arrays(chars, offsets, lengths, device=0)
+    n = len(seqs)
+    ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    for qlen in (130, 1100, 2100):
+        q = rng.integers(0, 20, qlen).astype(np.int8)
+        expect = O.scan(q, chars, offsets, lengths, simd=True)
+        ctx.set_query(q)
+        for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
+            for part_id in (33, 34):  # 33 -> 16-lane shape, 34 with a small n -> 64-lane shape
+                scores = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+                ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+                ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
+                ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+                need = ctx.scan_temp_bytes(kind, part_id, n, 2600)
+                temp = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+                ctx.scan_partition(kind, part_id, db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(), 0, n,
+                                   2600, -11, -1, scores.data_ptr(), ids.data_ptr(), 0, ovf_pos.data_ptr(),
+                                   ovf_cnt.data_ptr(), 1, temp.data_ptr(), temp.numel(), 0)
+                torch.cuda.synchronize()
+                assert int(ovf_cnt.item()) == 0
+                np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect,
+                                              err_msg="kind %d part %d qlen %d" % (kind, part_id, qlen))
