@@ -231,3 +231,37 @@ def test_group_shapes_agree_on_long_subjects():
                 assert int(ovf_cnt.item()) == 0
                 np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect,
                                               err_msg="kind %d part %d qlen %d" % (kind, part_id, qlen))
+
+
+def test_scores_beyond_int16_range_and_long_query():
+    """A 9014-residue query against itself (score 46662 > 32767) and against its parts: the packed kinds must
+    flag the overflow before their 16-bit state wraps and the 32-bit re-score must deliver the exact score.
+    Also covers a query of 18 stripes (packed) / 24 stripes (32-bit kinds) and unknown letters in the query."""
+    torch, capi, search = gpu_modules()
+    _, qs = O.load_queries()
+    big = np.concatenate([qs[i] for i in (10, 11, 12, 13)])
+    big_x = big.copy()
+    big_x[::97] = 20  # unknown residues in the query
+    db = O.make_db([qs[2], qs[10], qs[13], big])
+    for q in (big, big_x):
+        expect = O.scan(q, *db, simd=True)
+        assert expect.max() > 32767 or q is big_x
+        for cfg, kt in kinds_configs(search, capi).items():
+            got, res, _ = scan_all_scores(search, capi, db, q, kernel_types=kt)
+            np.testing.assert_array_equal(got, expect, err_msg=cfg)
+    assert O.scan(big, *db, simd=True)[3] == 46662
+
+
+@pytest.mark.parametrize("gop,gex", [(-40, -10), (-1, -1), (0, 0), (-20, 0)])
+def test_unusual_gap_scores(gop, gex):
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(21)
+    seqs = [rng.integers(0, 20, int(l)).astype(np.int8) for l in np.sort(rng.integers(5, 700, 300))]
+    q = rng.integers(0, 20, 333).astype(np.int8)
+    seqs[10] = q[50:250].copy()
+    seqs.sort(key=len)
+    db = O.make_db(seqs)
+    expect = O.scan(q, *db, gop=gop, gex=gex)
+    for cfg, kt in kinds_configs(search, capi).items():
+        got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, gop=gop, gex=gex)
+        np.testing.assert_array_equal(got, expect, err_msg="%s gop %d gex %d" % (cfg, gop, gex))
