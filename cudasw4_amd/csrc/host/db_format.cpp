@@ -40,12 +40,12 @@ int length_partition_of(int32_t length) {
 // ------------------------------------------------------------------ makedb side
 
 void SequenceBatch::add(std::string_view header, std::string_view sequence) {
-    chars.insert(chars.end(), sequence.begin(), sequence.end());
+    chars.append(sequence.data(), sequence.size());
     const size_t pad = (4 - sequence.size() % 4) % 4;
-    chars.insert(chars.end(), pad, ' ');
+    chars.append_fill(' ', pad);
     offsets.push_back(chars.size());
     lengths.push_back(int32_t(sequence.size()));
-    headers.insert(headers.end(), header.begin(), header.end());
+    headers.append(header.data(), header.size());
     header_offsets.push_back(headers.size());
 }
 
@@ -65,7 +65,16 @@ void put(std::ofstream& f, const T& v) {
 }  // namespace
 
 void write_database(const std::string& prefix, SequenceBatch& batch) {
-    encode_in_place(batch.chars.data(), batch.chars.size());
+    {   // thrust::transform(omp::par, ConvertAA_20) (makedb.cpp:361): encode in parallel chunks
+        const size_t total = batch.chars.size();
+        const size_t chunk = size_t(1) << 24;
+        const long nchunks = long((total + chunk - 1) / chunk);
+#pragma omp parallel for schedule(dynamic)
+        for (long c = 0; c < nchunks; c++) {
+            const size_t b = size_t(c) * chunk;
+            encode_in_place(batch.chars.data() + b, std::min(chunk, total - b));
+        }
+    }
 
     const size_t n = batch.size();
     // same call as the reference (std::sort over an iota permutation, compared by length only), so

@@ -19,6 +19,8 @@
 #include <string_view>
 #include <vector>
 
+#include "spill_vector.hpp"
+
 namespace swh {
 
 constexpr int kNumLengthPartitions = 36;
@@ -32,16 +34,28 @@ public:
     using std::runtime_error::runtime_error;
 };
 
-// Sequences collected by makedb before sorting (makedb.cpp:80-133): raw letters, padded to 4 with ' '.
+// Sequences collected by makedb before sorting (HybridBatch, makedb.cpp:80-133): raw letters, padded to 4
+// with ' '.  With a memory limit (--mem) the five arrays share the budget 50/7/7/29/7 % like the reference
+// (makedb.cpp:84-88) and spill to `<tempprefix>_cudasw4tmp*` files (makedb.cpp:90-94) when they outgrow it.
 struct SequenceBatch {
-    std::vector<char> chars;
-    std::vector<uint64_t> offsets{0};
-    std::vector<int32_t> lengths;
-    std::vector<char> headers;
-    std::vector<uint64_t> header_offsets{0};
+    explicit SequenceBatch(const std::string& tempprefix = std::string(), size_t mem_limit = 0)
+        : chars(tempprefix + "_cudasw4tmpchars", mem_limit / 100 * 50),
+          offsets(tempprefix + "_cudasw4tmpoffsets", mem_limit / 100 * 7),
+          lengths(tempprefix + "_cudasw4tmplengths", mem_limit / 100 * 7),
+          headers(tempprefix + "_cudasw4tmpheaders", mem_limit / 100 * 29),
+          header_offsets(tempprefix + "_cudasw4tmpheaderOffsets", mem_limit / 100 * 7) {
+        offsets.push_back(0);
+        header_offsets.push_back(0);
+    }
+    SpillVector<char> chars;
+    SpillVector<uint64_t> offsets;
+    SpillVector<int32_t> lengths;
+    SpillVector<char> headers;
+    SpillVector<uint64_t> header_offsets;
 
     void add(std::string_view header, std::string_view sequence);
     size_t size() const { return lengths.size(); }
+    bool spilled() const { return chars.spilled() || headers.spilled() || offsets.spilled(); }
 };
 
 // Encodes the batch (ConvertAA_20), sorts by length and writes the DB files (makedb.cpp:182-276,361).

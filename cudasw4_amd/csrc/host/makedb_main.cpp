@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
     }
     if (mem_limit) std::cout << "availableMem: " << mem_limit << "\n";
     try {
-        swh::SequenceBatch batch;
+        swh::SequenceBatch batch(tempdir, mem_limit);
         std::cout << "Parsing file\n";
         Stopwatch t1("file parsing");
         {
@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
         t1.print();
         std::cout << "Number of input sequences:  " << batch.size() << '\n';
         std::cout << "Number of input characters: " << batch.chars.size() << '\n';
+        if (batch.spilled()) std::cout << "Memory limit reached: using temp files " << tempdir << "_cudasw4tmp*\n";
         std::cout << "Converting amino acids\nCreating DB files\n";
         Stopwatch t3("db creation");
         swh::write_database(prefix, batch);

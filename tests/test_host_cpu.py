@@ -78,6 +78,23 @@ def test_makedb_equals_reference_makedb_live(tmp_path, variant):
         assert mine[f] == ref[f], (variant, f)
 
 
+def test_makedb_memory_limit_spills_and_matches(tmp_path):
+    """--mem below the input size: the batch spills to <tempdir>/_cudasw4tmp* files (makedb.cpp:90-94) and
+    the DB is byte-identical to the in-memory run; temp files are removed afterwards."""
+    rng = np.random.default_rng(23)
+    fasta = str(tmp_path / "in.fa")
+    _random_fasta(fasta, rng, 3000)
+    plain = run_makedb(MAKEDB, fasta, str(tmp_path / "plain"))
+    tmpd = tmp_path / "tmp"
+    tmpd.mkdir()
+    out = subprocess.run([MAKEDB, fasta, str(tmp_path / "lim"), "--mem", "64K", "--tempdir", str(tmpd)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "Memory limit reached" in out.stdout and "availableMem: 65536" in out.stdout
+    for f in DB_FILES:
+        assert open(str(tmp_path / "lim") + f, "rb").read() == plain[f], f
+    assert list(tmpd.iterdir()) == []
+
+
 def test_makedb_roundtrip_content(tmp_path):
     """Without the reference: decoded DB content equals the input, sorted by length, padded to 4 with 20."""
     rng = np.random.default_rng(5)
