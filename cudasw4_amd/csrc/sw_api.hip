@@ -69,7 +69,8 @@ QueryPlan plan_query(int kind, int32_t qlen, int lanes) {
         int r = (int)((per_lane + swk::kRowsGranule - 1) / swk::kRowsGranule * swk::kRowsGranule);
         r = std::min(std::max(r, swk::kRowsGranule), maxrows);
         if (ns > 1 && 2 * r <= maxrows) continue;  // multi-stripe kernels exist for R > max/2 only
-        const double cost = ns * (r + 1.2);
+        // per-step overhead in row equivalents: ~10 VALU ops single-stripe, ~20 with the stripe border
+        const double cost = ns * (r + (ns > 1 ? 2.5 : 1.2));
         if (cost < best - 1e-9) { best = cost; pl.rows = r; pl.nstripes = ns; }
     }
     return pl;

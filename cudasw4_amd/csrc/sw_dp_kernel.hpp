@@ -357,11 +357,22 @@ __device__ __forceinline__ u32 group_max(u32 v) {
 template <int LANES>
 constexpr int border_junk_words() { return LANES == 16 ? 128 : 320; }  // >= 4*(LANES-1) + LANES, multiple of 64
 
-#ifndef SWK_MIN_WAVES
-#define SWK_MIN_WAVES 1  // minimum waves per SIMD the register allocator must leave room for (tuning knob)
+// Minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument).
+// Packed kinds: 1 (unconstrained) is best — forcing 3-4 waves spills the multi-stripe kernels (-3..4 %).
+// 32-bit kinds: v_add_f32/v_add_u32 co-issue with v_max3_* mostly ACROSS waves (tools/ubench/mix_rate.hip:
+// 99 lanes/clk/CU at 4 waves/SIMD, 80 at 2), so they want occupancy more than registers.
+#ifndef SWK_MIN_WAVES_SCALAR
+#define SWK_MIN_WAVES_SCALAR 0
 #endif
+template <int KIND, int R, bool MULTI>
+constexpr int min_waves() {
+    if (Arith<KIND>::kPacked) return 1;
+    if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
+    return (R <= 16 && !MULTI) ? 4 : 3;  // 4 would spill the multi-stripe R = 14..16 kernels
+}
+
 template <int KIND, int R, int LANES, bool MULTI>
-__global__ void __launch_bounds__(kThreads, SWK_MIN_WAVES) sw_scan_kernel(const ScanParams p) {
+__global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_scan_kernel(const ScanParams p) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
     constexpr int kGroups = kThreads / LANES;

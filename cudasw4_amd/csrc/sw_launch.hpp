@@ -9,7 +9,7 @@ namespace swk {
 constexpr int kRowsGranule = 2;
 // standard shape (16-lane groups)
 constexpr int kMaxRowsPacked = 32;  // stripe = 512 query rows, 21.5 KB tile
-constexpr int kMaxRowsScalar = 24;  // stripe = 384 query rows (32-bit profile entries, 32 KB tile)
+constexpr int kMaxRowsScalar = 32;  // stripe = 512 query rows (32-bit profile entries, 43 KB tile)
 // long-subject shape (64-lane groups)
 constexpr int kMaxRowsPackedLong = 16;  // stripe = 1024 query rows, 43 KB tile
 constexpr int kMaxRowsScalarLong = 8;   // stripe = 512 query rows, 43 KB tile
@@ -71,7 +71,7 @@ constexpr size_t tile_bytes_r() {
 }
 
 #define SWK_FOR_EACH_R_PACKED(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
-#define SWK_FOR_EACH_R_SCALAR(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24)
+#define SWK_FOR_EACH_R_SCALAR(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
 
 #define SWK_DEFINE_KIND(FN, KIND, FOR_EACH_R)                                                                      \
     static hipError_t FN##_scan(int R, int lanes, bool multi, int grid, hipStream_t stream, const ScanParams& p) {  \

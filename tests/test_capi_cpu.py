@@ -45,7 +45,7 @@ def test_version_and_plan_without_gpu(built):
     for kind in (capi.KIND_I32, capi.KIND_F32):
         for q in (1, 256, 257, 5478):
             r, s = capi.plan_query(kind, q)
-            assert r % 2 == 0 and 2 <= r <= 24 and 16 * r * s >= q
+            assert r % 2 == 0 and 2 <= r <= 32 and 16 * r * s >= q
     with pytest.raises(capi.SwError):
         capi.plan_query(7, 100)
 
