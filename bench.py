@@ -89,19 +89,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import oracle_lib as O  # query set + pseudo-DB residues (data only; the scan below is all HIP)
-    from cudasw4_amd import capi, search
+    # inputs come from the product's own host library (FASTA reader, encoder, pseudo-DB generator, matrix);
+    # oracle/ is touched only inside cpu_baseline()
+    from cudasw4_amd import capi, driver, search
 
-    _, queries = O.load_queries()
+    _, query_letters = driver.read_sequences(os.path.join(ROOT, "tests", "golden", "allqueries.fasta"))
+    queries = [driver.encode(q) for q in query_letters]
     kind = KIND_BY_NAME[args.kernel]
     L, num = args.db_length, args.db_size
-    codes = O.pseudodb_codes(L, 42)
+    codes = driver.pseudo_sequence(L, 42)
     db = search.DeviceDB.pseudo(num, L, codes, device=local_rank)
     db.id_offset = rank * num  # global subject ids of this shard
     big = capi.KIND_F32 if kind in (0, 3) else capi.KIND_I32
     small = kind if kind in (0, 1) else (0 if kind == 3 else 1)
     kt = search.KernelTypeConfig(single_pass=kind, many_pass_small=small, many_pass_large=big, overflow=big)
-    s = search.Searcher(device=local_rank, num_top=args.top, matrix=O.blosum21(62), kernel_types=kt)
+    s = search.Searcher(device=local_rank, num_top=args.top, matrix=driver.matrix(62), kernel_types=kt)
     s.set_database(db)
     s.record_kernel_events = False
 

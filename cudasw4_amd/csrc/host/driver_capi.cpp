@@ -5,9 +5,16 @@
 #include <string>
 
 #include "../../../include/cudasw4_amd_driver.h"
+#include <random>
+
 #include "search_driver.hpp"
+#include "sequence_reader.hpp"
 
 using namespace swh;
+
+struct swdrv_reader {
+    std::unique_ptr<SequenceReader> reader;
+};
 
 struct swdrv {
     std::unique_ptr<SearchDriver> driver;
@@ -124,5 +131,47 @@ int swdrv_reference_header(swdrv* d, int64_t id, char* buf, int cap) {
     }
     return int(h.size());
 }
+
+void swdrv_encode(const char* letters, int8_t* codes, size_t n) {
+    for (size_t i = 0; i < n; i++) codes[i] = encode_residue(letters[i]);
+}
+
+void swdrv_pseudo_sequence(int32_t length, int seed, int8_t* codes) {
+    std::mt19937 gen(seed);
+    std::uniform_int_distribution<> dist(0, 19);
+    for (int32_t i = 0; i < length; i++) codes[i] = int8_t(dist(gen));
+}
+
+int swdrv_matrix(int matrix, int8_t* out441) {
+    MatrixId id;
+    if (!parse_matrix_name("blosum" + std::to_string(matrix), id)) return -1;
+    const SubstitutionMatrix& m = substitution_matrix(id);
+    std::memcpy(out441, m.m.data(), m.m.size());
+    return 0;
+}
+
+int swdrv_reader_open(const char* path, swdrv_reader** out) {
+    return guarded([&] {
+        auto* r = new swdrv_reader;
+        try {
+            r->reader = std::make_unique<SequenceReader>(path);
+        } catch (...) {
+            delete r;
+            throw;
+        }
+        *out = r;
+    });
+}
+
+int swdrv_reader_next(swdrv_reader* r, const char** header, size_t* header_len, const char** sequence, size_t* sequence_len) {
+    if (!r || !r->reader->next()) return 0;
+    *header = r->reader->header().data();
+    *header_len = r->reader->header().size();
+    *sequence = r->reader->sequence().data();
+    *sequence_len = r->reader->sequence().size();
+    return 1;
+}
+
+void swdrv_reader_close(swdrv_reader* r) { delete r; }
 
 }  // extern "C"

@@ -14,7 +14,8 @@ ALIGN = os.path.join(_HERE, "lib", "align")
 
 EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db", "swdrv_pseudo_db", "swdrv_upload",
            "swdrv_num_sequences", "swdrv_num_gpus", "swdrv_set_num_top", "swdrv_scan", "swdrv_reference_length",
-           "swdrv_reference_header"]
+           "swdrv_reference_header", "swdrv_encode", "swdrv_pseudo_sequence", "swdrv_matrix", "swdrv_reader_open",
+           "swdrv_reader_next", "swdrv_reader_close"]
 
 
 class DriverError(RuntimeError):
@@ -44,10 +45,58 @@ def _load():
     L.swdrv_reference_length.restype = i32
     L.swdrv_reference_length.argtypes = [vp, ctypes.c_int64]
     L.swdrv_reference_header.argtypes = [vp, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int]
+    L.swdrv_encode.argtypes = [ctypes.c_char_p, vp, sz]
+    L.swdrv_pseudo_sequence.argtypes = [i32, ctypes.c_int, vp]
+    L.swdrv_matrix.argtypes = [ctypes.c_int, vp]
+    L.swdrv_reader_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.swdrv_reader_next.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
+                                    ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz)]
+    L.swdrv_reader_close.argtypes = [vp]
     return L
 
 
 lib = _load()
+
+
+# ---- input helpers of the host library (what `align` does to its inputs; no GPU needed) ----
+
+def encode(letters) -> np.ndarray:
+    """ConvertAA_20: residue letters -> int8 codes 0..20."""
+    if isinstance(letters, str):
+        letters = letters.encode()
+    out = np.empty(len(letters), dtype=np.int8)
+    lib.swdrv_encode(letters, out.ctypes.data, len(letters))
+    return out
+
+
+def pseudo_sequence(length, seed=42) -> np.ndarray:
+    """The pseudo-DB subject (one mt19937(seed) sequence), as codes."""
+    out = np.empty(length, dtype=np.int8)
+    lib.swdrv_pseudo_sequence(length, seed, out.ctypes.data)
+    return out
+
+
+def matrix(which=62) -> np.ndarray:
+    out = np.empty(441, dtype=np.int8)
+    if lib.swdrv_matrix(which, out.ctypes.data) != 0:
+        raise ValueError("unknown matrix %r" % which)
+    return out
+
+
+def read_sequences(path):
+    """FASTA / FASTQ (.gz) -> (headers, sequences as bytes), parsed like the reference's kseq reader."""
+    h = ctypes.c_void_p()
+    _check(lib.swdrv_reader_open(path.encode(), ctypes.byref(h)))
+    headers, seqs = [], []
+    hp, sp = ctypes.c_char_p(), ctypes.c_char_p()
+    hl, sl = ctypes.c_size_t(), ctypes.c_size_t()
+    try:
+        while lib.swdrv_reader_next(h, ctypes.byref(hp), ctypes.byref(hl), ctypes.byref(sp), ctypes.byref(sl)):
+            headers.append(ctypes.string_at(hp, hl.value).decode())
+            seqs.append(ctypes.string_at(sp, sl.value))
+    finally:
+        lib.swdrv_reader_close(h)
+    return headers, seqs
 
 
 def _check(rc):

@@ -50,6 +50,21 @@ int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64
 int32_t swdrv_reference_length(swdrv* d, int64_t id);
 int swdrv_reference_header(swdrv* d, int64_t id, char* buf, int cap);
 
+/* ---- input helpers (no GPU needed): what `align` does to its inputs before the scan ---- */
+
+/* ConvertAA_20 (convert.cuh:6-34): letters -> codes 0..20 */
+void swdrv_encode(const char* letters, int8_t* codes, size_t n);
+/* the pseudo-DB subject (dbdata.hpp:222-272): `length` codes from std::mt19937(seed) + uniform_int_distribution<>(0,19) */
+void swdrv_pseudo_sequence(int32_t length, int seed, int8_t* codes);
+/* 21 x 21 substitution matrix (types.hpp:29-270); matrix = 45 | 50 | 62 | 80; returns 0 or -1 */
+int swdrv_matrix(int matrix, int8_t* out441);
+/* FASTA / FASTQ (.gz) reader (kseqpp/kseqpp.hpp:54-118): open -> next* -> close.  next returns 1 while there is a
+ * record; the header / sequence pointers stay valid until the following call. */
+typedef struct swdrv_reader swdrv_reader;
+int swdrv_reader_open(const char* path, swdrv_reader** out);
+int swdrv_reader_next(swdrv_reader* r, const char** header, size_t* header_len, const char** sequence, size_t* sequence_len);
+void swdrv_reader_close(swdrv_reader* r);
+
 #ifdef __cplusplus
 }
 #endif

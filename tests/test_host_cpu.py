@@ -154,3 +154,19 @@ def test_driver_header_symbols_exported():
     if not torch.cuda.is_available():
         with pytest.raises(driver.DriverError):
             driver.Driver()
+
+
+def test_host_input_helpers_match_reference(golden_dir):
+    """The product's own reader / encoder / pseudo-DB generator / matrices (used by bench.py and align)
+    against the reference-derived golden data."""
+    from cudasw4_amd import driver
+    g = O.golden("ref_tables.json")
+    headers, seqs = driver.read_sequences(os.path.join(golden_dir, "allqueries.fasta"))
+    assert headers == g["query_headers"] and [len(s) for s in seqs] == g["query_lengths"]
+    assert driver.encode(bytes(range(256))).tolist() == g["encode_map_256"]
+    assert driver.pseudo_sequence(2048, 42).tolist() == g["pseudodb_seed42_first2048"]
+    assert driver.pseudo_sequence(64, 7).tolist() == g["pseudodb_seed7_first64"]
+    for which in (45, 50, 62, 80):
+        assert driver.matrix(which).tolist() == g["blosum21"][str(which)]
+    with pytest.raises(ValueError):
+        driver.matrix(63)

@@ -18,8 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 
-import oracle_lib as O
-from cudasw4_amd import capi, search
+from cudasw4_amd import capi, driver, search
 
 KINDS = {"half2": 0, "dpxs16": 1, "dpxs32": 2, "float": 3}
 
@@ -32,11 +31,12 @@ def main():
     ap.add_argument("--per-query-length", type=int, default=512)
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
-    _, queries = O.load_queries()
+    _, _letters = driver.read_sequences(os.path.join(ROOT, "tests", "golden", "allqueries.fasta"))
+    queries = [driver.encode(q) for q in _letters]
     sum_q = sum(len(q) for q in queries)
     results = []
     for L in [int(x) for x in args.lengths.split(",")]:
-        db = search.DeviceDB.pseudo(args.db_size, L, O.pseudodb_codes(L, 42), device=0)
+        db = search.DeviceDB.pseudo(args.db_size, L, driver.pseudo_sequence(L, 42), device=0)
         for kname in args.kernels.split(","):
             kind = KINDS[kname]
             if kind in (2, 3) and L > 1024:
@@ -44,7 +44,7 @@ def main():
             big = capi.KIND_F32 if kind in (0, 3) else capi.KIND_I32
             small = kind if kind in (0, 1) else (0 if kind == 3 else 1)
             kt = search.KernelTypeConfig(kind, small, big, big)
-            s = search.Searcher(device=0, num_top=0, matrix=O.blosum21(62), kernel_types=kt)
+            s = search.Searcher(device=0, num_top=0, matrix=driver.matrix(62), kernel_types=kt)
             s.set_database(db)
             s.scan(queries[0])  # warm-up
             per_q = []

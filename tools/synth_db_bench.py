@@ -19,8 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 
-import oracle_lib as O
-from cudasw4_amd import capi, search
+from cudasw4_amd import capi, driver, search
 
 
 def synth_lengths(n, seed, max_len):
@@ -54,9 +53,10 @@ def main():
     chars[pos - offsets[seq_of].astype(np.int64) >= lengths[seq_of]] = 20
     db = search.DeviceDB.from_arrays(chars, offsets, lengths, device=0)
     kt = search.KernelTypeConfig.dpx() if args.config == "dpx" else search.KernelTypeConfig()
-    s = search.Searcher(device=0, num_top=args.top, matrix=O.blosum21(62), kernel_types=kt)
+    s = search.Searcher(device=0, num_top=args.top, matrix=driver.matrix(62), kernel_types=kt)
     s.set_database(db)
-    _, queries = O.load_queries()
+    _, _letters = driver.read_sequences(os.path.join(ROOT, "tests", "golden", "allqueries.fasta"))
+    queries = [driver.encode(q) for q in _letters]
     if args.queries != "all":
         queries = [queries[int(i)] for i in args.queries.split(",")]
     print("DB: %d sequences, %d residues, max length %d; partitions used: %s" % (
