@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--kernel", choices=sorted(KIND_BY_NAME), default="half2")
     ap.add_argument("--top", type=int, default=0, help="top-K per query (reference benchmark uses 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-subjects", type=int, default=40000)
+    ap.add_argument("--cpu-sample-subjects", type=int, default=100000)
     return ap.parse_args()
 
 
