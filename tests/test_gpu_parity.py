@@ -265,3 +265,18 @@ def test_unusual_gap_scores(gop, gex):
     for cfg, kt in kinds_configs(search, capi).items():
         got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, gop=gop, gex=gex)
         np.testing.assert_array_equal(got, expect, err_msg="%s gop %d gex %d" % (cfg, gop, gex))
+
+
+def test_zero_length_subjects_and_single_subject_batches():
+    """Empty records (length 0) score 0 and do not disturb their neighbours; counts that leave groups empty."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(31)
+    for n in (1, 2, 3, 17, 33):
+        seqs = [np.zeros(0, dtype=np.int8)] * min(2, n - 1) + [rng.integers(0, 20, int(l)).astype(np.int8)
+                                                              for l in np.sort(rng.integers(1, 90, n - min(2, n - 1)))]
+        db = O.make_db(seqs)
+        q = rng.integers(0, 20, 75).astype(np.int8)
+        expect = O.scan(q, *db)
+        for cfg, kt in kinds_configs(search, capi).items():
+            got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt)
+            np.testing.assert_array_equal(got, expect, err_msg="%s n=%d" % (cfg, n))
