@@ -48,21 +48,33 @@ def parse_args():
 
 def cpu_baseline(queries, L, nsubj):
     """Oracle's inter-sequence SIMD scan (kind 'port') on the host cores, bounded sample of the same
-    workload: all 20 queries x `nsubj` pseudo subjects of length L."""
+    workload: all 20 queries x `nsubj` pseudo subjects of length L.  The thread count is picked by a short
+    calibration (containers often cap CPU time below the number of visible hardware threads, where more
+    threads only add throttling); `cores` reports the threads actually used."""
     import oracle_lib as O
     codes = O.pseudodb_codes(L, 42)
-    chars, offsets, lengths = O.make_db([codes] * nsubj)
     m = O.blosum21(62)
-    cores = O.max_threads()
-    O.scan(queries[0], chars, offsets, lengths, m21=m, simd=True)  # warm-up (threads, pages)
+    cal = O.make_db([codes] * 6000)
+    best_nt, best_rate = 1, 0.0
+    nt = O.max_threads()
+    while nt >= 1:
+        O.scan(queries[9], *cal, m21=m, simd=True, nthreads=nt)  # warm-up of this team size
+        t0 = time.perf_counter()
+        O.scan(queries[9], *cal, m21=m, simd=True, nthreads=nt)
+        rate = len(queries[9]) * 6000.0 * L / (time.perf_counter() - t0)
+        if rate > best_rate:
+            best_nt, best_rate = nt, rate
+        nt //= 2
+    chars, offsets, lengths = O.make_db([codes] * nsubj)
     t0 = time.perf_counter()
     for q in queries:
-        O.scan(q, chars, offsets, lengths, m21=m, simd=True)
+        O.scan(q, chars, offsets, lengths, m21=m, simd=True, nthreads=best_nt)
     dt = time.perf_counter() - t0
     cells = float(sum(len(q) for q in queries)) * float(nsubj) * float(L)
-    return {"value": round(cells / 1e9 / dt, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
-            "sample": "20 queries x %d pseudo subjects of length %d, int16 inter-sequence SIMD oracle, %.1f s"
-                      % (nsubj, L, dt)}
+    return {"value": round(cells / 1e9 / dt, 3), "unit": "GCUPS", "cores": best_nt, "kind": "port",
+            "sample": "20 queries x %d pseudo subjects of length %d, int16 inter-sequence SIMD oracle "
+                      "(AVX-512 via gcc -march=native), %.1f s, %d of %d hardware threads (best of a calibration sweep)"
+                      % (nsubj, L, dt, best_nt, O.max_threads())}
 
 
 def main():
