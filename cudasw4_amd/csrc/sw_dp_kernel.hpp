@@ -6,8 +6,9 @@
 // streams the query through a 32-lane warp with a 37 KB pair table gathered from shared memory.
 // Here the orientation is transposed and built around CDNA4's DPP rows:
 //
-//   * one alignment group == one DPP row of 16 lanes; a wave64 runs 4 independent groups;
-//   * the QUERY is tiled in stripes of 16*R rows; lane l of a group owns R consecutive query rows
+//   * one alignment group == one DPP row of 16 lanes; a wave64 runs 4 independent groups (for the few long
+//     subjects of a real DB: group == the whole wave, 64 lanes, wave_shr:1);
+//   * the QUERY is tiled in stripes of LANES*R rows; lane l of a group owns R consecutive query rows
 //     and keeps their H (previous column) and E (horizontal gap) state in VGPRs;
 //   * subject letters stream through the row: at step t lane l works on subject column t-l
 //     (anti-diagonal wavefront).  H and F of a lane's bottom row go to lane l+1 with
@@ -18,8 +19,9 @@
 //   * packed kinds run two subjects per group in the two 16-bit halves (v_pk_add_u16 / v_pk_max_i16 /
 //     v_pk_sub_u16 clamp, or v_pk_add_f16 / v_pk_maximum3_f16);
 //   * queries longer than one stripe are processed stripe after stripe by the same group; the H/F
-//     row at the stripe border is spilled to a small global scratch (one coalesced 64-byte
-//     load/store per 16 columns), the analogue of the reference's devTempHcol2/devTempEcol2.
+//     row at the stripe border is spilled to a small global scratch (branch-free: 8 bytes stored per
+//     step, 32 bytes loaded per four steps), the analogue of the reference's devTempHcol2/devTempEcol2;
+//   * persistent workgroups pull batches of groups from an atomic counter, longest subjects first.
 //
 // Padding is self-neutralising exactly as in the reference: query rows >= Q and
 // subject columns >= len use letter code 20 whose scores are all negative.
@@ -37,7 +39,6 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kGroup = 16;        // lanes per alignment group in the standard shape (one DPP row)
 constexpr int kThreads = 256;     // workgroup size: 4 waves = 16 row groups or 4 wave-wide groups
-constexpr int kGroupsPerWg = kThreads / kGroup;
 constexpr int kPadLetter = 20;    // code used for padding rows / columns
 constexpr int kLetters = 21;
 
