@@ -92,7 +92,7 @@ struct sw_ctx {
     int device = 0;
     int num_cus = 0;
     int8_t* d_matrix = nullptr;  // 21 x 21
-    uint32_t* d_zeros = nullptr; // 256 bytes of zeros (first-stripe border)
+    uint32_t* d_zeros = nullptr; // per kind 64 bytes of its zero pattern (first-stripe border): [kind * 16 words]
     uint32_t* d_work = nullptr;  // kWorkSlots batch counters (dynamic batch distribution), one per launch in flight
     uint32_t work_next = 0;
     bool have_matrix = false;
@@ -167,7 +167,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     if (!kl) return fail(SW_ERR_INVALID, "unknown kind");
     if (n < 0 || max_subject_len < 0) return fail(SW_ERR_INVALID, "negative count or length");
     if (gop > 0 || gex > 0) return fail(SW_ERR_INVALID, "gap scores must be <= 0");
-    if (kind_packed(kind) && (gop < -2000 || gex < -2000)) return fail(SW_ERR_INVALID, "gap score out of range for a 16-bit kind");
+    if (kind_packed(kind) && (gop < -1000 || gex < -1000)) return fail(SW_ERR_INVALID, "gap score out of range for a 16-bit kind");
     if (!ctx->have_matrix) return fail(SW_ERR_NO_MATRIX, "sw_set_matrix has not been called");
     if (!ctx->have_query) return fail(SW_ERR_NO_QUERY, "sw_set_query has not been called");
     if (n == 0) return SW_OK;
@@ -197,7 +197,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     }
     p.scores = scores; p.ids = ids; p.id_offset = id_offset;
     p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;
-    p.scratch = nullptr; p.lcap = 0; p.zeros = ctx->d_zeros;
+    p.scratch = nullptr; p.lcap = 0; p.zeros = ctx->d_zeros + kind * 16;
     if (multi) {
         p.lcap = border_capacity(max_subject_len, lanes);
         const size_t per_wg = border_bytes_per_wg(p.lcap, lanes);
@@ -242,7 +242,11 @@ int sw_ctx_create(int device, sw_ctx** out) {
     hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(ctx->d_zeros, 0, 256);
+    if (e == hipSuccess) {
+        uint32_t z[64] = {};
+        for (int i = 0; i < 16; i++) z[SW_KIND_I16X2 * 16 + i] = swk::Arith<swk::I16X2>::kZero;
+        e = hipMemcpy(ctx->d_zeros, z, sizeof(z), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) { delete ctx; return fail(SW_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     *out = ctx;
     return SW_OK;

@@ -74,28 +74,45 @@ __device__ __forceinline__ u32 dpp(u32 old, u32 src) {
 template <int KIND>
 struct Arith;
 
+// int16 kind.  State is kept BIASED by 1024 in unsigned 16-bit fields: H~ = H + 1024, E~ = E' + 1024, F~ likewise.
+// Adds/subtracts are integer (v_pk_add_u16 / v_pk_sub_u16); every maximum is taken with the fp16 comparator
+// v_pk_maximum3_f16 ON THE INTEGER BIT PATTERNS: for patterns in [0x0400, 0x7BFF] (positive normal halves) the
+// fp16 order equals the integer order and the instruction returns one of its inputs bit-exactly, so the
+// 3-input maximum the int16 ISA lacks comes for free (8.5 instead of 10 instructions per cell pair).
+//   * diag+s can dip below 1024 (a denormal pattern, possibly flushed): it then loses against E~ >= 1024
+//     anyway, so the result is unaffected;
+//   * patterns >= 0x7C00 (inf/NaN, H >= 30720) only arise after the running maximum has passed the
+//     25000 overflow limit (H grows by at most max(s) per anti-diagonal), and a NaN maximum is itself
+//     >= the limit, so such subjects are always flagged and re-scored in 32 bits.
 template <>
 struct Arith<I16X2> {
     static constexpr bool kPacked = true;
     static constexpr int kSubjects = 2;
     static constexpr int kLimit = 25000;  // kernels.cuh:5 MAX_ACC_SHORT
-    // gap scores are <= 0; the packed kernel subtracts magnitudes with unsigned saturation
+    static constexpr int kBias = 1024;
+    static constexpr u32 kZero = (u32)kBias | ((u32)kBias << 16);  // the value 0 in both halves
+    // gap scores are <= 0; magnitudes are subtracted (|g| <= 1000 keeps E~ - |g| non-negative)
     static __host__ __device__ u32 encode_gap(int g) { u32 m = (u32)(-g) & 0xffffu; return m | (m << 16); }
     static __host__ __device__ u32 encode_score(int s) { return (u32)(uint16_t)(int16_t)s; }
     static __device__ __forceinline__ u32 add(u32 a, u32 b) {
         return __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
     }
+    static __device__ __forceinline__ u32 max3(u32 a, u32 b, u32 c) {
+        return __builtin_bit_cast(u32, __builtin_elementwise_maximum(
+            __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+            __builtin_bit_cast(f16x2, c)));
+    }
     static __device__ __forceinline__ u32 max2(u32 a, u32 b) {
-        return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+        return __builtin_bit_cast(u32, __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)));
     }
-    static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 f) { return max2(max2(t, e), f); }
-    static __device__ __forceinline__ u32 gap(u32 a, u32 g) {  // max(a + gapscore, 0)
-        return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, g)));
+    static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 f) { return max3(t, e, f); }
+    static __device__ __forceinline__ u32 gap(u32 a, u32 g) {
+        return __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, g)));
     }
-    static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return max2(ext, open); }
-    static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return max2(m, max2(a, b)); }
-    static __device__ __forceinline__ int score_lo(u32 v) { return (int)(int16_t)(v & 0xffffu); }
-    static __device__ __forceinline__ int score_hi(u32 v) { return (int)(int16_t)(v >> 16); }
+    static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return max3(ext, open, kZero); }
+    static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return max3(m, a, b); }
+    static __device__ __forceinline__ int score_lo(u32 v) { return (int)(v & 0xffffu) - kBias; }
+    static __device__ __forceinline__ int score_hi(u32 v) { return (int)(v >> 16) - kBias; }
 };
 
 template <>
@@ -103,6 +120,7 @@ struct Arith<F16X2> {
     static constexpr bool kPacked = true;
     static constexpr int kSubjects = 2;
     static constexpr int kLimit = 2048;  // kernels.cuh:4 MAX_ACC_HALF2
+    static constexpr u32 kZero = 0u;
     static __host__ __device__ u32 half_bits(int v) {
         // exact conversion of a small integer |v| < 2048 to IEEE binary16 bits
         if (v == 0) return 0;
@@ -139,6 +157,7 @@ struct Arith<I32> {
     static constexpr bool kPacked = false;
     static constexpr int kSubjects = 1;
     static constexpr int kLimit = 0x7fffffff;
+    static constexpr u32 kZero = 0u;
     static __host__ __device__ u32 encode_gap(int g) { return (u32)g; }
     static __host__ __device__ u32 encode_score(int s) { return (u32)s; }
     // v_max3_i32 spelled out: hipcc's own selection mixes signed/unsigned 2- and 3-input forms here
@@ -168,6 +187,7 @@ struct Arith<F32> {
     static constexpr bool kPacked = false;
     static constexpr int kSubjects = 1;
     static constexpr int kLimit = 0x7fffffff;
+    static constexpr u32 kZero = 0u;
     static __host__ __device__ u32 encode_gap(int g) { return __builtin_bit_cast(u32, (float)g); }
     static __host__ __device__ u32 encode_score(int s) { return __builtin_bit_cast(u32, (float)s); }
     static __device__ __forceinline__ float f(u32 v) { return __builtin_bit_cast(float, v); }
@@ -224,7 +244,7 @@ struct ScanParams {
     int32_t ovf_check;
     u32* scratch;              // stripe-border spill: per (workgroup, group): [64 junk][H lcap][64 junk][F lcap]
     int32_t lcap;
-    const u32* zeros;          // >= 64 bytes of zeros (border of the first stripe)
+    const u32* zeros;          // >= 64 bytes of the kind's zero pattern (border of the first stripe)
     u32* work_counter;         // zeroed before the launch: next batch to hand out
 };
 
@@ -290,9 +310,12 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
     if constexpr (MULTI) {
         upH = dpp<SHR1, false>(inH, st.Hlast);  // lane 0 keeps `old` == the border value
         F = dpp<SHR1, false>(inF, st.Fout);
-    } else {
-        upH = dpp<SHR1, true>(0u, st.Hlast);
+    } else if constexpr (A::kZero == 0u) {
+        upH = dpp<SHR1, true>(0u, st.Hlast);  // bound_ctrl zero fill == the local-alignment boundary
         F = dpp<SHR1, true>(0u, st.Fout);
+    } else {
+        upH = dpp<SHR1, false>(A::kZero, st.Hlast);
+        F = dpp<SHR1, false>(A::kZero, st.Fout);
     }
     u32 diag = st.upH_prev;
     st.upH_prev = upH;
@@ -437,7 +460,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_sc
         const int nquads = (lmax + LANES - 1 + 3) >> 2;
         const int len0pad = (len0 + 3) & ~3, len1pad = (len1 + 3) & ~3;
 
-        u32 maxv = 0;
+        u32 maxv = A::kZero;
         for (int stripe = 0; stripe < p.nstripes; stripe++) {
             const bool first = stripe == 0;
             if constexpr (MULTI) {
@@ -447,8 +470,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_sc
             }
             StripeState<KIND, R> st;
 #pragma unroll
-            for (int r = 0; r < R; r++) { st.H[r] = 0; st.E[r] = 0; }
-            st.upH_prev = 0; st.Hlast = 0; st.Fout = 0; st.maxv = maxv;
+            for (int r = 0; r < R; r++) { st.H[r] = A::kZero; st.E[r] = A::kZero; }
+            st.upH_prev = A::kZero; st.Hlast = A::kZero; st.Fout = A::kZero; st.maxv = maxv;
             st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
             st.yB = st.yA;
 
@@ -466,7 +489,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_sc
 
             // stripe border (MULTI only): lane 0 reads the previous stripe's bottom row four columns per
             // quad, one quad ahead (2 x 16-byte loads); the last lane stores its own bottom row every step.
-            uint4 curH = make_uint4(0, 0, 0, 0), curF = curH, nextH = curH, nextF = curH;
+            uint4 curH = make_uint4(A::kZero, A::kZero, A::kZero, A::kZero), curF = curH, nextH = curH, nextF = curH;
             const int walkIn = (lane == 0 && !first) ? 4 : 0;  // words per quad the load address advances
             const int walkOut = (lane == LANES - 1) ? 4 : 0;
             const u32* inH = (lane == 0 && !first) ? borderH : p.zeros;
@@ -505,8 +528,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_sc
             if constexpr (MULTI) {
                 // the last lane reached column 4*nquads-LANES; the next stripe reads up to 4*nquads-1: zero the rest
                 if (lane < LANES - 1) {
-                    borderH[4 * nquads - (LANES - 1) + lane] = 0;
-                    borderF[4 * nquads - (LANES - 1) + lane] = 0;
+                    borderH[4 * nquads - (LANES - 1) + lane] = A::kZero;
+                    borderF[4 * nquads - (LANES - 1) + lane] = A::kZero;
                 }
             }
             maxv = st.maxv;
