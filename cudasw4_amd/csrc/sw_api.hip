@@ -133,11 +133,14 @@ int ensure_profile(sw_ctx* ctx, int kind, int lanes, hipStream_t stream) {
     const size_t bytes = kl->tile_bytes(pl.rows, lanes) * (size_t)pl.nstripes;
     if (bytes == 0) return fail(SW_ERR_INVALID, "no kernel compiled for this query plan");
     if (bytes > pr.capacity) {
+        // hipFree/hipMalloc synchronise the device: they would serialise launches that are meant to overlap
+        // on other streams, so capacity starts at 2 MiB (queries up to ~50 k residues) and doubles
+        const size_t cap = std::max<size_t>(std::max(bytes, 2 * pr.capacity), size_t(2) << 20);
         if (pr.dev) SW_HIP(hipFree(pr.dev));
         pr.dev = nullptr;
         pr.capacity = 0;
-        SW_HIP(hipMalloc(&pr.dev, bytes));
-        pr.capacity = bytes;
+        SW_HIP(hipMalloc(&pr.dev, cap));
+        pr.capacity = cap;
     }
     SW_HIP(kl->profile(pl.rows, lanes, ctx->d_query, ctx->qlen, ctx->d_matrix, pl.nstripes, pr.dev, stream));
     if (!pr.ready) SW_HIP(hipEventCreateWithFlags(&pr.ready, hipEventDisableTiming));
@@ -292,7 +295,7 @@ int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void
         if (ctx->d_query) SW_HIP(hipFree(ctx->d_query));
         ctx->d_query = nullptr;
         ctx->query_capacity = 0;
-        const size_t cap = ((size_t)qlen + 4095) / 4096 * 4096;
+        const size_t cap = std::max<size_t>(((size_t)qlen + 4095) / 4096 * 4096 * 2, size_t(1) << 16);
         SW_HIP(hipMalloc(&ctx->d_query, cap));
         ctx->query_capacity = cap;
     }
