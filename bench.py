@@ -183,7 +183,7 @@ def main():
         valu_peak_instr = 256 * 64 * 2.4e9
         # VALU instructions the kernel issues per cell (pair), static count from the gfx950 ISA of the
         # R=32 / R=16 loop bodies incl. per-step overhead
-        instr_per_unit = {0: 9.0, 1: 10.5, 2: 8.9, 3: 8.0}[kind]
+        instr_per_unit = {0: 9.0, 1: 9.0, 2: 7.9, 3: 7.9}[kind]
         units_per_s = kern_gcups * 1e9 / (2 if packed else 1)
         achieved_instr = units_per_s * instr_per_unit
         traffic = None
