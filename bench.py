@@ -181,6 +181,10 @@ def main():
         # VALU issue ceiling (tools/ubench/valu_rate.hip): every op of the loop issues at one
         # wave64 instruction per 4 cycles per SIMD = 64 lanes/clk/CU; 256 CUs at 2.4 GHz.
         valu_peak_instr = 256 * 64 * 2.4e9
+        if kind == 3:
+            # fp32 kind: v_add_f32 (VOP2) co-issues with v_max3_f32 (VOP3); the 8:7 mix of the loop sustains
+            # 99.5 lanes/clk/CU in tools/ubench/mix_rate.hip
+            valu_peak_instr = 256 * 99.5 * 2.4e9
         # VALU instructions the kernel issues per cell (pair), static count from the gfx950 ISA of the
         # R=32 / R=16 loop bodies incl. per-step overhead
         instr_per_unit = {0: 9.0, 1: 9.0, 2: 7.9, 3: 7.9}[kind]
