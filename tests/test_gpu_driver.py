@@ -127,3 +127,26 @@ def test_align_cli_tsv_and_plain(tmp_path):
         assert "Query %d, header%s, length %d, num overflows 0" % (qi, headers[qi], len(seqs[qi])) in p.stdout
     assert "Result 0. Score: %d. Length: 128. Header H. referenceId 0" % exp[0] in p.stdout
     assert "Result 1. Score: %d. Length: 128. Header H. referenceId 1" % exp[19] in p.stdout
+
+
+def test_align_interactive_mode(tmp_path):
+    """main.cu:336-424: 's <sequence>' (multi-line until an empty line), 'f <file>', 'exit'."""
+    from cudasw4_amd import driver
+    g = O.golden("ref_scores.json")
+    headers, seqs = O.read_fasta(FASTA)
+    q3 = seqs[3].decode()
+    script = "s %s\n%s\n\nf %s\nbogus\nexit\n" % (q3[:100], q3[100:], FASTA)
+    of = str(tmp_path / "out.txt")
+    p = subprocess.run([driver.ALIGN, "--db", GOLDEN_DB, "--interactive", "--top", "2", "--of", of],
+                       input=script, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "Interactive mode ready" in p.stdout and "Unrecognized command: bogus" in p.stdout
+    assert p.stdout.count("Waiting for command...") >= 3
+    out = open(of).read().splitlines()
+    es, ei = expected_top(g["allvsall"][3], 2)
+    assert out[0] == "Result 0. Score: %d. Length: %d. Header %s. referenceId %d" % (es[0], len(seqs[ei[0]]), headers[ei[0]], ei[0])
+    assert out[1].startswith("Result 1. Score: %d." % es[1])
+    # the 'f' command prints the same two-line blocks for all 20 queries
+    assert len(out) == 2 + 20 * 2
+    es19, ei19 = expected_top(g["allvsall"][19], 2)
+    assert out[-2].startswith("Result 0. Score: %d." % es19[0]) and out[-2].endswith("referenceId %d" % ei19[0])
