@@ -572,18 +572,18 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
     using G = Geometry<KIND, R, LANES>;
     constexpr int kWordsPerRow = G::kRowBytes / 4;
     constexpr int kWordsPerChunkRow = G::kChunkRowBytes / 4;
-    const int total = nstripes * kLetters * kWordsPerRow;
+    const size_t total = (size_t)nstripes * kLetters * kWordsPerRow;
     u32* out = reinterpret_cast<u32*>(profile);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int word = i % kWordsPerRow;
-        const int letter = (i / kWordsPerRow) % kLetters;
-        const int stripe = i / (kWordsPerRow * kLetters);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int word = (int)(i % kWordsPerRow);
+        const int letter = (int)((i / kWordsPerRow) % kLetters);
+        const int stripe = (int)(i / ((size_t)kWordsPerRow * kLetters));
         const int chunk = word / kWordsPerChunkRow, lane = (word % kWordsPerChunkRow) / 4, sub = word % 4;
         const int w = chunk * 4 + sub;  // word index within the lane's NW words
         u32 v = 0;
         if (w < G::NW) {
             auto entry = [&](int row_in_lane) -> u32 {
-                const int row = stripe * G::kStripeRows + lane * R + row_in_lane;
+                const int64_t row = (int64_t)stripe * G::kStripeRows + lane * R + row_in_lane;
                 const int qc = row < qlen ? (int)query[row] : kPadLetter;
                 return A::encode_score((int)matrix21[qc * kLetters + letter]);
             };

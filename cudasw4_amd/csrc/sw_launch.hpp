@@ -1,6 +1,9 @@
 // sw_launch.hpp — per-kind launch tables shared by the kind translation units and sw_api.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+
 #include "sw_dp_kernel.hpp"
 
 namespace swk {
@@ -56,8 +59,8 @@ hipError_t launch_profile_r(const int8_t* query, int32_t qlen, const int8_t* mat
     if constexpr (R > max_rows(Arith<KIND>::kPacked, LANES)) {
         return hipErrorInvalidValue;
     } else {
-        const int total = nstripes * kLetters * (Geometry<KIND, R, LANES>::kRowBytes / 4);
-        const int grid = (total + 255) / 256;
+        const size_t total = (size_t)nstripes * kLetters * (Geometry<KIND, R, LANES>::kRowBytes / 4);
+        const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);  // grid-stride loop covers the rest
         hipLaunchKernelGGL((sw_build_profile_kernel<KIND, R, LANES>), dim3(grid), dim3(256), 0, stream, query, qlen,
                            matrix21, nstripes, out);
         return hipGetLastError();

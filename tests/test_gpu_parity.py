@@ -280,3 +280,18 @@ def test_zero_length_subjects_and_single_subject_batches():
         for cfg, kt in kinds_configs(search, capi).items():
             got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt)
             np.testing.assert_array_equal(got, expect, err_msg="%s n=%d" % (cfg, n))
+
+
+def test_very_long_query():
+    """A 70 000-residue query (137 packed stripes) against a handful of subjects, all kinds."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(41)
+    q = rng.integers(0, 20, 70000).astype(np.int8)
+    seqs = [rng.integers(0, 20, 40).astype(np.int8), q[30000:30300].copy(), rng.integers(0, 20, 900).astype(np.int8),
+            q[100:1700].copy()]
+    seqs.sort(key=len)
+    db = O.make_db(seqs)
+    expect = O.scan(q, *db)
+    for cfg, kt in kinds_configs(search, capi).items():
+        got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt)
+        np.testing.assert_array_equal(got, expect, err_msg=cfg)
