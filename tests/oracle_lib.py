@@ -16,12 +16,25 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 _lib = None
 
 
+def _cpu_has_avx512bw():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " avx512bw " in (line + " ")
+    except OSError:
+        pass
+    return False
+
+
 def build_oracle():
-    """Compile oracle/libsw_oracle.so with gcc if it is missing or stale."""
-    so = os.path.join(ORACLE_DIR, "libsw_oracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sw_oracle.c", "sw_oracle.h", "blosum_tables.inc")]
+    """Compile the oracle with gcc if it is missing or stale; returns the library for this host's ISA level
+    (AVX-512 build when the CPU has it, AVX2 build otherwise — no -march=native: the files travel)."""
+    name = "libsw_oracle_v4.so" if _cpu_has_avx512bw() else "libsw_oracle.so"
+    so = os.path.join(ORACLE_DIR, name)
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sw_oracle.c", "sw_oracle.h", "blosum_tables.inc", "Makefile")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "libsw_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, name], stdout=subprocess.DEVNULL)
     return so
 
 
