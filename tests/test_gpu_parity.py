@@ -295,3 +295,50 @@ def test_very_long_query():
     for cfg, kt in kinds_configs(search, capi).items():
         got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt)
         np.testing.assert_array_equal(got, expect, err_msg=cfg)
+
+
+def test_every_compiled_tile_shape():
+    """Every (kind, rows-per-lane R, group shape, single/multi stripe) instantiation that the planner can pick:
+    query lengths that land on each R for one and for several stripes, 16-lane groups (short subjects,
+    partition 33) and 64-lane groups (long subjects, partition 34 with a small n)."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(77)
+    short = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1, 260, 37))]
+    long_ = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1281, 1700, 9))]
+    ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    seen = set()
+    for seqs, part_id, lanes in ((short, 33, 16), (long_, 34, 64)):
+        chars, offsets, lengths = O.make_db(seqs)
+        db = search.DeviceDB.from_arrays(chars, offsets, lengths, device=0)
+        n = len(seqs)
+        maxlen = int(lengths.max())
+        scores = torch.empty(n, dtype=torch.float32, device="cuda")
+        ids = torch.empty(n, dtype=torch.int32, device="cuda")
+        ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
+            rmax = {16: 32, 64: 16 if kind < 2 else 8}[lanes]
+            qlens = set()
+            for r in range(2, rmax + 1, 2):
+                qlens.add(lanes * r - 1)                       # one stripe of R rows
+                if 2 * r > rmax:
+                    qlens.add(2 * lanes * r - lanes - 3)       # two stripes of R rows
+            qlens.add(3 * lanes * rmax - 5)                    # three full stripes
+            for qlen in sorted(qlens):
+                q = rng.integers(0, 20, qlen).astype(np.int8)
+                expect = O.scan(q, chars, offsets, lengths, simd=True)
+                ctx.set_query(q)
+                need = ctx.scan_temp_bytes(kind, part_id, n, maxlen)
+                temp = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+                scores.fill_(-1.0)
+                ovf_cnt.zero_()
+                ctx.scan_partition(kind, part_id, db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(), 0, n,
+                                   maxlen, -11, -1, scores.data_ptr(), ids.data_ptr(), 0, ovf_pos.data_ptr(),
+                                   ovf_cnt.data_ptr(), 1, temp.data_ptr(), temp.numel(), 0)
+                torch.cuda.synchronize()
+                assert int(ovf_cnt.item()) == 0
+                np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect,
+                                              err_msg="kind %d lanes %d qlen %d" % (kind, lanes, qlen))
+                seen.add((kind, lanes, qlen))
+    assert len(seen) > 120
