@@ -342,3 +342,39 @@ def test_every_compiled_tile_shape():
                                               err_msg="kind %d lanes %d qlen %d" % (kind, lanes, qlen))
                 seen.add((kind, lanes, qlen))
     assert len(seen) > 120
+
+
+def test_randomized_stress_many_scans():
+    """Back-to-back scans with changing query lengths and kernel configurations on one resident ragged DB
+    (concurrent partition launches, profile rebuilds, work-counter reuse, overflow re-score): every scan must
+    reproduce the oracle, including the overflow count and the top-K."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(1234)
+    lens = np.sort(np.concatenate([rng.integers(1, 400, 1500), rng.integers(400, 1280, 300), rng.integers(1281, 4000, 40),
+                                   [8200, 9100]]))
+    seqs = [rng.integers(0, 20, int(l)).astype(np.int8) for l in lens]
+    chars, offsets, lengths = O.make_db(seqs)
+    db = search.DeviceDB.from_arrays(chars, offsets, lengths, device=0)
+    cfgs = list(kinds_configs(search, capi).items())
+    searchers = {}
+    for name, kt in cfgs:
+        s = search.Searcher(device=0, num_top=15, matrix=O.blosum21(62), kernel_types=kt)
+        s.set_database(db)
+        searchers[name] = s
+    for it in range(60):
+        qlen = int(rng.choice([rng.integers(1, 64), rng.integers(64, 600), rng.integers(600, 2500)]))
+        q = rng.integers(0, 20, qlen).astype(np.int8)
+        if it % 3 == 0:  # a homolog of a long DB entry: large scores, packed overflows
+            src = seqs[int(rng.integers(len(seqs) - 45, len(seqs)))]
+            q = src[: max(1, min(len(src), qlen))].copy()
+        expect = O.scan(q, chars, offsets, lengths, simd=True)
+        es, ei = O.topk(expect, 15)
+        name, _ = cfgs[it % len(cfgs)]
+        s = searchers[name]
+        res = s.scan(q)
+        np.testing.assert_array_equal(s.all_scores(), expect, err_msg="%s it %d qlen %d" % (name, it, len(q)))
+        assert res.scores.tolist() == es.tolist() and res.reference_ids.tolist() == ei.tolist(), (name, it)
+        if name == "half2+float":
+            assert res.num_overflows == int((expect >= 2048).sum())
+        if name == "dpxs16+dpxs32":
+            assert res.num_overflows == int((expect >= 25000).sum())
