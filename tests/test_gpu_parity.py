@@ -374,7 +374,8 @@ def test_randomized_stress_many_scans():
         res = s.scan(q)
         np.testing.assert_array_equal(s.all_scores(), expect, err_msg="%s it %d qlen %d" % (name, it, len(q)))
         assert res.scores.tolist() == es.tolist() and res.reference_ids.tolist() == ei.tolist(), (name, it)
+        packed = lengths <= 8000  # partition 35 (> 8000) is scored by a 32-bit kind in these configurations
         if name == "half2+float":
-            assert res.num_overflows == int((expect >= 2048).sum())
+            assert res.num_overflows == int(((expect >= 2048) & packed).sum())
         if name == "dpxs16+dpxs32":
-            assert res.num_overflows == int((expect >= 25000).sum())
+            assert res.num_overflows == int(((expect >= 25000) & packed).sum())
