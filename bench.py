@@ -73,7 +73,7 @@ def cpu_baseline(queries, L, nsubj):
     cells = float(sum(len(q) for q in queries)) * float(nsubj) * float(L)
     return {"value": round(cells / 1e9 / dt, 3), "unit": "GCUPS", "cores": best_nt, "kind": "port",
             "sample": "20 queries x %d pseudo subjects of length %d, int16 inter-sequence SIMD oracle "
-                      "(AVX-512 via gcc -march=native), %.1f s, %d of %d hardware threads (best of a calibration sweep)"
+                      "(gcc, AVX-512 or AVX2 build picked by cpuid), %.1f s, %d of %d hardware threads (best of a calibration sweep)"
                       % (nsubj, L, dt, best_nt, O.max_threads())}
 
 
