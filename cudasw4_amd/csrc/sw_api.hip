@@ -213,7 +213,9 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // because another launch still holds the CUs simply take fewer batches
     p.work_counter = ctx->d_work + (ctx->work_next++ % kWorkSlots);
     SW_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream));
-    SW_HIP(kl->scan(pl.rows, lanes, multi, grid, stream, p));
+    // short subjects: the F half of the stripe border stays in LDS (packed kinds, 16-lane groups)
+    const bool ldsf = multi && lanes == 16 && kl->packed && p.lcap <= swk::kLdsFCols;
+    SW_HIP(kl->scan(pl.rows, lanes, multi, ldsf, grid, stream, p));
     return SW_OK;
 }
 

@@ -395,15 +395,24 @@ constexpr int min_waves() {
     return (R <= 16 && !MULTI) ? 4 : 3;  // 4 would spill the multi-stripe R = 14..16 kernels
 }
 
-template <int KIND, int R, int LANES, bool MULTI>
+// F half of the stripe border kept in LDS (LDSF kernels: 16-lane groups, subjects up to ~540 residues): the
+// spill traffic that leaves the CU halves and the H half (2.8 MB per XCD) fits the 4 MB L2.
+constexpr int kLdsFCols = 576;   // columns per group (>= border_capacity of the longest subject served)
+constexpr int kLdsFJunk = 64;    // junk words in front of each group's columns (non-last lanes, columns < 0)
+constexpr int kLdsFStride = kLdsFCols + kLdsFJunk;
+
+template <int KIND, int R, int LANES, bool MULTI, bool LDSF = false>
 __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_scan_kernel(const ScanParams p) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
+    static_assert(!LDSF || (MULTI && LANES == 16), "the LDS border exists for multi-stripe 16-lane kernels only");
     constexpr int kGroups = kThreads / LANES;
     constexpr int kJunk = border_junk_words<LANES>();
+    constexpr int kJunkF = LDSF ? kLdsFJunk : kJunk;
     constexpr int SHL1 = Shift<LANES>::kShl1;
     constexpr int kQuadsPerLetterBlock = LANES;  // a lane holds 4 letters: LANES quads per reload
     __shared__ __attribute__((aligned(16))) unsigned char lds[16 + G::kTileBytes];
+    __shared__ __attribute__((aligned(16))) u32 ldsF[LDSF ? kGroups * kLdsFStride + 16 : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & (LANES - 1);  // position in the alignment group
@@ -423,7 +432,13 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_sc
     // last lane's store address walk the real arrays; the other lanes hit the junk words (the last lane's
     // stores for columns t-(LANES-1) < 0 land there too).
     u32* const borderH = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroups + group) * 2 * ((size_t)p.lcap + kJunk) + kJunk : nullptr;
-    u32* const borderF = MULTI ? borderH + p.lcap + kJunk : nullptr;
+    u32* borderF = MULTI ? borderH + p.lcap + kJunk : nullptr;
+    const u32* zerosF = p.zeros;
+    if constexpr (LDSF) {
+        borderF = &ldsF[group * kLdsFStride + kLdsFJunk];
+        zerosF = &ldsF[kGroups * kLdsFStride];
+        if (tid < 16) ldsF[kGroups * kLdsFStride + tid] = A::kZero;  // published by the stripe loop's barriers
+    }
 
     __shared__ int next_batch;
     for (;;) {
@@ -493,9 +508,9 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_sc
             const int walkIn = (lane == 0 && !first) ? 4 : 0;  // words per quad the load address advances
             const int walkOut = (lane == LANES - 1) ? 4 : 0;
             const u32* inH = (lane == 0 && !first) ? borderH : p.zeros;
-            const u32* inF = (lane == 0 && !first) ? borderF : p.zeros;
+            const u32* inF = (lane == 0 && !first) ? borderF : zerosF;
             u32* outH = (lane == LANES - 1) ? borderH - (LANES - 1) : borderH - kJunk + 4 * lane;
-            u32* outF = (lane == LANES - 1) ? borderF - (LANES - 1) : borderF - kJunk + 4 * lane;
+            u32* outF = (lane == LANES - 1) ? borderF - (LANES - 1) : borderF - kJunkF + 4 * lane;
             if constexpr (MULTI) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 nextH = *reinterpret_cast<const uint4*>(inH);

@@ -23,7 +23,7 @@ constexpr int max_rows(bool packed, int lanes) {
 
 struct KindLaunch {
     // return hipSuccess or the launch error; (R, lanes) must be a compiled combination, else hipErrorInvalidValue
-    hipError_t (*scan)(int R, int lanes, bool multi, int grid, hipStream_t stream, const ScanParams& p);
+    hipError_t (*scan)(int R, int lanes, bool multi, bool ldsf, int grid, hipStream_t stream, const ScanParams& p);
     hipError_t (*profile)(int R, int lanes, const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t nstripes,
                           unsigned char* out, hipStream_t stream);
     size_t (*tile_bytes)(int R, int lanes);
@@ -37,15 +37,24 @@ const KindLaunch& launch_f32();
 
 // ---- helpers used by the kind TUs ----
 template <int KIND, int R, int LANES>
-hipError_t launch_scan_r(bool multi, int grid, hipStream_t stream, const ScanParams& p) {
+hipError_t launch_scan_r(bool multi, bool ldsf, int grid, hipStream_t stream, const ScanParams& p) {
     // a query that needs more than one stripe always gets R > max/2 from the planner
     constexpr int kMaxR = max_rows(Arith<KIND>::kPacked, LANES);
     if constexpr (R > kMaxR) {
         return hipErrorInvalidValue;
     } else {
         if (multi) {
-            if constexpr (2 * R > kMaxR) hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true>), dim3(grid), dim3(kThreads), 0, stream, p);
-            else return hipErrorInvalidValue;
+            if constexpr (2 * R > kMaxR) {
+                if constexpr (Arith<KIND>::kPacked && LANES == 16) {
+                    if (ldsf) {
+                        hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, true>), dim3(grid), dim3(kThreads), 0, stream, p);
+                        return hipGetLastError();
+                    }
+                }
+                hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true>), dim3(grid), dim3(kThreads), 0, stream, p);
+            } else {
+                return hipErrorInvalidValue;
+            }
         } else {
             hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, false>), dim3(grid), dim3(kThreads), 0, stream, p);
         }
@@ -77,7 +86,8 @@ constexpr size_t tile_bytes_r() {
 #define SWK_FOR_EACH_R_SCALAR(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
 
 #define SWK_DEFINE_KIND(FN, KIND, FOR_EACH_R)                                                                      \
-    static hipError_t FN##_scan(int R, int lanes, bool multi, int grid, hipStream_t stream, const ScanParams& p) {  \
+    static hipError_t FN##_scan(int R, int lanes, bool multi, bool ldsf, int grid, hipStream_t stream,            \
+                                const ScanParams& p) {                                                              \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN64_##KIND) } }                                 \
         return hipErrorInvalidValue;                                                                                \
