@@ -398,7 +398,8 @@ constexpr int min_waves() {
 // F half of the stripe border kept in LDS (LDSF kernels: 16-lane groups, subjects up to ~540 residues): the
 // spill traffic that leaves the CU halves and the H half (2.8 MB per XCD) fits the 4 MB L2.
 constexpr int kLdsFCols = 576;   // columns per group (>= border_capacity of the longest subject served)
-constexpr int kLdsFJunk = 64;    // junk words in front of each group's columns (non-last lanes, columns < 0)
+constexpr int kLdsFJunk = 96;    // junk words in front of each group's columns (non-last lanes, columns < 0);
+                                 // stride 672 = 21 * 32 words keeps the bank pattern identical for every group
 constexpr int kLdsFStride = kLdsFCols + kLdsFJunk;
 
 template <int KIND, int R, int LANES, bool MULTI, bool LDSF = false>
@@ -510,7 +511,10 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_sc
             const u32* inH = (lane == 0 && !first) ? borderH : p.zeros;
             const u32* inF = (lane == 0 && !first) ? borderF : zerosF;
             u32* outH = (lane == LANES - 1) ? borderH - (LANES - 1) : borderH - kJunk + 4 * lane;
-            u32* outF = (lane == LANES - 1) ? borderF - (LANES - 1) : borderF - kJunkF + 4 * lane;
+            // junk slots: 4 words per lane; in LDS they are skewed so that the 32 lanes of a half wave hit 32
+            // different banks (4*lane repeats every 8 lanes; the two groups of a half wave share a bank pattern)
+            const int junkSlot = LDSF ? 4 * lane + (lane >> 3) + 2 * (group & 1) : 4 * lane;
+            u32* outF = (lane == LANES - 1) ? borderF - (LANES - 1) : borderF - kJunkF + junkSlot;
             if constexpr (MULTI) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 nextH = *reinterpret_cast<const uint4*>(inH);
