@@ -170,3 +170,30 @@ def test_host_input_helpers_match_reference(golden_dir):
         assert driver.matrix(which).tolist() == g["blosum21"][str(which)]
     with pytest.raises(ValueError):
         driver.matrix(63)
+
+
+def test_cpp_reader_and_sharding_match_python_mirror(tmp_path, golden_dir):
+    """The C++ DB reader / partition counts / shard_database against the reference's metadata file and the
+    Python mirror used by bench.py (search.shard_ranges)."""
+    import json
+    from cudasw4_amd import search
+    dbinspect = os.path.join(LIBDIR, "dbinspect")
+    rng = np.random.default_rng(29)
+    fasta = str(tmp_path / "in.fa")
+    _random_fasta(fasta, rng, 1500)
+    prefix = str(tmp_path / "db")
+    subprocess.check_call([MAKEDB, fasta, prefix], stdout=subprocess.DEVNULL)
+    lengths = np.fromfile(prefix + "0lengths", dtype=np.int32)
+    offsets = np.fromfile(prefix + "0offsets", dtype=np.uint64)
+    meta = open(prefix + "0metadata", "rb").read()
+    counts_file = np.frombuffer(meta[4 + 36 * 4:], dtype=np.uint64)
+    for shards in (1, 2, 3, 8):
+        info = json.loads(subprocess.check_output([dbinspect, prefix, str(shards)]))
+        assert info["num_sequences"] == len(lengths) and info["residues"] == int(lengths.sum())
+        assert info["partition_counts"] == counts_file.tolist()
+        expect = search.shard_ranges(offsets, lengths, shards)
+        assert info["shards"] == [[list(r) for r in shard] for shard in expect]
+    info = json.loads(subprocess.check_output([dbinspect, os.path.join(golden_dir, "allqueries_db", "aq"), "2"]))
+    assert info["num_sequences"] == 20 and info["first_header"].startswith("gi|")
+    bad = subprocess.run([dbinspect, str(tmp_path / "nope")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Cannot open DB" in bad.stderr
