@@ -459,6 +459,8 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
     const double t0 = now_seconds();
 
     const int k = numTop_;
+    // the query goes to every GPU first (a short synchronous copy each), then the scans are enqueued: the
+    // GPUs start within microseconds of each other instead of one set-up time apart
     for (auto& gp : gpus_) {
         Gpu& g = *gp;
         g.use();
@@ -466,6 +468,11 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
         if (g.numLocal == 0) continue;
         if (g.wantResident && !g.resident) uploadShard(g);  // first query pays the upload unless --uploadFull
         SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
+    }
+    for (auto& gp : gpus_) {
+        Gpu& g = *gp;
+        g.use();
+        if (g.numLocal == 0) continue;
         // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
         if (g.resident) scanResident(g, queryLength);
         else scanStreamed(g, queryLength);
