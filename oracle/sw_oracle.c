@@ -254,6 +254,140 @@ void swo_scan_simd(const int8_t* q, int32_t qlen, const int8_t* chars, const uin
     (void)nthreads;
 }
 
+/* ------------------------------------------------------------------ Farrar striped baseline */
+
+/* Striped layout (Farrar 2007): the query is cut into SWO_SW segments of seg = ceil(qlen/SWO_SW) rows; vector i
+ * (0 <= i < seg) holds rows i, i+seg, i+2*seg, ... in its lanes.  One pass over the seg vectors per subject
+ * letter computes H and E; the vertical gap F is propagated lane to lane afterwards by the lazy-F loop, which
+ * (unlike the original SSE2 code) also refreshes E so that the result is exact for every gap setting. */
+#if defined(__AVX512BW__)
+#include <immintrin.h>
+#define SWO_SW 32
+typedef int16_t swo_v __attribute__((vector_size(64)));
+static inline swo_v swo_vmax(swo_v a, swo_v b) { return (swo_v)_mm512_max_epi16((__m512i)a, (__m512i)b); }
+static inline int swo_any_gt(swo_v a, swo_v b) { return _mm512_cmpgt_epi16_mask((__m512i)a, (__m512i)b) != 0; }
+static inline swo_v swo_shift_in(swo_v v, int16_t first) {  /* lane l <- lane l-1, lane 0 <- first */
+    const __m512i idx = _mm512_set_epi16(30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10,
+                                         9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 0);
+    swo_v r = (swo_v)_mm512_permutexvar_epi16(idx, (__m512i)v);
+    r[0] = first;
+    return r;
+}
+#elif defined(__AVX2__)
+#include <immintrin.h>
+#define SWO_SW 16
+typedef int16_t swo_v __attribute__((vector_size(32)));
+static inline swo_v swo_vmax(swo_v a, swo_v b) { return (swo_v)_mm256_max_epi16((__m256i)a, (__m256i)b); }
+static inline int swo_any_gt(swo_v a, swo_v b) { return _mm256_movemask_epi8(_mm256_cmpgt_epi16((__m256i)a, (__m256i)b)) != 0; }
+static inline swo_v swo_shift_in(swo_v v, int16_t first) {
+    const __m256i lo = _mm256_permute2x128_si256((__m256i)v, (__m256i)v, 0x08);  /* [0, v.lo128] */
+    swo_v r = (swo_v)_mm256_alignr_epi8((__m256i)v, lo, 14);
+    r[0] = first;
+    return r;
+}
+#else
+#define SWO_SW 16
+typedef int16_t swo_v __attribute__((vector_size(32)));
+static inline swo_v swo_vmax(swo_v a, swo_v b) {
+    const swo_v m = a > b;  /* all-ones lanes where a > b (C has no vector ?:) */
+    return (a & m) | (b & ~m);
+}
+static inline swo_v swo_shift_in(swo_v v, int16_t first) {
+    swo_v r;
+    for (int l = SWO_SW - 1; l > 0; l--) r[l] = v[l - 1];
+    r[0] = first;
+    return r;
+}
+static inline int swo_any_gt(swo_v a, swo_v b) {
+    swo_v m = a > b;
+    for (int l = 0; l < SWO_SW; l++) if (m[l]) return 1;
+    return 0;
+}
+#endif
+
+static int32_t swo_striped_one(const swo_v* profile, int32_t seg, const int8_t* s, int32_t slen, int16_t go, int16_t ge,
+                               swo_v* Hstore, swo_v* Hload, swo_v* E) {
+    swo_v zero = {0}, vmaxv = {0}, vgo, vge;
+    for (int l = 0; l < SWO_SW; l++) { vgo[l] = go; vge[l] = ge; }
+    for (int32_t i = 0; i < seg; i++) { Hstore[i] = zero; E[i] = zero; }
+    for (int32_t j = 0; j < slen; j++) {
+        const swo_v* prow = profile + (size_t)s[j] * seg;
+        swo_v vF = zero;
+        swo_v vH = swo_shift_in(Hstore[seg - 1], 0);
+        swo_v* t = Hload; Hload = Hstore; Hstore = t;
+        for (int32_t i = 0; i < seg; i++) {
+            vH = vH + prow[i];
+            vH = swo_vmax(vH, E[i]);
+            vH = swo_vmax(vH, vF);
+            vH = swo_vmax(vH, zero);
+            vmaxv = swo_vmax(vmaxv, vH);
+            Hstore[i] = vH;
+            const swo_v open = vH - vgo;
+            E[i] = swo_vmax(swo_vmax(E[i] - vge, open), zero);   /* clamped like the GPU kernels: same H */
+            vF = swo_vmax(swo_vmax(vF - vge, open), zero);
+            vH = Hload[i];
+        }
+        /* lazy F: the F leaving a lane's last row enters the next lane's first row; propagate until the
+         * chain equals what the first pass already computed (F - ge <= H - go in every lane) */
+        for (int k = 0; k < SWO_SW; k++) {
+            vF = swo_shift_in(vF, 0);
+            int done = 0;
+            for (int32_t i = 0; i < seg; i++) {
+                swo_v h = Hstore[i];
+                const int raised = swo_any_gt(vF, h);
+                if (raised) {
+                    h = swo_vmax(h, vF);
+                    Hstore[i] = h;
+                    vmaxv = swo_vmax(vmaxv, h);
+                    E[i] = swo_vmax(E[i], swo_vmax(h - vgo, zero));
+                }
+                const swo_v open = swo_vmax(h - vgo, zero);
+                const swo_v ext = swo_vmax(vF - vge, zero);
+                /* H untouched here and the extended gap no better than a freshly opened one: identical to pass 1 */
+                if (!raised && !swo_any_gt(ext, open)) { done = 1; break; }
+                vF = swo_vmax(ext, open);
+            }
+            if (done) break;
+        }
+    }
+    int16_t best = 0;
+    for (int l = 0; l < SWO_SW; l++) if (vmaxv[l] > best) best = vmaxv[l];
+    return best;
+}
+
+void swo_scan_striped(const int8_t* q, int32_t qlen, const int8_t* chars, const uint64_t* offsets,
+                      const int32_t* lengths, int64_t n, const int8_t* m21, int32_t gop, int32_t gex,
+                      int32_t* scores, int nthreads) {
+    if (qlen <= 0) { for (int64_t k = 0; k < n; k++) scores[k] = 0; return; }
+    const int32_t seg = (qlen + SWO_SW - 1) / SWO_SW;
+    swo_v* profile = (swo_v*)aligned_alloc(64, sizeof(swo_v) * 21 * (size_t)seg);
+    for (int c = 0; c < 21; c++)
+        for (int32_t i = 0; i < seg; i++)
+            for (int l = 0; l < SWO_SW; l++) {
+                const int32_t row = i + l * seg;
+                profile[(size_t)c * seg + i][l] = row < qlen ? m21[(int)q[row] * 21 + c] : m21[20 * 21 + c];
+            }
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        swo_v* buf = (swo_v*)aligned_alloc(64, sizeof(swo_v) * 3 * (size_t)seg);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (int64_t k = 0; k < n; k++) {
+            const int8_t* s = chars + (offsets[k] - offsets[0]);
+            int32_t sc = swo_striped_one(profile, seg, s, lengths[k], (int16_t)(-gop), (int16_t)(-gex), buf, buf + seg, buf + 2 * seg);
+            if (sc >= SWO_I16_LIMIT) sc = swo_score(q, qlen, s, lengths[k], m21, gop, gex);
+            scores[k] = sc;
+        }
+        free(buf);
+    }
+    free(profile);
+    (void)nthreads;
+}
+
 /* ------------------------------------------------------------------ pseudo DB generator */
 
 /* MT19937 (Matsumoto & Nishimura) == std::mt19937; seeding == std::mt19937(seed). */

@@ -44,6 +44,13 @@ void swo_scan_simd(const int8_t* q, int32_t qlen, const int8_t* chars, const uin
                    const int32_t* lengths, int64_t n, const int8_t* m21, int32_t gop, int32_t gex,
                    int32_t* scores, int nthreads);
 
+/* Farrar's striped Smith-Waterman (the SSW algorithm): intra-sequence SIMD over the query with a striped query
+ * profile and the lazy-F correction loop, int16 lanes, int32 re-score on saturation.  Second CPU baseline and a
+ * third independent implementation of the recurrence.  Same results as swo_scan. */
+void swo_scan_striped(const int8_t* q, int32_t qlen, const int8_t* chars, const uint64_t* offsets,
+                      const int32_t* lengths, int64_t n, const int8_t* m21, int32_t gop, int32_t gex,
+                      int32_t* scores, int nthreads);
+
 /* dbdata.hpp:222-272 — the pseudo-DB subject: `length` codes drawn with std::mt19937(seed) and
  * std::uniform_int_distribution<>(0,19) (libstdc++ >= 11 algorithm). */
 void swo_pseudodb_codes(int32_t length, uint32_t seed, int8_t* out);

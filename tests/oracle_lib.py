@@ -48,7 +48,7 @@ def lib():
         L.swo_score.restype = ctypes.c_int32
         L.swo_score.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                 ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
-        for name in ("swo_scan", "swo_scan_simd"):
+        for name in ("swo_scan", "swo_scan_simd", "swo_scan_striped"):
             f = getattr(L, name)
             f.restype = None
             f.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -85,14 +85,14 @@ def score(q, s, m21=None, gop=-11, gex=-1) -> int:
     return int(lib().swo_score(q.ctypes.data, len(q), s.ctypes.data, len(s), m.ctypes.data, gop, gex))
 
 
-def scan(q, chars, offsets, lengths, m21=None, gop=-11, gex=-1, simd=False, nthreads=0) -> np.ndarray:
+def scan(q, chars, offsets, lengths, m21=None, gop=-11, gex=-1, simd=False, nthreads=0, striped=False) -> np.ndarray:
     q = np.ascontiguousarray(q, dtype=np.int8)
     chars = np.ascontiguousarray(chars, dtype=np.int8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     lengths = np.ascontiguousarray(lengths, dtype=np.int32)
     m = blosum21(62) if m21 is None else np.ascontiguousarray(m21, dtype=np.int8)
     out = np.empty(len(lengths), dtype=np.int32)
-    f = lib().swo_scan_simd if simd else lib().swo_scan
+    f = lib().swo_scan_striped if striped else (lib().swo_scan_simd if simd else lib().swo_scan)
     f(q.ctypes.data, len(q), chars.ctypes.data, offsets.ctypes.data, lengths.ctypes.data, len(lengths),
       m.ctypes.data, gop, gex, out.ctypes.data, nthreads)
     return out

@@ -93,6 +93,28 @@ def test_simd_equals_scalar_on_ragged_db():
     np.testing.assert_array_equal(O.scan(q, chars, offsets, lengths), O.scan(q, chars, offsets, lengths, simd=True))
 
 
+def test_striped_equals_scalar():
+    """Farrar striped SW (second CPU baseline): lazy-F path, query lengths around the vector width, gap
+    settings where extension costs more than opening, scores that saturate int16."""
+    rng = np.random.default_rng(11)
+    lens = np.sort(rng.integers(1, 400, 150))
+    seqs = [rng.integers(0, 21, int(n)).astype(np.int8) for n in lens]
+    seqs[100] = seqs[140][: len(seqs[100])].copy()
+    db = O.make_db(seqs)
+    for ql in (1, 15, 16, 17, 31, 32, 33, 150, 513):
+        q = rng.integers(0, 20, ql).astype(np.int8)
+        if ql == 150:
+            q = seqs[140][:150].copy()
+        for gop, gex in ((-11, -1), (-3, -3), (0, 0), (-1, -5), (-20, -7)):
+            np.testing.assert_array_equal(O.scan(q, *db, gop=gop, gex=gex), O.scan(q, *db, gop=gop, gex=gex, striped=True),
+                                          err_msg="q %d gop %d gex %d" % (ql, gop, gex))
+    g = O.golden("ref_scores.json")
+    _, qs = O.load_queries()
+    dbq = O.make_db(qs)
+    for i in (3, 16, 19):  # incl. scores >= 25000 -> int32 re-score
+        assert O.scan(qs[i], *dbq, striped=True).tolist() == g["allvsall"][i]
+
+
 def test_topk_order():
     s = np.array([5, 9, 9, 1, 7], dtype=np.int32)
     sc, ids = O.topk(s, 3)
