@@ -473,7 +473,10 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_sc
             lmax = max(lmax, __shfl_xor(lmax, 32));
         }
         // the last lane finishes column lmax-1 at step lmax+LANES-2
-        const int nquads = (lmax + LANES - 1 + 3) >> 2;
+        int nquads = (lmax + LANES - 1 + 3) >> 2;
+        // the border arrays hold lcap columns (sized from the caller's max_subject_len): never walk past them,
+        // even if a caller under-reports the bound (scores of such subjects are then wrong, memory is not)
+        if constexpr (MULTI) nquads = min(nquads, (p.lcap - 4) >> 2);
         const int len0pad = (len0 + 3) & ~3, len1pad = (len1 + 3) & ~3;
 
         u32 maxv = A::kZero;
