@@ -73,9 +73,22 @@ def cpu_baseline(queries, L, nsubj):
         for q in queries:
             O.scan(q, chars, offsets, lengths, m21=m, nthreads=best_nt, **kw)
         rates[name] = (cells / 1e9 / (time.perf_counter() - t0), time.perf_counter() - t0)
+    # the reference's own scalar int32 DP (cudasw4.cuh:2331-2392 restated), one core, a few hundred subjects
+    ns = 300
+    sc = O.make_db([codes] * ns)
+    t0 = time.perf_counter()
+    O.scan(queries[9], *sc, m21=m, nthreads=1)
+    scalar_rate = len(queries[9]) * float(ns) * L / 1e9 / (time.perf_counter() - t0)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
     best = max(rates, key=lambda k: rates[k][0])
     return {"value": round(rates[best][0], 3), "unit": "GCUPS", "cores": best_nt, "kind": "port",
             "algorithm": best, "striped_gcups": round(rates["striped"][0], 3), "interseq_gcups": round(rates["interseq"][0], 3),
+            "scalar_1core_gcups": round(scalar_rate, 4), "cpu_model": model,
             "sample": "20 queries x %d pseudo subjects of length %d; oracle ports with int16 lanes (gcc, AVX-512 or AVX2 "
                       "build picked by cpuid): Farrar striped SW %.1f s, inter-sequence SIMD %.1f s; %d of %d hardware "
                       "threads (best of a calibration sweep)"

@@ -368,8 +368,8 @@ struct TopkLayout {
 TopkLayout topk_layout(int64_t n) {
     TopkLayout L{};
     size_t cub = 0;
-    hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const float*)nullptr, (float*)nullptr,
-                                                 (const int32_t*)nullptr, (int32_t*)nullptr, (int)std::max<int64_t>(n, 1));
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const float*)nullptr, (float*)nullptr,
+                                                       (const int32_t*)nullptr, (int32_t*)nullptr, (int)std::max<int64_t>(n, 1));
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     L.keys_off = 0;
     L.vals_off = al((size_t)n * sizeof(float));

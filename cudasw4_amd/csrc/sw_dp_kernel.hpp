@@ -204,7 +204,7 @@ struct Arith<F32> {
 
 // ------------------------------------------------------------------------------------------------
 // Profile tile geometry (shared by the profile builder and the kernel).
-//   NW     32-bit words a lane reads per letter per step (R/2 packed, R scalar)
+//   NW     32-bit words a lane reads per letter per step (ceil(R/2) packed, R scalar)
 //   NCH    16-byte chunks per lane per letter
 //   letter row  = NCH chunks-rows of 256 bytes: chunk k of lane l at  k*256 + l*16
 //   tile        = 21 letter rows, preceded by 16 bytes (lane addresses carry a +16 bias, see Step)
@@ -212,8 +212,8 @@ struct Arith<F32> {
 template <int KIND, int R, int LANES = kGroup>
 struct Geometry {
     static constexpr bool kPacked = Arith<KIND>::kPacked;
-    static_assert(!kPacked || (R % 2 == 0), "packed kinds need an even number of rows per lane");
-    static constexpr int NW = kPacked ? R / 2 : R;
+    // packed kinds keep two query rows per 32-bit profile word; an odd R leaves the upper half of the last word unused
+    static constexpr int NW = kPacked ? (R + 1) / 2 : R;
     static constexpr int NCH = (NW + 3) / 4;
     static constexpr int kChunkRowBytes = LANES * 16;            // chunk k of lane l at k*kChunkRowBytes + l*16
     static constexpr int kRowBytes = NCH * kChunkRowBytes;
@@ -338,11 +338,8 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
         F = A::gap_state(A::gap(F, gex), hg);
         st.H[r] = h;
         // running maximum: folded two rows at a time (a 3-input max where the ISA has one)
-        if constexpr (R % 2 == 0) {
-            if (r & 1) maxv = A::fold2(maxv, st.H[r - 1], h);
-        } else {
-            maxv = A::max2(maxv, h);
-        }
+        if (r & 1) maxv = A::fold2(maxv, st.H[r - 1], h);
+        else if (r == R - 1) maxv = A::max2(maxv, h);
     }
     st.maxv = maxv;
     st.Hlast = st.H[R - 1];
@@ -388,11 +385,12 @@ constexpr int border_junk_words() { return LANES == 16 ? 128 : 320; }  // >= 4*(
 #ifndef SWK_MIN_WAVES_SCALAR
 #define SWK_MIN_WAVES_SCALAR 0
 #endif
-template <int KIND, int R, bool MULTI>
+template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
     if (Arith<KIND>::kPacked) return 1;
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
-    return (R <= 16 && !MULTI) ? 4 : 3;  // 4 would spill the multi-stripe R = 14..16 kernels
+    // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
+    return (R <= 16 && !MULTI && LANES == 16) ? 4 : 3;
 }
 
 // F half of the stripe border kept in LDS (LDSF kernels: 16-lane groups, subjects up to ~540 residues): the
@@ -403,7 +401,7 @@ constexpr int kLdsFJunk = 96;    // junk words in front of each group's columns 
 constexpr int kLdsFStride = kLdsFCols + kLdsFJunk;
 
 template <int KIND, int R, int LANES, bool MULTI, bool LDSF = false>
-__global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, MULTI>())) sw_scan_kernel(const ScanParams p) {
+__global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())) sw_scan_kernel(const ScanParams p) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
     static_assert(!LDSF || (MULTI && LANES == 16), "the LDS border exists for multi-stripe 16-lane kernels only");
@@ -605,6 +603,7 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
         u32 v = 0;
         if (w < G::NW) {
             auto entry = [&](int row_in_lane) -> u32 {
+                if (row_in_lane >= R) return 0u;  // unused upper half of an odd R's last word
                 const int64_t row = (int64_t)stripe * G::kStripeRows + lane * R + row_in_lane;
                 const int qc = row < qlen ? (int)query[row] : kPadLetter;
                 return A::encode_score((int)matrix21[qc * kLetters + letter]);

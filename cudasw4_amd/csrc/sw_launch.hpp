@@ -9,9 +9,12 @@
 namespace swk {
 
 // Rows-per-lane values that are compiled.  The query planner (sw_api.hip: plan_query) only picks these.
-constexpr int kRowsGranule = 2;
+constexpr int kRowsGranule = 1;
 // standard shape (16-lane groups)
-constexpr int kMaxRowsPacked = 32;  // stripe = 512 query rows, 21.5 KB tile
+#ifndef SWK_MAX_ROWS_PACKED
+#define SWK_MAX_ROWS_PACKED 44
+#endif
+constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 704 query rows, 31.5 KB tile; 251 VGPRs as a multi-stripe kernel (2 waves/SIMD)
 constexpr int kMaxRowsScalar = 32;  // stripe = 512 query rows (32-bit profile entries, 43 KB tile)
 // long-subject shape (64-lane groups)
 constexpr int kMaxRowsPackedLong = 16;  // stripe = 1024 query rows, 43 KB tile
@@ -82,8 +85,10 @@ constexpr size_t tile_bytes_r() {
     else return (size_t)Geometry<KIND, R, LANES>::kTileBytes;
 }
 
-#define SWK_FOR_EACH_R_PACKED(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
-#define SWK_FOR_EACH_R_SCALAR(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+#define SWK_FOR_EACH_R_PACKED(X) \
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44)
+#define SWK_FOR_EACH_R_SCALAR(X) \
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
 #define SWK_DEFINE_KIND(FN, KIND, FOR_EACH_R)                                                                      \
     static hipError_t FN##_scan(int R, int lanes, bool multi, bool ldsf, int grid, hipStream_t stream,            \

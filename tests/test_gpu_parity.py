@@ -318,12 +318,16 @@ def test_every_compiled_tile_shape():
         ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
         ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
-            rmax = {16: 32, 64: 16 if kind < 2 else 8}[lanes]
+            rmax = {16: 44 if kind < 2 else 32, 64: 16 if kind < 2 else 8}[lanes]
             qlens = set()
-            for r in range(2, rmax + 1, 2):
+            for r in range(1, rmax + 1):
                 qlens.add(lanes * r - 1)                       # one stripe of R rows
+                if lanes == 16:
+                    assert capi.plan_query(kind, lanes * r - 1) == (r, 1)
                 if 2 * r > rmax:
                     qlens.add(2 * lanes * r - lanes - 3)       # two stripes of R rows
+                    if lanes == 16:
+                        assert capi.plan_query(kind, 2 * lanes * r - lanes - 3) == (r, 2)
             qlens.add(3 * lanes * rmax - 5)                    # three full stripes
             for qlen in sorted(qlens):
                 q = rng.integers(0, 20, qlen).astype(np.int8)
@@ -341,7 +345,7 @@ def test_every_compiled_tile_shape():
                 np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect,
                                               err_msg="kind %d lanes %d qlen %d" % (kind, lanes, qlen))
                 seen.add((kind, lanes, qlen))
-    assert len(seen) > 120
+    assert len(seen) > 250
 
 
 def test_randomized_stress_many_scans():
