@@ -96,6 +96,8 @@ struct sw_ctx {
     uint32_t* d_zeros = nullptr; // per kind 64 bytes of its zero pattern (first-stripe border): [kind * 16 words]
     uint32_t* d_work = nullptr;  // kWorkSlots batch counters (dynamic batch distribution), one per launch in flight
     uint32_t work_next = 0;
+    int grid_mult = 4;           // persistent workgroups per CU (CUDASW4_AMD_GRID_MULT overrides, for experiments)
+    bool use_stream = true;      // CUDASW4_AMD_NO_STREAM=1 falls back to one pipeline fill per subject (A/B measurements)
     bool have_matrix = false;
     int8_t* d_query = nullptr;
     size_t query_capacity = 0;
@@ -106,7 +108,7 @@ struct sw_ctx {
 
 namespace {
 
-int max_grid(const sw_ctx* ctx) { return std::max(1, ctx->num_cus) * 4; }
+int max_grid(const sw_ctx* ctx) { return std::max(1, ctx->num_cus) * ctx->grid_mult; }
 
 // Reference partitions 34 (1281..8000) and 35 (> 8000) hold the long subjects.  When there are only a few
 // of them (the tail of a real DB) they get the wave-wide group shape: 4x the lanes per alignment, so the
@@ -215,6 +217,12 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     SW_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream));
     // short subjects: the F half of the stripe border stays in LDS (packed kinds, 16-lane groups)
     const bool ldsf = multi && lanes == 16 && kl->packed && p.lcap <= swk::kLdsFCols;
+    // single-stripe queries over 16-lane groups: the subjects of a wave follow each other without draining the
+    // pipeline (sw_stream_kernel.hpp); the re-score path (position list, device-side count) keeps the plain kernel
+    if (!multi && lanes == 16 && !positions && !count_ptr && ctx->use_stream) {
+        SW_HIP(kl->stream(pl.rows, grid, stream, p));
+        return SW_OK;
+    }
     SW_HIP(kl->scan(pl.rows, lanes, multi, ldsf, grid, stream, p));
     return SW_OK;
 }
@@ -245,6 +253,8 @@ int sw_ctx_create(int device, sw_ctx** out) {
     sw_ctx* ctx = new sw_ctx;
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    if (const char* e = getenv("CUDASW4_AMD_NO_STREAM")) ctx->use_stream = !(e[0] == '1');
+    if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
     hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));

@@ -348,6 +348,31 @@ def test_every_compiled_tile_shape():
     assert len(seen) > 250
 
 
+@pytest.mark.parametrize("qlen", [300, 600])
+def test_stream_nonfinite_states(qlen):
+    """Single-stripe queries run as a continuous stream of subjects per wave, separated by columns that reset the DP
+    state.  With a custom matrix of large entries a subject can drive the packed state to fp16 +inf (score > 65504)
+    or to an int16 NaN bit pattern (> 30719), which no separator can reset: the subjects that follow it in the
+    stream must then come out flagged and be re-scored exactly, like the offender itself."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(5)
+    m = np.full((21, 21), -4, dtype=np.int8)
+    np.fill_diagonal(m, 120)
+    m[20, 20] = -4                              # scores against the padding letter must stay negative
+    q = rng.integers(0, 20, qlen).astype(np.int8)
+    seqs = [rng.integers(0, 20, int(l)).astype(np.int8) for l in rng.integers(20, qlen + 40, 700)]
+    for k in range(0, 700, 37):
+        seqs[k] = q.copy()                      # self hits: qlen * 120 = 36000 / 72000
+    for k in range(5, 700, 53):
+        seqs[k] = q[: qlen // 2].copy()         # half hits: 18000 / 36000
+    db = O.make_db(seqs)
+    expect = O.scan(q, *db, m21=m, simd=False)
+    assert expect.max() == qlen * 120
+    for cfg, kt in kinds_configs(search, capi).items():
+        got, res, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, matrix=m)
+        np.testing.assert_array_equal(got, expect, err_msg=cfg)
+
+
 def test_randomized_stress_many_scans():
     """Back-to-back scans with changing query lengths and kernel configurations on one resident ragged DB
     (concurrent partition launches, profile rebuilds, work-counter reuse, overflow re-score): every scan must
