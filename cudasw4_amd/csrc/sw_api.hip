@@ -220,6 +220,18 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // single-stripe queries over 16-lane groups: the subjects of a wave follow each other without draining the
     // pipeline (sw_stream_kernel.hpp); the re-score path (position list, device-side count) keeps the plain kernel
     if (!multi && lanes == 16 && !positions && !count_ptr && ctx->use_stream) {
+#ifdef SWK_TRACE  // diagnostic builds only: dump the per-wave timeline of this launch (tools/trace_stats.py)
+        static uint32_t* trace = nullptr;
+        if (!trace) SW_HIP(hipMalloc(&trace, 1 << 20));
+        SW_HIP(hipMemsetAsync(trace, 0, 1 << 20, stream));
+        p.scratch = trace;
+        SW_HIP(kl->stream(pl.rows, grid, stream, p));
+        SW_HIP(hipStreamSynchronize(stream));
+        static std::vector<uint64_t> host(1 << 17);
+        SW_HIP(hipMemcpy(host.data(), trace, 1 << 20, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen("gpurun_out/trace.bin", "wb")) { fwrite(host.data(), 8, (size_t)grid * 4 * 4, f); fclose(f); }
+        return SW_OK;
+#endif
         SW_HIP(kl->stream(pl.rows, grid, stream, p));
         return SW_OK;
     }

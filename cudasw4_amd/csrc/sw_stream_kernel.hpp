@@ -201,9 +201,10 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, kGroup, false>()
         l = max(l, __shfl_xor(l, 32));
         return max(S::kMinQuads, __builtin_amdgcn_readfirstlane((l + 3) >> 2));
     };
+    const int nwaves_ = (int)gridDim.x * (kThreads / 64);
     auto grab = [&]() -> u32 {  // next round of this wave; the value is read (readfirstlane) one round later
         u32 v = 0;
-        if (wlane == 0) v = atomicAdd(p.work_counter, 1u);
+        if (wlane == 0) v = atomicAdd(p.work_counter, 1u) + 2u * (u32)nwaves_;
         return v;
     };
     // lane l holds letters 64*blk + 4l .. +3 of the round's column stream (subject, padding, separator quad),
@@ -227,10 +228,17 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, kGroup, false>()
         return w;
     };
 
-    int b_cur = __builtin_amdgcn_readfirstlane((int)grab());
+    // The first two rounds of a wave are assigned statically (wave w: rounds w and w + W) and the counter hands out
+    // rounds from 2W on: 4096 waves starting with three dependent atomics each on one address cost ~120 us.
+#ifdef SWK_TRACE  // per-wave timeline for tools/trace_stats.py (diagnostic builds only)
+    const uint64_t t_start = wall_clock64();
+    int rounds_done = 0;
+#endif
+    const int nwaves = (int)gridDim.x * (kThreads / 64);
+    int b_cur = (int)blockIdx.x * (kThreads / 64) + (tid >> 6);
     if (b_cur >= nrounds) return;
     commit_meta(0, issue_meta(b_cur));
-    int b_nxt = __builtin_amdgcn_readfirstlane((int)grab());
+    int b_nxt = b_cur + nwaves;
     commit_meta(1, issue_meta(b_nxt));
     u32 ticket = grab();
     int slot_cur = 0;
@@ -272,6 +280,9 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, kGroup, false>()
         }
     };
 
+#ifdef SWK_TRACE
+    const uint64_t t_loop = wall_clock64();
+#endif
     for (;;) {
         const bool drain = b_cur >= nrounds;  // past the last round: three more quads complete the hand-over
         const int slot_nxt = slot_cur == 2 ? 0 : slot_cur + 1;
@@ -314,11 +325,20 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, kGroup, false>()
             }
         }
         if (drain) break;
+#ifdef SWK_TRACE
+        rounds_done++;
+#endif
         commit_meta(slot_nxt2, inflight);
         pend_b = b_cur;
         b_cur = b_nxt; nq_cur = nq_nxt; slot_cur = slot_nxt;
         b_nxt = b_nxt2;
     }
+#ifdef SWK_TRACE
+    if (wlane == 0 && p.scratch) {
+        uint64_t* out = reinterpret_cast<uint64_t*>(p.scratch) + 4 * (size_t)(blockIdx.x * (kThreads / 64) + (tid >> 6));
+        out[0] = t_start; out[1] = t_loop; out[2] = wall_clock64(); out[3] = (uint64_t)rounds_done | ((uint64_t)__smid() << 32);
+    }
+#endif
 }
 
 }  // namespace swk
