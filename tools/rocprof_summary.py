@@ -12,19 +12,19 @@ from collections import defaultdict
 def stats(path):
     db = sqlite3.connect(path)
     rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    print("%-78s %6s %14s %14s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+    print("%-78s %6s %14s %14s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, total, avg, pct in rows:
         print("%-78s %6d %14.0f %14.0f %7.2f" % (name[:78], calls, total, avg, pct))
     print()
     print("per-dispatch register/LDS use of the DP kernels:")
     q = ("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x, count(*), avg(duration) "
-         "from kernels where name like '%sw_scan_kernel%' group by name, grid_x order by avg(duration) desc")
+         "from kernels where (name like '%sw_scan_kernel%' or name like '%sw_stream_kernel%') group by name, grid_x order by avg(duration) desc")
     print("%-60s %5s %5s %5s %7s %8s %5s %6s %12s" % ("kernel", "vgpr", "agpr", "sgpr", "lds", "grid", "wg", "calls", "avg_ns"))
     for r in db.execute(q):
         print("%-60s %5d %5d %5d %7d %8d %5d %6d %12.0f" % ((r[0][:60],) + tuple(r[1:])))
 
 
-def pmc(path, flt="sw_scan_kernel"):
+def pmc(path, flt="swk::sw_s"):
     db = sqlite3.connect(path)
     acc = defaultdict(lambda: [0, 0.0, 0.0])
     for name, counter, value, dur in db.execute(
@@ -50,7 +50,7 @@ def traffic(fetch_db, write_db):
         acc = defaultdict(lambda: [0, 0.0, 0.0])
         for name, value, dur in db.execute(
                 "select kernel_name, value, duration from counters_collection where counter_name = ?", (counter,)):
-            if "sw_scan_kernel" in name:
+            if "sw_scan_kernel" in name or "sw_stream_kernel" in name:
                 a = acc[name]
                 a[0] += 1
                 a[1] += value
@@ -75,4 +75,4 @@ if __name__ == "__main__":
     elif mode == "traffic":
         traffic(sys.argv[2], sys.argv[3])
     else:
-        pmc(path, sys.argv[3] if len(sys.argv) > 3 else "sw_scan_kernel")
+        pmc(path, sys.argv[3] if len(sys.argv) > 3 else "swk::sw_s")
