@@ -82,6 +82,7 @@ struct Profile {
     size_t capacity = 0;
     bool valid = false;
     QueryPlan plan;
+    int shift = 0;               // added to every substitution score (a = -gex for the column-offset kernels, else 0)
     hipEvent_t ready = nullptr;  // recorded after the build; scans on other streams wait on it
 };
 
@@ -103,7 +104,8 @@ struct sw_ctx {
     size_t query_capacity = 0;
     int32_t qlen = 0;
     bool have_query = false;
-    Profile profiles[4][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups]
+    Profile profiles[4][2][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups][plain | column-offset recurrence]
+    bool use_offs = true;        // CUDASW4_AMD_NO_OFFS=1: always the plain recurrence (A/B measurements)
 };
 
 namespace {
@@ -124,8 +126,9 @@ int lanes_for_partition(const sw_ctx* ctx, int part_id, int32_t n) {
 }
 
 
-int ensure_profile(sw_ctx* ctx, int kind, int lanes, hipStream_t stream) {
-    Profile& pr = ctx->profiles[kind][lanes == 64];
+int ensure_profile(sw_ctx* ctx, int kind, int lanes, bool offs, int shift, hipStream_t stream) {
+    Profile& pr = ctx->profiles[kind][lanes == 64][offs];
+    if (pr.valid && pr.shift != shift) pr.valid = false;  // other gap-extension score than last time
     if (pr.valid) {
         // built on another stream earlier in this query: order this stream after the build
         SW_HIP(hipStreamWaitEvent(stream, pr.ready, 0));
@@ -145,7 +148,8 @@ int ensure_profile(sw_ctx* ctx, int kind, int lanes, hipStream_t stream) {
         SW_HIP(hipMalloc(&pr.dev, cap));
         pr.capacity = cap;
     }
-    SW_HIP(kl->profile(pl.rows, lanes, ctx->d_query, ctx->qlen, ctx->d_matrix, pl.nstripes, pr.dev, stream));
+    SW_HIP(kl->profile(pl.rows, lanes, ctx->d_query, ctx->qlen, ctx->d_matrix, pl.nstripes, pr.dev, shift, stream));
+    pr.shift = shift;
     if (!pr.ready) SW_HIP(hipEventCreateWithFlags(&pr.ready, hipEventDisableTiming));
     SW_HIP(hipEventRecord(pr.ready, stream));
     pr.plan = pl;
@@ -180,9 +184,16 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     if (!chars || !offsets || !lengths || !scores || !ids) return fail(SW_ERR_INVALID, "null buffer");
     if (ovf_check && kind_packed(kind) && (!ovf_pos || !ovf_count)) return fail(SW_ERR_INVALID, "overflow check without overflow buffers");
     SW_HIP(hipSetDevice(ctx->device));
-    int rc = ensure_profile(ctx, kind, lanes, stream);
+    // Column-offset recurrence (7.5 instead of 8.5 instructions per cell pair): values grow by a = -gex per column,
+    // so it is used while a * columns stays in the lower half of the kind's exact range (a subject whose bound
+    // score + a * columns reaches the limit is flagged and re-scored like an overflow)
+    const int a = -gex;
+    const int64_t growth = (int64_t)a * ((int64_t)max_subject_len + 3 * lanes + 8);
+    const int64_t room = kind == SW_KIND_F16X2 ? 1024 : kind == SW_KIND_I16X2 ? 12500 : (int64_t)1 << 22;
+    const bool offs = ctx->use_offs && growth <= room && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
+    int rc = ensure_profile(ctx, kind, lanes, offs, offs ? a : 0, stream);
     if (rc != SW_OK) return rc;
-    const Profile& prof = ctx->profiles[kind][lanes == 64];
+    const Profile& prof = ctx->profiles[kind][lanes == 64][offs];
     const QueryPlan pl = prof.plan;
     const bool multi = pl.nstripes > 1;
 
@@ -200,6 +211,16 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
         case SW_KIND_I16X2: p.gop = swk::Arith<swk::I16X2>::encode_gap(gop); p.gex = swk::Arith<swk::I16X2>::encode_gap(gex); break;
         case SW_KIND_I32: p.gop = swk::Arith<swk::I32>::encode_gap(gop); p.gex = swk::Arith<swk::I32>::encode_gap(gex); break;
         default: p.gop = swk::Arith<swk::F32>::encode_gap(gop); p.gex = swk::Arith<swk::F32>::encode_gap(gex); break;
+    }
+    if (offs) {  // gop slot: gop + a
+        const int g = gop - gex;
+        switch (kind) {
+            case SW_KIND_F16X2: p.gop = swk::Arith<swk::F16X2>::encode_gap(g); break;
+            case SW_KIND_I16X2: p.gop = swk::Arith<swk::I16X2>::encode_gap(g); break;
+            case SW_KIND_I32: p.gop = swk::Arith<swk::I32>::encode_gap(g); break;
+            default: p.gop = swk::Arith<swk::F32>::encode_gap(g); break;
+        }
+        p.gex_mag = a;
     }
     p.scores = scores; p.ids = ids; p.id_offset = id_offset;
     p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;
@@ -219,7 +240,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     const bool ldsf = multi && lanes == 16 && kl->packed && p.lcap <= swk::kLdsFCols;
     // single-stripe queries over 16-lane groups: the subjects of a wave follow each other without draining the
     // pipeline (sw_stream_kernel.hpp); the re-score path (position list, device-side count) keeps the plain kernel
-    if (!multi && lanes == 16 && !positions && !count_ptr && ctx->use_stream) {
+    if (!multi && lanes == 16 && !positions && !count_ptr && ctx->use_stream && !offs) {
 #ifdef SWK_TRACE  // diagnostic builds only: dump the per-wave timeline of this launch (tools/trace_stats.py)
         static uint32_t* trace = nullptr;
         if (!trace) SW_HIP(hipMalloc(&trace, 1 << 20));
@@ -235,7 +256,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
         SW_HIP(kl->stream(pl.rows, grid, stream, p));
         return SW_OK;
     }
-    SW_HIP(kl->scan(pl.rows, lanes, multi, ldsf, grid, stream, p));
+    SW_HIP(kl->scan(pl.rows, lanes, multi, ldsf, offs, grid, stream, p));
     return SW_OK;
 }
 
@@ -267,6 +288,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     ctx->num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("CUDASW4_AMD_NO_STREAM")) ctx->use_stream = !(e[0] == '1');
     if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
+    if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
     hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
@@ -288,10 +310,11 @@ int sw_ctx_destroy(sw_ctx* ctx) {
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_query) (void)hipFree(ctx->d_query);
     for (auto& row : ctx->profiles)
-        for (auto& pr : row) {
-            if (pr.dev) (void)hipFree(pr.dev);
-            if (pr.ready) (void)hipEventDestroy(pr.ready);
-        }
+        for (auto& shape : row)
+            for (auto& pr : shape) {
+                if (pr.dev) (void)hipFree(pr.dev);
+                if (pr.ready) (void)hipEventDestroy(pr.ready);
+            }
     delete ctx;
     return SW_OK;
 }
@@ -306,7 +329,8 @@ int sw_set_matrix(sw_ctx* ctx, const int8_t* matrix_host, int dim) {
     SW_HIP(hipMemcpy(ctx->d_matrix, matrix_host, dim * dim, hipMemcpyHostToDevice));
     ctx->have_matrix = true;
     for (auto& row : ctx->profiles)
-        for (auto& pr : row) pr.valid = false;
+        for (auto& shape : row)
+            for (auto& pr : shape) pr.valid = false;
     return SW_OK;
 }
 
@@ -331,7 +355,8 @@ int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void
     ctx->qlen = qlen;
     ctx->have_query = true;
     for (auto& row : ctx->profiles)
-        for (auto& pr : row) pr.valid = false;
+        for (auto& shape : row)
+            for (auto& pr : shape) pr.valid = false;
     return SW_OK;
 }
 

@@ -113,6 +113,15 @@ struct Arith<I16X2> {
     static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return max3(m, a, b); }
     static __device__ __forceinline__ int score_lo(u32 v) { return (int)(v & 0xffffu) - kBias; }
     static __device__ __forceinline__ int score_hi(u32 v) { return (int)(v >> 16) - kBias; }
+    // column-offset recurrence (dp_step<OFFS>): the zero level of column offset k, +a, star -> true values
+    static __host__ __device__ u32 zero_at(int a, int k) { u32 z = (u32)(kBias + a * k) & 0xffffu; return z | (z << 16); }
+    static __host__ __device__ u32 pos_word(int a) { u32 m = (u32)a & 0xffffu; return m | (m << 16); }
+    static __device__ __forceinline__ u32 true_of(u32 m, u32 z) { return gap(m, z); }  // plain unsigned integers
+    static __device__ __forceinline__ u32 true_max(u32 a, u32 b) {
+        return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+    }
+    static __device__ __forceinline__ int true_lo(u32 v) { return (int)(v & 0xffffu); }
+    static __device__ __forceinline__ int true_hi(u32 v) { return (int)(v >> 16); }
 };
 
 template <>
@@ -150,6 +159,14 @@ struct Arith<F16X2> {
     static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return max3(m, a, b); }  // one v_pk_maximum3_f16 per two rows
     static __device__ __forceinline__ int score_lo(u32 v) { return (int)(float)__builtin_bit_cast(f16x2, v).x; }
     static __device__ __forceinline__ int score_hi(u32 v) { return (int)(float)__builtin_bit_cast(f16x2, v).y; }
+    static __host__ __device__ u32 zero_at(int a, int k) { u32 h = half_bits(a * k); return h | (h << 16); }
+    static __host__ __device__ u32 pos_word(int a) { u32 h = half_bits(a); return h | (h << 16); }
+    static __device__ __forceinline__ u32 true_of(u32 m, u32 z) {
+        return __builtin_bit_cast(u32, (f16x2)(__builtin_bit_cast(f16x2, m) - __builtin_bit_cast(f16x2, z)));
+    }
+    static __device__ __forceinline__ u32 true_max(u32 a, u32 b) { return max2(a, b); }
+    static __device__ __forceinline__ int true_lo(u32 v) { return score_lo(v); }
+    static __device__ __forceinline__ int true_hi(u32 v) { return score_hi(v); }
 };
 
 template <>
@@ -180,6 +197,12 @@ struct Arith<I32> {
     static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return max3(m, a, b); }
     static __device__ __forceinline__ int score_lo(u32 v) { return (int)v; }
     static __device__ __forceinline__ int score_hi(u32) { return 0; }
+    static __host__ __device__ u32 zero_at(int a, int k) { return (u32)(a * k); }
+    static __host__ __device__ u32 pos_word(int a) { return (u32)a; }
+    static __device__ __forceinline__ u32 true_of(u32 m, u32 z) { return m - z; }
+    static __device__ __forceinline__ u32 true_max(u32 a, u32 b) { return max2(a, b); }
+    static __device__ __forceinline__ int true_lo(u32 v) { return (int)v; }
+    static __device__ __forceinline__ int true_hi(u32) { return 0; }
 };
 
 template <>
@@ -194,12 +217,19 @@ struct Arith<F32> {
     static __device__ __forceinline__ u32 u(float v) { return __builtin_bit_cast(u32, v); }
     static __device__ __forceinline__ u32 add(u32 a, u32 b) { return u(f(a) + f(b)); }
     static __device__ __forceinline__ u32 max2(u32 a, u32 b) { return u(__builtin_fmaxf(f(a), f(b))); }
+    static __device__ __forceinline__ u32 max3(u32 a, u32 b, u32 c) { return u(__builtin_fmaxf(__builtin_fmaxf(f(a), f(b)), f(c))); }
     static __device__ __forceinline__ u32 cell_h(u32 t, u32 e, u32 ff) { return u(__builtin_fmaxf(__builtin_fmaxf(f(t), f(e)), f(ff))); }
     static __device__ __forceinline__ u32 gap(u32 a, u32 g) { return u(f(a) + f(g)); }
     static __device__ __forceinline__ u32 gap_state(u32 ext, u32 open) { return u(__builtin_fmaxf(__builtin_fmaxf(f(ext), f(open)), 0.0f)); }
     static __device__ __forceinline__ u32 fold2(u32 m, u32 a, u32 b) { return u(__builtin_fmaxf(__builtin_fmaxf(f(m), f(a)), f(b))); }  // v_max3_f32
     static __device__ __forceinline__ int score_lo(u32 v) { return (int)f(v); }
     static __device__ __forceinline__ int score_hi(u32) { return 0; }
+    static __host__ __device__ u32 zero_at(int a, int k) { return __builtin_bit_cast(u32, (float)(a * k)); }
+    static __host__ __device__ u32 pos_word(int a) { return __builtin_bit_cast(u32, (float)a); }
+    static __device__ __forceinline__ u32 true_of(u32 m, u32 z) { return u(f(m) - f(z)); }
+    static __device__ __forceinline__ u32 true_max(u32 a, u32 b) { return max2(a, b); }
+    static __device__ __forceinline__ int true_lo(u32 v) { return (int)f(v); }
+    static __device__ __forceinline__ int true_hi(u32) { return 0; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -246,6 +276,7 @@ struct ScanParams {
     int32_t lcap;
     const u32* zeros;          // >= 64 bytes of the kind's zero pattern (border of the first stripe)
     u32* work_counter;         // zeroed before the launch: next batch to hand out
+    int32_t gex_mag;           // OFFS kernels: a = -gex; then gop holds encode_gap(gop - gex) and the profile s + a
 };
 
 template <int NW, int CHUNK_ROW_BYTES>
@@ -278,15 +309,27 @@ struct StripeState {
     u32 Fout;      // vertical gap state leaving the lane's bottom row after the last step
     u32 yA, yB;    // LDS byte address (+16 bias) of the lane's chunk for the current letter(s)
     u32 maxv;
+    u32 Z;         // OFFS: zero level (in the column-offset frame) of the column this lane enters next
 };
 
 // One anti-diagonal step of one lane: R cells (or R cell pairs).
 //   BYTE    which byte of the letter words feeds lane 0 in this step
 //   MULTI   stripe borders in play: lane 0 takes (inH, inF) — the previous stripe's bottom row at this
 //           column — instead of the zero boundary; the caller stores lane 15's (Hlast, Fout) afterwards
-template <int KIND, int R, int LANES, int BYTE, bool MULTI>
+//
+// OFFS — the column-offset form of the recurrence.  With a = -gex all values of column j are kept as
+// X* = X + a*c_j (c_j = j + LANES).  Then E*(i,j+1) = max3(E*(i,j), H* + (gop + a), Z_{j+1}) needs no addition of
+// its own (E decays by a per column, the frame rises by a per column), F*(i+1,j) = max3(F*, H* + (gop + a), Z_{j+1}) - a,
+// the diagonal term is H*(i-1,j-1) + (s + a) with the +a folded into the profile, and Z_j = a*c_j is the zero level
+// of the column: 7.5 instead of 8.5 instructions per cell pair (6.5 instead of 7.5 per cell).  Price: one register
+// (Z) and four instructions per step (Z += a; the step's maximum converted back to a true score), and magnitudes
+// that grow with the column index: the launcher picks OFFS only while a * columns stays well inside the exact range
+// of the kind, and a subject whose bound maxscore + a * columns reaches the limit is flagged like an overflow.
+// `first` (MULTI): the stripe has no predecessor, lane 0's boundary is the zero level instead of the border row.
+template <int KIND, int R, int LANES, int BYTE, bool MULTI, bool OFFS = false>
 __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned char* tile,
-                                        u32 lettersA, u32 lettersB, u32 gop, u32 gex, u32 inH, u32 inF) {
+                                        u32 lettersA, u32 lettersB, u32 gop, u32 gex, u32 inH, u32 inF,
+                                        u32 apos = 0, bool first = false) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
     constexpr int SHR1 = Shift<LANES>::kShr1;
@@ -303,6 +346,42 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
         const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel) << kPostShift;
         st.yB = dpp<SHR1, false>(injB, st.yB) + 16u;
         lds_read_words<G::NW, G::kChunkRowBytes>(wb, tile + st.yB);
+    }
+
+    if constexpr (OFFS) {
+        const u32 Zj = st.Z;
+        const u32 Zn = A::add(Zj, apos);
+        st.Z = Zn;
+        u32 upH, F;
+        if constexpr (MULTI) {
+            upH = dpp<SHR1, false>(first ? Zj : inH, st.Hlast);
+            F = dpp<SHR1, false>(first ? Zj : inF, st.Fout);
+        } else {
+            upH = dpp<SHR1, false>(Zj, st.Hlast);
+            F = dpp<SHR1, false>(Zj, st.Fout);
+        }
+        u32 diag = st.upH_prev;
+        st.upH_prev = upH;
+        u32 m = Zj;  // maximum of this step's cells, in the column's frame
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            u32 s;
+            if constexpr (A::kPacked) s = __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+            else s = wa[r];
+            const u32 t = A::add(diag, s);
+            diag = st.H[r];
+            const u32 h = A::cell_h(t, st.E[r], F);
+            const u32 hg = A::gap(h, gop);  // gop + a
+            st.E[r] = A::max3(st.E[r], hg, Zn);
+            F = A::gap(A::max3(F, hg, Zn), gex);
+            st.H[r] = h;
+            if (r & 1) m = A::fold2(m, st.H[r - 1], h);
+            else if (r == R - 1) m = A::max2(m, h);
+        }
+        st.maxv = A::true_max(st.maxv, A::true_of(m, Zj));
+        st.Hlast = st.H[R - 1];
+        st.Fout = F;
+        return;
     }
 
     // row above the lane's first row: from the neighbouring lane, or from the stripe border
@@ -400,7 +479,7 @@ constexpr int kLdsFJunk = 96;    // junk words in front of each group's columns 
                                  // stride 672 = 21 * 32 words keeps the bank pattern identical for every group
 constexpr int kLdsFStride = kLdsFCols + kLdsFJunk;
 
-template <int KIND, int R, int LANES, bool MULTI, bool LDSF = false>
+template <int KIND, int R, int LANES, bool MULTI, bool LDSF = false, bool OFFS = false>
 __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())) sw_scan_kernel(const ScanParams p) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
@@ -438,6 +517,11 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         zerosF = &ldsF[kGroups * kLdsFStride];
         if (tid < 16) ldsF[kGroups * kLdsFStride + tid] = A::kZero;  // published by the stripe loop's barriers
     }
+
+    // OFFS: a lane starts every stripe "at column -lane": zero level a*(LANES - lane), +a per step
+    const u32 apos = OFFS ? A::pos_word(p.gex_mag) : 0u;
+    const u32 zstart = OFFS ? A::zero_at(p.gex_mag, LANES - lane) : A::kZero;
+    const u32 zbefore = OFFS ? A::zero_at(p.gex_mag, LANES - lane - 1) : A::kZero;  // the column before
 
     __shared__ int next_batch;
     for (;;) {
@@ -477,7 +561,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         if constexpr (MULTI) nquads = min(nquads, (p.lcap - 4) >> 2);
         const int len0pad = (len0 + 3) & ~3, len1pad = (len1 + 3) & ~3;
 
-        u32 maxv = A::kZero;
+        u32 maxv = OFFS ? 0u : A::kZero;  // OFFS tracks true scores (unbiased), the plain form the kind's own zero
         for (int stripe = 0; stripe < p.nstripes; stripe++) {
             const bool first = stripe == 0;
             if constexpr (MULTI) {
@@ -487,8 +571,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             }
             StripeState<KIND, R> st;
 #pragma unroll
-            for (int r = 0; r < R; r++) { st.H[r] = A::kZero; st.E[r] = A::kZero; }
-            st.upH_prev = A::kZero; st.Hlast = A::kZero; st.Fout = A::kZero; st.maxv = maxv;
+            for (int r = 0; r < R; r++) { st.H[r] = zbefore; st.E[r] = zstart; }
+            st.upH_prev = zbefore; st.Hlast = zbefore; st.Fout = zbefore; st.maxv = maxv; st.Z = zstart;
             st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
             st.yB = st.yA;
 
@@ -534,13 +618,13 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     nextH = *reinterpret_cast<const uint4*>(inH);
                     nextF = *reinterpret_cast<const uint4*>(inF);
                 }
-                dp_step<KIND, R, LANES, 0, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x);
+                dp_step<KIND, R, LANES, 0, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first);
                 if constexpr (MULTI) { outH[0] = st.Hlast; outF[0] = st.Fout; }
-                dp_step<KIND, R, LANES, 1, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y);
+                dp_step<KIND, R, LANES, 1, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first);
                 if constexpr (MULTI) { outH[1] = st.Hlast; outF[1] = st.Fout; }
-                dp_step<KIND, R, LANES, 2, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z);
+                dp_step<KIND, R, LANES, 2, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first);
                 if constexpr (MULTI) { outH[2] = st.Hlast; outF[2] = st.Fout; }
-                dp_step<KIND, R, LANES, 3, MULTI>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w);
+                dp_step<KIND, R, LANES, 3, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first);
                 if constexpr (MULTI) { outH[3] = st.Hlast; outF[3] = st.Fout; outH += walkOut; outF += walkOut; }
                 lettersA = dpp<SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
@@ -556,12 +640,29 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             if constexpr (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
 
-        maxv = group_max<KIND, LANES>(maxv);
+        int sc0, sc1, guard = 0;
+        if constexpr (OFFS) {
+            // group maximum of true scores
+            maxv = A::true_max(maxv, dpp<0x128, false>(maxv, maxv));
+            maxv = A::true_max(maxv, dpp<0x124, false>(maxv, maxv));
+            maxv = A::true_max(maxv, dpp<0x122, false>(maxv, maxv));
+            maxv = A::true_max(maxv, dpp<0x121, false>(maxv, maxv));
+            if constexpr (LANES == 64) {
+                maxv = A::true_max(maxv, (u32)__shfl_xor((int)maxv, 16));
+                maxv = A::true_max(maxv, (u32)__shfl_xor((int)maxv, 32));
+            }
+            sc0 = A::true_lo(maxv);
+            sc1 = A::true_hi(maxv);
+            // no value of the alignment exceeded score + a * (columns + LANES): inside the exact range below the limit
+            guard = p.gex_mag * (4 * nquads + 2 * LANES);
+        } else {
+            maxv = group_max<KIND, LANES>(maxv);
+            sc0 = A::score_lo(maxv);
+            sc1 = A::score_hi(maxv);
+        }
         if (lane == 0) {
-            const int sc0 = A::score_lo(maxv);
-            const int sc1 = A::score_hi(maxv);
             if (valid0) {
-                if (A::kPacked && p.ovf_check && sc0 >= A::kLimit) {
+                if (A::kPacked && p.ovf_check && sc0 >= A::kLimit - guard) {
                     p.ovf_pos[atomicAdd(p.ovf_count, 1)] = pos0;
                 } else {
                     p.scores[pos0] = (float)sc0;
@@ -569,7 +670,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 p.ids[pos0] = (int32_t)(p.id_offset + pos0);
             }
             if (valid1) {
-                if (p.ovf_check && sc1 >= A::kLimit) {
+                if (p.ovf_check && sc1 >= A::kLimit - guard) {
                     p.ovf_pos[atomicAdd(p.ovf_count, 1)] = pos1;
                 } else {
                     p.scores[pos1] = (float)sc1;
@@ -587,7 +688,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 template <int KIND, int R, int LANES>
 __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_t qlen,
                                         const int8_t* __restrict__ matrix21, int32_t nstripes,
-                                        unsigned char* __restrict__ profile) {
+                                        unsigned char* __restrict__ profile, int32_t shift) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
     constexpr int kWordsPerRow = G::kRowBytes / 4;
@@ -606,7 +707,7 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
                 if (row_in_lane >= R) return 0u;  // unused upper half of an odd R's last word
                 const int64_t row = (int64_t)stripe * G::kStripeRows + lane * R + row_in_lane;
                 const int qc = row < qlen ? (int)query[row] : kPadLetter;
-                return A::encode_score((int)matrix21[qc * kLetters + letter]);
+                return A::encode_score((int)matrix21[qc * kLetters + letter] + shift);  // shift = a for the OFFS kernels
             };
             if constexpr (A::kPacked) v = entry(2 * w) | (entry(2 * w + 1) << 16);
             else v = entry(w);

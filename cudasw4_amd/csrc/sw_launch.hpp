@@ -26,11 +26,12 @@ constexpr int max_rows(bool packed, int lanes) {
 
 struct KindLaunch {
     // return hipSuccess or the launch error; (R, lanes) must be a compiled combination, else hipErrorInvalidValue
-    hipError_t (*scan)(int R, int lanes, bool multi, bool ldsf, int grid, hipStream_t stream, const ScanParams& p);
+    // offs: the column-offset form of the recurrence (sw_dp_kernel.hpp: dp_step<OFFS>); needs a profile built with shift = a
+    hipError_t (*scan)(int R, int lanes, bool multi, bool ldsf, bool offs, int grid, hipStream_t stream, const ScanParams& p);
     // single-stripe scan of 16-lane groups as a continuous stream of subjects (sw_stream_kernel.hpp)
     hipError_t (*stream)(int R, int grid, hipStream_t stream, const ScanParams& p);
     hipError_t (*profile)(int R, int lanes, const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t nstripes,
-                          unsigned char* out, hipStream_t stream);
+                          unsigned char* out, int32_t shift, hipStream_t stream);
     size_t (*tile_bytes)(int R, int lanes);
     bool packed;
 };
@@ -47,8 +48,8 @@ const KindLaunch& launch_i32();
 const KindLaunch& launch_f32();
 
 // ---- helpers used by the kind TUs ----
-template <int KIND, int R, int LANES>
-hipError_t launch_scan_r(bool multi, bool ldsf, int grid, hipStream_t stream, const ScanParams& p) {
+template <int KIND, int R, int LANES, bool OFFS>
+hipError_t launch_scan_ro(bool multi, bool ldsf, int grid, hipStream_t stream, const ScanParams& p) {
     // a query that needs more than one stripe always gets R > max/2 from the planner
     constexpr int kMaxR = max_rows(Arith<KIND>::kPacked, LANES);
     if constexpr (R > kMaxR) {
@@ -58,31 +59,37 @@ hipError_t launch_scan_r(bool multi, bool ldsf, int grid, hipStream_t stream, co
             if constexpr (2 * R > kMaxR) {
                 if constexpr (Arith<KIND>::kPacked && LANES == 16) {
                     if (ldsf) {
-                        hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, true>), dim3(grid), dim3(kThreads), 0, stream, p);
+                        hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, true, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
                         return hipGetLastError();
                     }
                 }
-                hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true>), dim3(grid), dim3(kThreads), 0, stream, p);
+                hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, false, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
             } else {
                 return hipErrorInvalidValue;
             }
         } else {
-            hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, false>), dim3(grid), dim3(kThreads), 0, stream, p);
+            hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, false, false, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
         }
         return hipGetLastError();
     }
 }
 
 template <int KIND, int R, int LANES>
+hipError_t launch_scan_r(bool multi, bool ldsf, bool offs, int grid, hipStream_t stream, const ScanParams& p) {
+    return offs ? launch_scan_ro<KIND, R, LANES, true>(multi, ldsf, grid, stream, p)
+                : launch_scan_ro<KIND, R, LANES, false>(multi, ldsf, grid, stream, p);
+}
+
+template <int KIND, int R, int LANES>
 hipError_t launch_profile_r(const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t nstripes,
-                            unsigned char* out, hipStream_t stream) {
+                            unsigned char* out, int32_t shift, hipStream_t stream) {
     if constexpr (R > max_rows(Arith<KIND>::kPacked, LANES)) {
         return hipErrorInvalidValue;
     } else {
         const size_t total = (size_t)nstripes * kLetters * (Geometry<KIND, R, LANES>::kRowBytes / 4);
         const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);  // grid-stride loop covers the rest
         hipLaunchKernelGGL((sw_build_profile_kernel<KIND, R, LANES>), dim3(grid), dim3(256), 0, stream, query, qlen,
-                           matrix21, nstripes, out);
+                           matrix21, nstripes, out, shift);
         return hipGetLastError();
     }
 }
@@ -99,14 +106,14 @@ constexpr size_t tile_bytes_r() {
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
 #define SWK_DEFINE_KIND(FN, STREAMFN, KIND, FOR_EACH_R)                                                                      \
-    static hipError_t FN##_scan(int R, int lanes, bool multi, bool ldsf, int grid, hipStream_t stream,            \
+    static hipError_t FN##_scan(int R, int lanes, bool multi, bool ldsf, bool offs, int grid, hipStream_t stream, \
                                 const ScanParams& p) {                                                              \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN64_##KIND) } }                                 \
         return hipErrorInvalidValue;                                                                                \
     }                                                                                                               \
     static hipError_t FN##_profile(int R, int lanes, const int8_t* q, int32_t qlen, const int8_t* m, int32_t ns,    \
-                                   unsigned char* out, hipStream_t s) {                                             \
+                                   unsigned char* out, int32_t shift, hipStream_t s) {                              \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_PROF16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_PROF64_##KIND) } }                                 \
         return hipErrorInvalidValue;                                                                                \

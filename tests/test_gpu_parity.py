@@ -11,6 +11,18 @@ from gpu_util import gpu_modules, scan_all_scores, kinds_configs
 pytestmark = pytest.mark.gpu
 
 
+def check_overflow_count(num_overflows, expect, lengths, limit):
+    """Every subject whose score reaches the limit of the packed kind must have been re-scored.  The column-offset
+    kernels keep all values of column j raised by a*(j + lanes) and flag a subject already when the bound
+    score + a*(columns of its wave + 2*lanes) reaches the limit; the launcher uses them only while a*columns stays
+    within half the range (1024 of 2048, 12500 of 25000), so nothing scoring below limit - range/2 is ever flagged."""
+    expect = np.asarray(expect)
+    room = {2048: 1024, 25000: 12500}[limit]
+    lo = int((expect >= limit).sum())
+    hi = int((expect >= limit - room).sum())
+    assert lo <= num_overflows <= hi, (num_overflows, lo, hi)
+
+
 def test_library_sees_gpu():
     torch, capi, search = gpu_modules()
     assert capi.device_count() >= 1
@@ -42,13 +54,14 @@ def test_allvsall_matches_reference_dp(cfg, merge):
     db = O.make_db(qs)
     kt = kinds_configs(search, capi)[cfg]
     expect = np.array(g["allvsall"], dtype=np.int32)
+    lens = np.array([len(x) for x in qs])
     for i, q in enumerate(qs):
         got, res, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, merge=merge)
         assert got.tolist() == expect[i].tolist(), (cfg, i)
         if cfg == "half2+float":
-            assert res.num_overflows == int((expect[i] >= 2048).sum())
+            check_overflow_count(res.num_overflows, expect[i], lens, 2048)
         if cfg == "dpxs16+dpxs32":
-            assert res.num_overflows == int((expect[i] >= 25000).sum())
+            check_overflow_count(res.num_overflows, expect[i], lens, 25000)
 
 
 @pytest.mark.parametrize("cfg", ["half2+float", "dpxs16+dpxs32", "dpxs32", "float"])
@@ -405,6 +418,6 @@ def test_randomized_stress_many_scans():
         assert res.scores.tolist() == es.tolist() and res.reference_ids.tolist() == ei.tolist(), (name, it)
         packed = lengths <= 8000  # partition 35 (> 8000) is scored by a 32-bit kind in these configurations
         if name == "half2+float":
-            assert res.num_overflows == int(((expect >= 2048) & packed).sum())
+            check_overflow_count(res.num_overflows, expect[packed], lengths[packed], 2048)
         if name == "dpxs16+dpxs32":
-            assert res.num_overflows == int(((expect >= 25000) & packed).sum())
+            check_overflow_count(res.num_overflows, expect[packed], lengths[packed], 25000)
