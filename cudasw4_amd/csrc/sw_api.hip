@@ -185,11 +185,12 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     if (ovf_check && kind_packed(kind) && (!ovf_pos || !ovf_count)) return fail(SW_ERR_INVALID, "overflow check without overflow buffers");
     SW_HIP(hipSetDevice(ctx->device));
     // Column-offset recurrence (7.5 instead of 8.5 instructions per cell pair): values grow by a = -gex per column,
-    // so it is used while a * columns stays in the lower half of the kind's exact range (a subject whose bound
-    // score + a * columns reaches the limit is flagged and re-scored like an overflow)
+    // so it is used while a * columns leaves room below the kind's limit (fp16: 3/4 of the exact range — every
+    // single-pass partition with the default gap scores; int16: half).  A subject whose bound score + a * columns
+    // reaches the limit is flagged and re-scored like an overflow.
     const int a = -gex;
     const int64_t growth = (int64_t)a * ((int64_t)max_subject_len + 3 * lanes + 8);
-    const int64_t room = kind == SW_KIND_F16X2 ? 1024 : kind == SW_KIND_I16X2 ? 12500 : (int64_t)1 << 22;
+    const int64_t room = kind == SW_KIND_F16X2 ? 1536 : kind == SW_KIND_I16X2 ? 12500 : (int64_t)1 << 22;
     const bool offs = ctx->use_offs && growth <= room && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
     int rc = ensure_profile(ctx, kind, lanes, offs, offs ? a : 0, stream);
     if (rc != SW_OK) return rc;
