@@ -322,7 +322,7 @@ struct StripeState {
 // its own (E decays by a per column, the frame rises by a per column), F*(i+1,j) = max3(F*, H* + (gop + a), Z_{j+1}) - a,
 // the diagonal term is H*(i-1,j-1) + (s + a) with the +a folded into the profile, and Z_j = a*c_j is the zero level
 // of the column: 7.5 instead of 8.5 instructions per cell pair (6.5 instead of 7.5 per cell).  Price: one register
-// (Z) and four instructions per step (Z += a; the step's maximum converted back to a true score), and magnitudes
+// (Z) and two instructions per step (Z += a; running maximum += a), and magnitudes
 // that grow with the column index: the launcher picks OFFS only while a * columns stays well inside the exact range
 // of the kind, and a subject whose bound maxscore + a * columns reaches the limit is flagged like an overflow.
 // `first` (MULTI): the stripe has no predecessor, lane 0's boundary is the zero level instead of the border row.
@@ -362,23 +362,36 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
         }
         u32 diag = st.upH_prev;
         st.upH_prev = upH;
-        u32 m = Zj;  // maximum of this step's cells, in the column's frame
+        // the running maximum travels in the moving frame: raised by a per step like everything else, so the rows'
+        // maxima fold straight into it (it is converted back to a true score once per stripe)
+        u32 m = A::add(st.maxv, apos);
+        // The rows are software-pipelined by hand: the chain h -> h+G -> max3 -> -a -> next row's h is serial, and on
+        // gfx950 a packed op that reads the result of the instruction right before it costs a wait state, so the
+        // independent work (score lookup and diagonal term of the rows ahead, the E update, the maximum) is
+        // written in between the links of the chain.
+        auto score = [&](int r) -> u32 {
+            if constexpr (A::kPacked) return __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+            else return wa[r];
+        };
+        u32 s_next = score(0);
+        u32 t_next = A::add(diag, s_next);
+        s_next = R > 1 ? score(1) : 0u;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            u32 s;
-            if constexpr (A::kPacked) s = __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
-            else s = wa[r];
-            const u32 t = A::add(diag, s);
-            diag = st.H[r];
+            const u32 t = t_next;
             const u32 h = A::cell_h(t, st.E[r], F);
+            const u32 s1 = s_next;
+            if (r + 2 < R) s_next = score(r + 2);
             const u32 hg = A::gap(h, gop);  // gop + a
+            if (r + 1 < R) t_next = A::add(st.H[r], s1);  // the row's old H is the next row's diagonal
+            const u32 fm = A::max3(F, hg, Zn);
             st.E[r] = A::max3(st.E[r], hg, Zn);
-            F = A::gap(A::max3(F, hg, Zn), gex);
-            st.H[r] = h;
+            F = A::gap(fm, gex);
             if (r & 1) m = A::fold2(m, st.H[r - 1], h);
             else if (r == R - 1) m = A::max2(m, h);
+            st.H[r] = h;
         }
-        st.maxv = A::true_max(st.maxv, A::true_of(m, Zj));
+        st.maxv = m;
         st.Hlast = st.H[R - 1];
         st.Fout = F;
         return;
@@ -466,7 +479,7 @@ constexpr int border_junk_words() { return LANES == 16 ? 128 : 320; }  // >= 4*(
 #endif
 template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
-    if (Arith<KIND>::kPacked) return 1;
+    if (Arith<KIND>::kPacked) return 2;  // 256 VGPRs: what the tallest multi-stripe kernels need; 3 would spill them
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
     // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
     return (R <= 16 && !MULTI && LANES == 16) ? 4 : 3;
@@ -572,7 +585,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             StripeState<KIND, R> st;
 #pragma unroll
             for (int r = 0; r < R; r++) { st.H[r] = zbefore; st.E[r] = zstart; }
-            st.upH_prev = zbefore; st.Hlast = zbefore; st.Fout = zbefore; st.maxv = maxv; st.Z = zstart;
+            st.upH_prev = zbefore; st.Hlast = zbefore; st.Fout = zbefore; st.Z = zstart;
+            st.maxv = OFFS ? A::add(maxv, zbefore) : maxv;  // OFFS: true score -> frame of the column before the first
             st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
             st.yB = st.yA;
 
@@ -636,7 +650,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     borderF[4 * nquads - (LANES - 1) + lane] = A::kZero;
                 }
             }
-            maxv = st.maxv;
+            if constexpr (OFFS) maxv = A::true_of(st.maxv, A::gap(st.Z, p.gex));  // frame of the lane's last column -> true score
+            else maxv = st.maxv;
             if constexpr (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
 
