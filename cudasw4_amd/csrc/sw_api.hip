@@ -189,9 +189,12 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // single-pass partition with the default gap scores; int16: half).  A subject whose bound score + a * columns
     // reaches the limit is flagged and re-scored like an overflow.
     const int a = -gex;
-    const int64_t growth = (int64_t)a * ((int64_t)max_subject_len + 3 * lanes + 8);
     const int64_t room = kind == SW_KIND_F16X2 ? 1536 : kind == SW_KIND_I16X2 ? 12500 : (int64_t)1 << 22;
-    const bool offs = ctx->use_offs && growth <= room && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
+    // every K columns the frame is lowered by a*K (K a power of two, at least 4*lanes): the longest run of columns in
+    // one frame plus the pipeline skew must fit the room
+    int64_t K = 1 << 21;
+    while (K >= 4 * lanes && (int64_t)a * (K + 3 * lanes + 8) > room) K >>= 1;
+    const bool offs = ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
     int rc = ensure_profile(ctx, kind, lanes, offs, offs ? a : 0, stream);
     if (rc != SW_OK) return rc;
     const Profile& prof = ctx->profiles[kind][lanes == 64][offs];
@@ -222,6 +225,14 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
             default: p.gop = swk::Arith<swk::F32>::encode_gap(g); break;
         }
         p.gex_mag = a;
+        p.renorm_quads = (int32_t)(K / 4);
+        const int lower = -(int)((int64_t)a * K);
+        switch (kind) {
+            case SW_KIND_F16X2: p.renorm_word = swk::Arith<swk::F16X2>::encode_gap(lower); break;
+            case SW_KIND_I16X2: p.renorm_word = swk::Arith<swk::I16X2>::encode_gap(lower); break;
+            case SW_KIND_I32: p.renorm_word = swk::Arith<swk::I32>::encode_gap(lower); break;
+            default: p.renorm_word = swk::Arith<swk::F32>::encode_gap(lower); break;
+        }
     }
     p.scores = scores; p.ids = ids; p.id_offset = id_offset;
     p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;

@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace swk {
 
 typedef uint32_t u32;
@@ -277,6 +279,8 @@ struct ScanParams {
     const u32* zeros;          // >= 64 bytes of the kind's zero pattern (border of the first stripe)
     u32* work_counter;         // zeroed before the launch: next batch to hand out
     int32_t gex_mag;           // OFFS kernels: a = -gex; then gop holds encode_gap(gop - gex) and the profile s + a
+    int32_t renorm_quads;      // OFFS: K/4 — every K columns a lane lowers its frame by a*K (0: never); a power of two
+    u32 renorm_word;           // encode_gap(-a*K)
 };
 
 template <int NW, int CHUNK_ROW_BYTES>
@@ -533,6 +537,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 
     // OFFS: a lane starts every stripe "at column -lane": zero level a*(LANES - lane), +a per step
     const u32 apos = OFFS ? A::pos_word(p.gex_mag) : 0u;
+    const int rq = OFFS ? p.renorm_quads : 0;
     const u32 zstart = OFFS ? A::zero_at(p.gex_mag, LANES - lane) : A::kZero;
     const u32 zbefore = OFFS ? A::zero_at(p.gex_mag, LANES - lane - 1) : A::kZero;  // the column before
 
@@ -620,7 +625,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 nextF = *reinterpret_cast<const uint4*>(inF);
             }
 
-            for (int q = 0; q < nquads; q++) {
+            auto quad = [&](int q, auto lower_tag) {
+                constexpr bool LOWER = decltype(lower_tag)::value;
                 if ((q & (kQuadsPerLetterBlock - 1)) == 0) {
                     lettersA = nextA; lettersB = nextB;
                     nextA = fetch(s0, len0pad, q / kQuadsPerLetterBlock + 1);
@@ -632,16 +638,48 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     nextH = *reinterpret_cast<const uint4*>(inH);
                     nextF = *reinterpret_cast<const uint4*>(inF);
                 }
+                // OFFS on long subjects: the frame of column j is a*(j mod K + LANES), i.e. a lane lowers everything it
+                // holds by a*K right before it enters a column that is a multiple of K (lane l at step m*K + l).  The
+                // values it receives for that column come from a lane that has already done so, the ones it passed
+                // on last belong to the column before: the frame stays a function of the column alone, which is what
+                // keeps the stripe borders consistent.  16 of K steps pay 2R + 4 extra instructions.
+                const int lower_lane = 4 * (q & (rq - 1));
+                auto lower_frame = [&](int k) {
+                    const u32 gw = lane == k ? p.renorm_word : 0u;
+#pragma unroll
+                    for (int r = 0; r < R; r++) { st.H[r] = A::gap(st.H[r], gw); st.E[r] = A::gap(st.E[r], gw); }
+                    st.upH_prev = A::gap(st.upH_prev, gw); st.Z = A::gap(st.Z, gw); st.maxv = A::gap(st.maxv, gw);
+                };
+                if constexpr (LOWER) lower_frame(lower_lane + 0);
                 dp_step<KIND, R, LANES, 0, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first);
                 if constexpr (MULTI) { outH[0] = st.Hlast; outF[0] = st.Fout; }
+                if constexpr (LOWER) lower_frame(lower_lane + 1);
                 dp_step<KIND, R, LANES, 1, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first);
                 if constexpr (MULTI) { outH[1] = st.Hlast; outF[1] = st.Fout; }
+                if constexpr (LOWER) lower_frame(lower_lane + 2);
                 dp_step<KIND, R, LANES, 2, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first);
                 if constexpr (MULTI) { outH[2] = st.Hlast; outF[2] = st.Fout; }
+                if constexpr (LOWER) lower_frame(lower_lane + 3);
                 dp_step<KIND, R, LANES, 3, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first);
                 if constexpr (MULTI) { outH[3] = st.Hlast; outF[3] = st.Fout; outH += walkOut; outF += walkOut; }
                 lettersA = dpp<SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
+            };
+            // the quads in which lanes lower their frame (the first LANES/4 of every K/4 quads but the first) run a second
+            // copy of the loop body, so that the others pay nothing for it
+            {
+                const int seg = (OFFS && rq > 0) ? rq : nquads;
+                for (int q0 = 0; q0 < nquads; q0 += seg) {
+                    const int qend = min(nquads, q0 + seg);
+                    int q = q0;
+                    if constexpr (OFFS) {
+                        if (q0 > 0) {
+                            const int qlow = min(qend, q0 + LANES / 4);
+                            for (; q < qlow; q++) quad(q, std::true_type{});
+                        }
+                    }
+                    for (; q < qend; q++) quad(q, std::false_type{});
+                }
             }
             if constexpr (MULTI) {
                 // the last lane reached column 4*nquads-LANES; the next stripe reads up to 4*nquads-1: zero the rest
@@ -669,7 +707,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             sc0 = A::true_lo(maxv);
             sc1 = A::true_hi(maxv);
             // no value of the alignment exceeded score + a * (columns + LANES): inside the exact range below the limit
-            guard = p.gex_mag * (4 * nquads + 2 * LANES);
+            guard = p.gex_mag * ((rq > 0 && 4 * nquads > 4 * rq ? 4 * rq : 4 * nquads) + 2 * LANES + 4);
         } else {
             maxv = group_max<KIND, LANES>(maxv);
             sc0 = A::score_lo(maxv);
