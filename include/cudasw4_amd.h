@@ -102,7 +102,7 @@ size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t
  *                   untouched (half2_kernels.cuh:1087-1109).  Ignored for the 32-bit kinds.
  *                   The list may hold a few subjects more than strictly overflowed: the kernels keep
  *                   column j's values raised by |gex|*(j+16) and flag a subject as soon as the bound
- *                   score + |gex|*(columns+32) reaches the limit (never one scoring below limit-1536
+ *                   score + |gex|*(min(columns,K)+36) reaches the limit (never one scoring below limit-1536
  *                   for F16X2 / limit-12500 for I16X2).  Re-scoring them all keeps every score exact.
  *   temp            DEVICE scratch of at least sw_scan_temp_bytes() (may be NULL when that is 0)
  */

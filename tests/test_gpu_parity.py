@@ -265,7 +265,7 @@ def test_scores_beyond_int16_range_and_long_query():
     assert O.scan(big, *db, simd=True)[3] == 46662
 
 
-@pytest.mark.parametrize("gop,gex", [(-40, -10), (-1, -1), (0, 0), (-20, 0)])
+@pytest.mark.parametrize("gop,gex", [(-40, -10), (-1, -1), (0, 0), (-20, 0), (-2, -5)])
 def test_unusual_gap_scores(gop, gex):
     torch, capi, search = gpu_modules()
     rng = np.random.default_rng(21)
@@ -359,6 +359,30 @@ def test_every_compiled_tile_shape():
                                               err_msg="kind %d lanes %d qlen %d" % (kind, lanes, qlen))
                 seen.add((kind, lanes, qlen))
     assert len(seen) > 250
+
+
+@pytest.mark.parametrize("gop,gex", [(-12, -5), (-1000, -1000), (-3, -12)])
+def test_frame_lowering_on_long_subjects(gop, gex):
+    """The column-offset kernels keep column j's values raised by |gex|*(j mod K + lanes) and lower the frame every K
+    columns, K chosen from |gex| and the kind's range (fp16: K = 1024 at gex = -1, 128 at -5; int16: 2048 at -5; the
+    32-bit kinds: 4096 at -1000).  Long subjects in both group shapes, multi- and single-stripe queries, homologs with
+    large scores: every configuration must reproduce the oracle."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(99)
+    lens = np.sort(np.concatenate([rng.integers(50, 1280, 40), rng.integers(1281, 7000, 30), [8100, 9300]]))
+    seqs = [rng.integers(0, 20, int(l)).astype(np.int8) for l in lens]
+    for qlen in (300, 1900):
+        q = rng.integers(0, 20, qlen).astype(np.int8)
+        for k in (5, 33, 50, 66, 70):  # homologs: the query (or a mutated copy) embedded in a long subject
+            emb = q.copy()
+            emb[:: 7 + k % 5] = rng.integers(0, 20, len(emb[:: 7 + k % 5]))
+            pos = int(rng.integers(0, max(1, len(seqs[k]) - qlen)))
+            seqs[k] = np.concatenate([seqs[k][:pos], emb, seqs[k][pos + qlen:]])[: max(len(seqs[k]), qlen)]
+        db = O.make_db(seqs)
+        expect = O.scan(q, *db, gop=gop, gex=gex)
+        for cfg, kt in kinds_configs(search, capi).items():
+            got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, gop=gop, gex=gex)
+            np.testing.assert_array_equal(got, expect, err_msg="%s gop %d gex %d qlen %d" % (cfg, gop, gex, qlen))
 
 
 @pytest.mark.parametrize("qlen", [300, 600])
