@@ -194,6 +194,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // one frame plus the pipeline skew must fit the room
     int64_t K = 1 << 21;
     while (K >= 4 * lanes && (int64_t)a * (K + 3 * lanes + 8) > room) K >>= 1;
+    if (!kind_packed(kind) && max_subject_len + 3 * lanes + 8 > K) K = 0;  // the 32-bit kernels do not lower their frame
     const bool offs = ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
     int rc = ensure_profile(ctx, kind, lanes, offs, offs ? a : 0, stream);
     if (rc != SW_OK) return rc;

@@ -180,7 +180,8 @@ struct Arith<I32> {
     static __host__ __device__ u32 encode_gap(int g) { return (u32)g; }
     static __host__ __device__ u32 encode_score(int s) { return (u32)s; }
     // v_max3_i32 spelled out: hipcc's own selection mixes signed/unsigned 2- and 3-input forms here
-    // (4.4 max instructions per cell instead of 3.5)
+    // (4.4 max instructions per cell instead of 3.5).  The compiler puts a wait state behind each inline-asm result that
+    // is read at once; the plain-C++ form has none but spills more under the occupancy bound (5.6 vs 6.0 TCUPS)
     static __device__ __forceinline__ u32 max3(u32 a, u32 b, u32 c) {
         u32 d;
         asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -537,7 +538,10 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 
     // OFFS: a lane starts every stripe "at column -lane": zero level a*(LANES - lane), +a per step
     const u32 apos = OFFS ? A::pos_word(p.gex_mag) : 0u;
-    const int rq = OFFS ? p.renorm_quads : 0;
+    // frame lowering exists in the packed kernels only: a 32-bit frame has room for any subject (a second copy of the
+    // loop body would only cost the occupancy-bounded 32-bit kernels registers)
+    constexpr bool kLowers = OFFS && A::kPacked;
+    const int rq = kLowers ? p.renorm_quads : 0;
     const u32 zstart = OFFS ? A::zero_at(p.gex_mag, LANES - lane) : A::kZero;
     const u32 zbefore = OFFS ? A::zero_at(p.gex_mag, LANES - lane - 1) : A::kZero;  // the column before
 
@@ -668,11 +672,11 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             // the quads in which lanes lower their frame (the first LANES/4 of every K/4 quads but the first) run a second
             // copy of the loop body, so that the others pay nothing for it
             {
-                const int seg = (OFFS && rq > 0) ? rq : nquads;
+                const int seg = (kLowers && rq > 0) ? rq : nquads;
                 for (int q0 = 0; q0 < nquads; q0 += seg) {
                     const int qend = min(nquads, q0 + seg);
                     int q = q0;
-                    if constexpr (OFFS) {
+                    if constexpr (kLowers) {
                         if (q0 > 0) {
                             const int qlow = min(qend, q0 + LANES / 4);
                             for (; q < qlow; q++) quad(q, std::true_type{});
