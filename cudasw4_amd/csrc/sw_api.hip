@@ -98,7 +98,6 @@ struct sw_ctx {
     uint32_t* d_work = nullptr;  // kWorkSlots batch counters (dynamic batch distribution), one per launch in flight
     uint32_t work_next = 0;
     int grid_mult = 4;           // persistent workgroups per CU (CUDASW4_AMD_GRID_MULT overrides, for experiments)
-    bool use_stream = true;      // CUDASW4_AMD_NO_STREAM=1 falls back to one pipeline fill per subject (A/B measurements)
     bool have_matrix = false;
     int8_t* d_query = nullptr;
     size_t query_capacity = 0;
@@ -251,24 +250,6 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     SW_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream));
     // short subjects: the F half of the stripe border stays in LDS (packed kinds, 16-lane groups)
     const bool ldsf = multi && lanes == 16 && kl->packed && p.lcap <= swk::kLdsFCols;
-    // single-stripe queries over 16-lane groups: the subjects of a wave follow each other without draining the
-    // pipeline (sw_stream_kernel.hpp); the re-score path (position list, device-side count) keeps the plain kernel
-    if (!multi && lanes == 16 && !positions && !count_ptr && ctx->use_stream && !offs) {
-#ifdef SWK_TRACE  // diagnostic builds only: dump the per-wave timeline of this launch (tools/trace_stats.py)
-        static uint32_t* trace = nullptr;
-        if (!trace) SW_HIP(hipMalloc(&trace, 1 << 20));
-        SW_HIP(hipMemsetAsync(trace, 0, 1 << 20, stream));
-        p.scratch = trace;
-        SW_HIP(kl->stream(pl.rows, grid, stream, p));
-        SW_HIP(hipStreamSynchronize(stream));
-        static std::vector<uint64_t> host(1 << 17);
-        SW_HIP(hipMemcpy(host.data(), trace, 1 << 20, hipMemcpyDeviceToHost));
-        if (FILE* f = fopen("gpurun_out/trace.bin", "wb")) { fwrite(host.data(), 8, (size_t)grid * 4 * 4, f); fclose(f); }
-        return SW_OK;
-#endif
-        SW_HIP(kl->stream(pl.rows, grid, stream, p));
-        return SW_OK;
-    }
     SW_HIP(kl->scan(pl.rows, lanes, multi, ldsf, offs, grid, stream, p));
     return SW_OK;
 }
@@ -299,7 +280,6 @@ int sw_ctx_create(int device, sw_ctx** out) {
     sw_ctx* ctx = new sw_ctx;
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
-    if (const char* e = getenv("CUDASW4_AMD_NO_STREAM")) ctx->use_stream = !(e[0] == '1');
     if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
     hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);

@@ -28,19 +28,11 @@ struct KindLaunch {
     // return hipSuccess or the launch error; (R, lanes) must be a compiled combination, else hipErrorInvalidValue
     // offs: the column-offset form of the recurrence (sw_dp_kernel.hpp: dp_step<OFFS>); needs a profile built with shift = a
     hipError_t (*scan)(int R, int lanes, bool multi, bool ldsf, bool offs, int grid, hipStream_t stream, const ScanParams& p);
-    // single-stripe scan of 16-lane groups as a continuous stream of subjects (sw_stream_kernel.hpp)
-    hipError_t (*stream)(int R, int grid, hipStream_t stream, const ScanParams& p);
     hipError_t (*profile)(int R, int lanes, const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t nstripes,
                           unsigned char* out, int32_t shift, hipStream_t stream);
     size_t (*tile_bytes)(int R, int lanes);
     bool packed;
 };
-
-// the stream kernels live in their own translation units (own scheduling flags, see Makefile)
-hipError_t stream_f16x2(int R, int grid, hipStream_t stream, const ScanParams& p);
-hipError_t stream_i16x2(int R, int grid, hipStream_t stream, const ScanParams& p);
-hipError_t stream_i32(int R, int grid, hipStream_t stream, const ScanParams& p);
-hipError_t stream_f32(int R, int grid, hipStream_t stream, const ScanParams& p);
 
 const KindLaunch& launch_f16x2();
 const KindLaunch& launch_i16x2();
@@ -105,7 +97,7 @@ constexpr size_t tile_bytes_r() {
 #define SWK_FOR_EACH_R_SCALAR(X) \
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
-#define SWK_DEFINE_KIND(FN, STREAMFN, KIND, FOR_EACH_R)                                                                      \
+#define SWK_DEFINE_KIND(FN, KIND, FOR_EACH_R)                                                                      \
     static hipError_t FN##_scan(int R, int lanes, bool multi, bool ldsf, bool offs, int grid, hipStream_t stream, \
                                 const ScanParams& p) {                                                              \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN16_##KIND) } }                                      \
@@ -124,7 +116,7 @@ constexpr size_t tile_bytes_r() {
         return 0;                                                                                                   \
     }                                                                                                               \
     const KindLaunch& FN() {                                                                                        \
-        static const KindLaunch k{FN##_scan, STREAMFN, FN##_profile, FN##_tile_bytes, Arith<KIND>::kPacked};                  \
+        static const KindLaunch k{FN##_scan, FN##_profile, FN##_tile_bytes, Arith<KIND>::kPacked};                  \
         return k;                                                                                                   \
     }
 

@@ -386,11 +386,10 @@ def test_frame_lowering_on_long_subjects(gop, gex):
 
 
 @pytest.mark.parametrize("qlen", [300, 600])
-def test_stream_nonfinite_states(qlen):
-    """Single-stripe queries run as a continuous stream of subjects per wave, separated by columns that reset the DP
-    state.  With a custom matrix of large entries a subject can drive the packed state to fp16 +inf (score > 65504)
-    or to an int16 NaN bit pattern (> 30719), which no separator can reset: the subjects that follow it in the
-    stream must then come out flagged and be re-scored exactly, like the offender itself."""
+def test_nonfinite_packed_states(qlen):
+    """With a custom matrix of large entries a subject can drive the packed state to fp16 +inf (score > 65504) or to
+    an int16 NaN bit pattern (> 30719): it must come out flagged and be re-scored exactly, and its neighbours in the
+    wave must not be affected."""
     torch, capi, search = gpu_modules()
     rng = np.random.default_rng(5)
     m = np.full((21, 21), -4, dtype=np.int8)

@@ -18,7 +18,7 @@ def stats(path):
     print()
     print("per-dispatch register/LDS use of the DP kernels:")
     q = ("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x, count(*), avg(duration) "
-         "from kernels where (name like '%sw_scan_kernel%' or name like '%sw_stream_kernel%') group by name, grid_x order by avg(duration) desc")
+         "from kernels where name like '%sw_scan_kernel%' group by name, grid_x order by avg(duration) desc")
     print("%-60s %5s %5s %5s %7s %8s %5s %6s %12s" % ("kernel", "vgpr", "agpr", "sgpr", "lds", "grid", "wg", "calls", "avg_ns"))
     for r in db.execute(q):
         print("%-60s %5d %5d %5d %7d %8d %5d %6d %12.0f" % ((r[0][:60],) + tuple(r[1:])))
@@ -50,7 +50,7 @@ def traffic(fetch_db, write_db):
         acc = defaultdict(lambda: [0, 0.0, 0.0])
         for name, value, dur in db.execute(
                 "select kernel_name, value, duration from counters_collection where counter_name = ?", (counter,)):
-            if "sw_scan_kernel" in name or "sw_stream_kernel" in name:
+            if "sw_scan_kernel" in name:
                 a = acc[name]
                 a[0] += 1
                 a[1] += value
