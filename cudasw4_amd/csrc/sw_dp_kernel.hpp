@@ -16,8 +16,11 @@
 //   * the substitution scores come from a per-query PROFILE tile in LDS: for subject letter c the
 //     lane reads its R scores as contiguous 16-byte chunks (ds_read_b128), laid out so that the
 //     bank of an access depends on the lane only -> conflict-free for any mix of letters;
-//   * packed kinds run two subjects per group in the two 16-bit halves (v_pk_add_u16 / v_pk_max_i16 /
-//     v_pk_sub_u16 clamp, or v_pk_add_f16 / v_pk_maximum3_f16);
+//   * packed kinds run two subjects per group in the two 16-bit halves (v_pk_add_f16 / v_pk_maximum3_f16; the int16
+//     kind adds with v_pk_add_u16 / v_pk_sub_u16 and compares its biased bit patterns with the same fp16 maximum);
+//   * the recurrence runs in a column-offset frame (dp_step<OFFS>): every value of subject column j is kept raised by
+//     |gex| * (j mod K + LANES), which takes the "+ gex" out of the horizontal gap state — 7.5 instead of 8.5
+//     instructions per cell pair; the plain form remains for gap-extension scores too large for any K;
 //   * queries longer than one stripe are processed stripe after stripe by the same group; the H/F
 //     row at the stripe border is spilled to a small global scratch (branch-free: 8 bytes stored per
 //     step, 32 bytes loaded per four steps), the analogue of the reference's devTempHcol2/devTempEcol2;
