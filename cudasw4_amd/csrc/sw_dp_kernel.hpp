@@ -315,7 +315,8 @@ struct StripeState {
     u32 upH_prev;  // H(row0-1, column-1): diagonal input of the lane's first row
     u32 Hlast;     // H of the lane's bottom row after the last step
     u32 Fout;      // vertical gap state leaving the lane's bottom row after the last step
-    u32 yA, yB;    // LDS byte address (+16 bias) of the lane's chunk for the current letter(s)
+    u32 yA, yB;    // LDS byte address (+16 bias) of the lane's chunk for the current letter(s); packed kinds with
+                   // 16-lane groups keep both in yA (B's address in the upper half)
     u32 maxv;
     u32 Z;         // OFFS: zero level (in the column-offset frame) of the column this lane enters next
 };
@@ -345,15 +346,24 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
     constexpr int kPostShift = G::kLetterShift - 8;        // row offset = byte << kLetterShift
 
     // subject letter(s): shift along the group, lane 0 takes the next letter of its subject
-    const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel) << kPostShift;
-    st.yA = dpp<SHR1, false>(injA, st.yA) + 16u;
     u32 wa[G::NW];
-    lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + st.yA);
     u32 wb[G::NW];
-    if constexpr (A::kPacked) {
-        const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel) << kPostShift;
-        st.yB = dpp<SHR1, false>(injB, st.yB) + 16u;
-        lds_read_words<G::NW, G::kChunkRowBytes>(wb, tile + st.yB);
+    if constexpr (A::kPacked && LANES == 16) {
+        // both LDS addresses (< 64 KB) travel in one register: one permute, one DPP move and one add for the pair
+        constexpr u32 kSel2 = ((u32)(4 + BYTE) << 24) | 0x000c000cu | ((u32)BYTE << 8);  // B's byte -> 31:24, A's -> 15:8
+        const u32 inj = __builtin_amdgcn_perm(lettersB, lettersA, kSel2);
+        st.yA = dpp<SHR1, false>(inj, st.yA) + 0x00100010u;
+        lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + (st.yA & 0xffffu));
+        lds_read_words<G::NW, G::kChunkRowBytes>(wb, tile + (st.yA >> 16));
+    } else {
+        const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel) << kPostShift;
+        st.yA = dpp<SHR1, false>(injA, st.yA) + 16u;
+        lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + st.yA);
+        if constexpr (A::kPacked) {
+            const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel) << kPostShift;
+            st.yB = dpp<SHR1, false>(injB, st.yB) + 16u;
+            lds_read_words<G::NW, G::kChunkRowBytes>(wb, tile + st.yB);
+        }
     }
 
     if constexpr (OFFS) {
@@ -601,6 +611,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             st.maxv = OFFS ? A::add(maxv, zbefore) : maxv;  // OFFS: true score -> frame of the column before the first
             st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
             st.yB = st.yA;
+            if constexpr (A::kPacked && LANES == 16) st.yA |= st.yA << 16;  // (address for subject B, address for subject A)
 
             // subject letters: lane l holds letters 4*LANES*blk + 4l .. +3 of each subject, premultiplied
             // by kLetterUnits so that a byte << kLetterShift is the byte offset of the letter's profile row
