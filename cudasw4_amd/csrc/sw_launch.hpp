@@ -15,7 +15,10 @@ constexpr int kRowsGranule = 1;
 #define SWK_MAX_ROWS_PACKED 44
 #endif
 constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 704 query rows, 31.5 KB tile; 251 VGPRs as a multi-stripe kernel (2 waves/SIMD)
-constexpr int kMaxRowsScalar = 32;  // stripe = 512 query rows (32-bit profile entries, 43 KB tile)
+#ifndef SWK_MAX_ROWS_SCALAR
+#define SWK_MAX_ROWS_SCALAR 32
+#endif
+constexpr int kMaxRowsScalar = SWK_MAX_ROWS_SCALAR;  // stripe = 512 query rows (32-bit profile entries, 43 KB tile)
 // long-subject shape (64-lane groups)
 constexpr int kMaxRowsPackedLong = 16;  // stripe = 1024 query rows, 43 KB tile
 constexpr int kMaxRowsScalarLong = 8;   // stripe = 512 query rows, 43 KB tile
