@@ -192,8 +192,8 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // every K columns the frame is lowered by a*K (K a power of two, at least 4*lanes): the longest run of columns in
     // one frame plus the pipeline skew must fit the room
     int64_t K = 1 << 21;
-    while (K >= 4 * lanes && (int64_t)a * (K + 3 * lanes + 8) > room) K >>= 1;
-    if (!kind_packed(kind) && max_subject_len + 3 * lanes + 8 > K) K = 0;  // the 32-bit kernels do not lower their frame
+    while (K >= 4 * lanes && (int64_t)a * (K + 3 * lanes + 16) > room) K >>= 1;
+    if (!kind_packed(kind) && max_subject_len + 3 * lanes + 16 > K) K = 0;  // the 32-bit kernels do not lower their frame
     const bool offs = ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
     int rc = ensure_profile(ctx, kind, lanes, offs, offs ? a : 0, stream);
     if (rc != SW_OK) return rc;
@@ -225,6 +225,16 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
             default: p.gop = swk::Arith<swk::F32>::encode_gap(g); break;
         }
         p.gex_mag = a;
+        {   // row classes of the kernel that plan (rows, lanes) selects: lowering words at the class wrap / the last row
+            const int P = swk::frame_classes(kl->packed, pl.rows, lanes);
+            const int wrap = -a * P, wrap_last = -a * ((pl.rows - 1) % P + 1);
+            switch (kind) {
+                case SW_KIND_F16X2: p.wrap_class = swk::Arith<swk::F16X2>::encode_gap(wrap); p.wrap_last = swk::Arith<swk::F16X2>::encode_gap(wrap_last); break;
+                case SW_KIND_I16X2: p.wrap_class = swk::Arith<swk::I16X2>::encode_gap(wrap); p.wrap_last = swk::Arith<swk::I16X2>::encode_gap(wrap_last); break;
+                case SW_KIND_I32: p.wrap_class = swk::Arith<swk::I32>::encode_gap(wrap); p.wrap_last = swk::Arith<swk::I32>::encode_gap(wrap_last); break;
+                default: p.wrap_class = swk::Arith<swk::F32>::encode_gap(wrap); p.wrap_last = swk::Arith<swk::F32>::encode_gap(wrap_last); break;
+            }
+        }
         p.renorm_quads = (int32_t)(K / 4);
         const int lower = -(int)((int64_t)a * K);
         switch (kind) {

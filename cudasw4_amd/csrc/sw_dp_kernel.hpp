@@ -285,6 +285,8 @@ struct ScanParams {
     int32_t gex_mag;           // OFFS kernels: a = -gex; then gop holds encode_gap(gop - gex) and the profile s + a
     int32_t renorm_quads;      // OFFS: K/4 — every K columns a lane lowers its frame by a*K (0: never); a power of two
     u32 renorm_word;           // encode_gap(-a*K)
+    u32 wrap_class;            // OFFS: encode_gap(-a*P), P = frame_classes(...) of the launched kernel (dp_step: row classes)
+    u32 wrap_last;             // OFFS: encode_gap(-a*((R-1) % P + 1))
 };
 
 template <int NW, int CHUNK_ROW_BYTES>
@@ -307,8 +309,24 @@ __device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned ch
     }
 }
 
+// Row classes of the column-offset frame (dp_step<OFFS>): lane-local row r belongs to class r mod P and is kept raised
+// by a further a * (r mod P).  P = 1 is the plain column frame.
+#ifndef SWK_CLASSES_PACKED
+#define SWK_CLASSES_PACKED 4
+#endif
+#ifndef SWK_CLASSES_SCALAR
+#define SWK_CLASSES_SCALAR 4
+#endif
+constexpr int frame_classes(bool packed, int R, int lanes) {
+    (void)lanes;
+    const int want = packed ? SWK_CLASSES_PACKED : SWK_CLASSES_SCALAR;
+    int P = want;
+    while (P > 1 && 2 * P > R) P--;  // at least two rows per class, so that the running maximum still folds two rows per max3
+    return P;
+}
+
 // Per-group DP state that lives across the steps of one stripe.
-template <int KIND, int R>
+template <int KIND, int R, int P = 1>
 struct StripeState {
     u32 H[R];      // H(row, column-1)
     u32 E[R];      // horizontal gap state entering the current column (clamped)
@@ -317,8 +335,8 @@ struct StripeState {
     u32 Fout;      // vertical gap state leaving the lane's bottom row after the last step
     u32 yA, yB;    // LDS byte address (+16 bias) of the lane's chunk for the current letter(s); packed kinds with
                    // 16-lane groups keep both in yA (B's address in the upper half)
-    u32 maxv;
-    u32 Z;         // OFFS: zero level (in the column-offset frame) of the column this lane enters next
+    u32 maxv[P];   // running maximum (OFFS: one per row class, each in its class's frame)
+    u32 Zc[P + 1]; // OFFS: Zc[k] = zero level of the column this lane enters next, raised by a*k (k = class, or class + 1)
 };
 
 // One anti-diagonal step of one lane: R cells (or R cell pairs).
@@ -335,10 +353,10 @@ struct StripeState {
 // that grow with the column index: the launcher picks OFFS only while a * columns stays well inside the exact range
 // of the kind, and a subject whose bound maxscore + a * columns reaches the limit is flagged like an overflow.
 // `first` (MULTI): the stripe has no predecessor, lane 0's boundary is the zero level instead of the border row.
-template <int KIND, int R, int LANES, int BYTE, bool MULTI, bool OFFS = false>
-__device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned char* tile,
+template <int KIND, int R, int LANES, int BYTE, bool MULTI, bool OFFS = false, int P = 1>
+__device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsigned char* tile,
                                         u32 lettersA, u32 lettersB, u32 gop, u32 gex, u32 inH, u32 inF,
-                                        u32 apos = 0, bool first = false) {
+                                        u32 apos = 0, bool first = false, u32 wrapP = 0, u32 wrapLast = 0) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
     constexpr int SHR1 = Shift<LANES>::kShr1;
@@ -367,23 +385,31 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
     }
 
     if constexpr (OFFS) {
-        const u32 Zj = st.Z;
-        const u32 Zn = A::add(Zj, apos);
-        st.Z = Zn;
+        // Row classes: lane-local row r (class p = r mod P) is kept raised by a further a*p.  F then needs its "- a" only
+        // where the class wraps (every P rows, and after the lane's last row: by a*(p+1), back to class 0), E and F of a
+        // row share the zero level Zc[p+1], and the running maximum is kept per class (rows r and r+P fold into one
+        // max3).  What a lane passes on (Hlast) stays in the frame of its last row's class; the profile entry of a row
+        // carries s + a*(1 + class - class of the row above) (sw_build_profile_kernel), which makes row 0 consistent.
+        constexpr int kLastClass = (R - 1) % P;
+        const u32 bH = st.Zc[kLastClass];  // the local-alignment boundary H = 0 as row 0's diagonal expects it
         u32 upH, F;
         if constexpr (MULTI) {
-            upH = dpp<SHR1, false>(first ? Zj : inH, st.Hlast);
-            F = dpp<SHR1, false>(first ? Zj : inF, st.Fout);
+            upH = dpp<SHR1, false>(first ? bH : inH, st.Hlast);
+            F = dpp<SHR1, false>(first ? 0u : inF, st.Fout);
         } else {
-            upH = dpp<SHR1, false>(Zj, st.Hlast);
-            F = dpp<SHR1, false>(Zj, st.Fout);
+            upH = dpp<SHR1, false>(bH, st.Hlast);
+            // any F below the column's zero level is "no vertical gap": bound_ctrl zero fill (pattern 0 is below every
+            // zero level of every kind, and the fp16 comparator of the int16 kind orders +0.0 below all its patterns)
+            F = dpp<SHR1, true>(0u, st.Fout);
         }
         u32 diag = st.upH_prev;
         st.upH_prev = upH;
-        // the running maximum travels in the moving frame: raised by a per step like everything else, so the rows'
-        // maxima fold straight into it (it is converted back to a true score once per stripe)
-        u32 m = A::add(st.maxv, apos);
-        // The rows are software-pipelined by hand: the chain h -> h+G -> max3 -> -a -> next row's h is serial, and on
+        // the running maxima travel in the moving frame: raised by a per step like everything else, so the rows'
+        // maxima fold straight into them (converted back to true scores once per stripe)
+        u32 m[P];
+#pragma unroll
+        for (int c = 0; c < P; c++) m[c] = A::add(st.maxv[c], apos);
+        // The rows are software-pipelined by hand: the chain h -> h+G -> max3 -> next row's h is serial, and on
         // gfx950 a packed op that reads the result of the instruction right before it costs a wait state, so the
         // independent work (score lookup and diagonal term of the rows ahead, the E update, the maximum) is
         // written in between the links of the chain.
@@ -396,20 +422,27 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
         s_next = R > 1 ? score(1) : 0u;
 #pragma unroll
         for (int r = 0; r < R; r++) {
+            const int c = r % P;
+            const u32 zop = st.Zc[c + 1];
             const u32 t = t_next;
             const u32 h = A::cell_h(t, st.E[r], F);
             const u32 s1 = s_next;
             if (r + 2 < R) s_next = score(r + 2);
             const u32 hg = A::gap(h, gop);  // gop + a
             if (r + 1 < R) t_next = A::add(st.H[r], s1);  // the row's old H is the next row's diagonal
-            const u32 fm = A::max3(F, hg, Zn);
-            st.E[r] = A::max3(st.E[r], hg, Zn);
-            F = A::gap(fm, gex);
-            if (r & 1) m = A::fold2(m, st.H[r - 1], h);
-            else if (r == R - 1) m = A::max2(m, h);
+            const u32 fm = A::max3(F, hg, zop);
+            st.E[r] = A::max3(st.E[r], hg, zop);
+            if (c == P - 1) F = A::gap(fm, wrapP);          // class P-1 -> class 0: lower by a*P
+            else if (r == R - 1) F = A::gap(fm, wrapLast);  // the lane's last row: back to class 0 for the next lane
+            else F = fm;                                     // next class: frame rises by a while F decays by a
+            if ((r / P) & 1) m[c] = A::fold2(m[c], st.H[r - P], h);
+            else if (r + P >= R) m[c] = A::max2(m[c], h);
             st.H[r] = h;
         }
-        st.maxv = m;
+#pragma unroll
+        for (int c = 0; c < P; c++) st.maxv[c] = m[c];
+#pragma unroll
+        for (int k = (kLastClass == 0 ? 0 : 1); k <= P; k++) st.Zc[k] = A::add(st.Zc[k], apos);
         st.Hlast = st.H[R - 1];
         st.Fout = F;
         return;
@@ -430,7 +463,7 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
     u32 diag = st.upH_prev;
     st.upH_prev = upH;
 
-    u32 maxv = st.maxv;
+    u32 maxv = st.maxv[0];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         u32 s;
@@ -451,7 +484,7 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R>& st, const unsigned
         if (r & 1) maxv = A::fold2(maxv, st.H[r - 1], h);
         else if (r == R - 1) maxv = A::max2(maxv, h);
     }
-    st.maxv = maxv;
+    st.maxv[0] = maxv;
     st.Hlast = st.H[R - 1];
     st.Fout = F;
 }
@@ -520,6 +553,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     constexpr int kJunkF = LDSF ? kLdsFJunk : kJunk;
     constexpr int SHL1 = Shift<LANES>::kShl1;
     constexpr int kQuadsPerLetterBlock = LANES;  // a lane holds 4 letters: LANES quads per reload
+    constexpr int P = OFFS ? frame_classes(A::kPacked, R, LANES) : 1;  // row classes of the column-offset frame
     __shared__ __attribute__((aligned(16))) unsigned char lds[16 + G::kTileBytes];
     __shared__ __attribute__((aligned(16))) u32 ldsF[LDSF ? kGroups * kLdsFStride + 16 : 4];
 
@@ -604,11 +638,22 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 load_tile<G::kTileBytes>(lds, p.profile + (size_t)stripe * G::kTileBytes);
                 __syncthreads();
             }
-            StripeState<KIND, R> st;
+            StripeState<KIND, R, P> st;
+            {
+                // zero levels of the column before the lane's first one, per class (zc[k] = zbefore + a*k)
+                u32 zc[P + 2];
+                zc[0] = zbefore; zc[1] = zstart;
 #pragma unroll
-            for (int r = 0; r < R; r++) { st.H[r] = zbefore; st.E[r] = zstart; }
-            st.upH_prev = zbefore; st.Hlast = zbefore; st.Fout = zbefore; st.Z = zstart;
-            st.maxv = OFFS ? A::add(maxv, zbefore) : maxv;  // OFFS: true score -> frame of the column before the first
+                for (int k = 2; k < P + 2; k++) zc[k] = A::add(zc[k - 1], apos);
+#pragma unroll
+                for (int r = 0; r < R; r++) { st.H[r] = zc[r % P]; st.E[r] = zc[r % P + 1]; }
+                st.upH_prev = zc[(R - 1) % P]; st.Hlast = zc[(R - 1) % P]; st.Fout = zbefore;
+#pragma unroll
+                for (int k = 0; k <= P; k++) st.Zc[k] = zc[k + 1];
+                // OFFS: true score -> frame of the column before the first
+#pragma unroll
+                for (int c = 0; c < P; c++) st.maxv[c] = OFFS ? A::add(maxv, zc[c]) : maxv;
+            }
             st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
             st.yB = st.yA;
             if constexpr (A::kPacked && LANES == 16) st.yA |= st.yA << 16;  // (address for subject B, address for subject A)
@@ -666,19 +711,23 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     const u32 gw = lane == k ? p.renorm_word : 0u;
 #pragma unroll
                     for (int r = 0; r < R; r++) { st.H[r] = A::gap(st.H[r], gw); st.E[r] = A::gap(st.E[r], gw); }
-                    st.upH_prev = A::gap(st.upH_prev, gw); st.Z = A::gap(st.Z, gw); st.maxv = A::gap(st.maxv, gw);
+                    st.upH_prev = A::gap(st.upH_prev, gw);
+#pragma unroll
+                    for (int k = 0; k <= P; k++) st.Zc[k] = A::gap(st.Zc[k], gw);
+#pragma unroll
+                    for (int c = 0; c < P; c++) st.maxv[c] = A::gap(st.maxv[c], gw);
                 };
                 if constexpr (LOWER) lower_frame(lower_lane + 0);
-                dp_step<KIND, R, LANES, 0, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first);
+                dp_step<KIND, R, LANES, 0, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first, p.wrap_class, p.wrap_last);
                 if constexpr (MULTI) { outH[0] = st.Hlast; outF[0] = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 1);
-                dp_step<KIND, R, LANES, 1, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first);
+                dp_step<KIND, R, LANES, 1, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first, p.wrap_class, p.wrap_last);
                 if constexpr (MULTI) { outH[1] = st.Hlast; outF[1] = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 2);
-                dp_step<KIND, R, LANES, 2, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first);
+                dp_step<KIND, R, LANES, 2, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first, p.wrap_class, p.wrap_last);
                 if constexpr (MULTI) { outH[2] = st.Hlast; outF[2] = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 3);
-                dp_step<KIND, R, LANES, 3, MULTI, OFFS>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first);
+                dp_step<KIND, R, LANES, 3, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first, p.wrap_class, p.wrap_last);
                 if constexpr (MULTI) { outH[3] = st.Hlast; outF[3] = st.Fout; outH += walkOut; outF += walkOut; }
                 lettersA = dpp<SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
@@ -706,8 +755,15 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     borderF[4 * nquads - (LANES - 1) + lane] = A::kZero;
                 }
             }
-            if constexpr (OFFS) maxv = A::true_of(st.maxv, A::gap(st.Z, p.gex));  // frame of the lane's last column -> true score
-            else maxv = st.maxv;
+            if constexpr (OFFS) {
+                // frames of the lane's last column -> true score (Zc[c + 1] is the NEXT column's level of class c + 1: 2a above)
+                maxv = A::true_of(st.maxv[0], A::gap(A::gap(st.Zc[1], p.gex), p.gex));
+#pragma unroll
+                for (int c = 1; c < P; c++)
+                    maxv = A::true_max(maxv, A::true_of(st.maxv[c], A::gap(A::gap(st.Zc[c + 1], p.gex), p.gex)));
+            } else {
+                maxv = st.maxv[0];
+            }
             if constexpr (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
 
@@ -725,7 +781,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             sc0 = A::true_lo(maxv);
             sc1 = A::true_hi(maxv);
             // no value of the alignment exceeded score + a * (columns + LANES): inside the exact range below the limit
-            guard = p.gex_mag * ((rq > 0 && 4 * nquads > 4 * rq ? 4 * rq : 4 * nquads) + 2 * LANES + 4);
+            guard = p.gex_mag * ((rq > 0 && 4 * nquads > 4 * rq ? 4 * rq : 4 * nquads) + 2 * LANES + 4 + P);
         } else {
             maxv = group_max<KIND, LANES>(maxv);
             sc0 = A::score_lo(maxv);
@@ -778,7 +834,11 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
                 if (row_in_lane >= R) return 0u;  // unused upper half of an odd R's last word
                 const int64_t row = (int64_t)stripe * G::kStripeRows + lane * R + row_in_lane;
                 const int qc = row < qlen ? (int)query[row] : kPadLetter;
-                return A::encode_score((int)matrix21[qc * kLetters + letter] + shift);  // shift = a for the OFFS kernels
+                // OFFS kernels (shift = a): the diagonal step raises the frame by a per column and by a per row class;
+                // the row above lane-local row 0 is the previous lane's last row (dp_step<OFFS>)
+                constexpr int P = frame_classes(A::kPacked, R, LANES);
+                const int cls = row_in_lane % P, above = (row_in_lane == 0 ? R - 1 : row_in_lane - 1) % P;
+                return A::encode_score((int)matrix21[qc * kLetters + letter] + shift * (1 + cls - above));
             };
             if constexpr (A::kPacked) v = entry(2 * w) | (entry(2 * w + 1) << 16);
             else v = entry(w);
