@@ -127,6 +127,14 @@ struct Arith<I16X2> {
     }
     static __device__ __forceinline__ int true_lo(u32 v) { return (int)(v & 0xffffu); }
     static __device__ __forceinline__ int true_hi(u32 v) { return (int)(v >> 16); }
+    // wide profile words (score, 1): (wa.lo * wb.hi + c.lo, wa.hi * wb.lo + c.hi) = c + (score A, score B) in ONE
+    // v_pk_mad_u16 (op_sel swaps the halves of wb) — replaces the v_perm_b32 + add of the two-rows-per-word layout
+    static constexpr u32 kOne = 1u;
+    static __device__ __forceinline__ u32 add_pair(u32 wa, u32 wb, u32 c) {
+        u32 d;
+        asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(wa), "v"(wb), "v"(c));
+        return d;
+    }
 };
 
 template <>
@@ -172,6 +180,15 @@ struct Arith<F16X2> {
     static __device__ __forceinline__ u32 true_max(u32 a, u32 b) { return max2(a, b); }
     static __device__ __forceinline__ int true_lo(u32 v) { return score_lo(v); }
     static __device__ __forceinline__ int true_hi(u32 v) { return score_hi(v); }
+    // wide profile words (score, 1.0): one v_pk_fma_f16 with op_sel (exact: a product with 1.0, one rounding of an integer sum)
+    static constexpr u32 kOne = 0x3c00u;
+    static __device__ __forceinline__ u32 add_pair(u32 wa, u32 wb, u32 c) {
+        // spelled out: from a shufflevector hipcc folds the swap into op_sel for three words of a 16-byte LDS chunk but
+        // rotates the first one with an extra v_alignbit_b32
+        u32 d;
+        asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(wa), "v"(wb), "v"(c));
+        return d;
+    }
 };
 
 template <>
@@ -248,8 +265,11 @@ struct Arith<F32> {
 template <int KIND, int R, int LANES = kGroup>
 struct Geometry {
     static constexpr bool kPacked = Arith<KIND>::kPacked;
-    // packed kinds keep two query rows per 32-bit profile word; an odd R leaves the upper half of the last word unused
-    static constexpr int NW = kPacked ? (R + 1) / 2 : R;
+    // packed kinds, 16-lane groups: WIDE words (score of the row, 1) — the pair (score A, score B) of a cell pair and its
+    // addition to the diagonal are ONE packed multiply-add (Arith::add_pair).  Wave-wide groups keep two query rows per
+    // word (an odd R leaves the upper half of the last word unused) and pair the scores with v_perm_b32.
+    static constexpr bool kWide = kPacked && LANES == 16;
+    static constexpr int NW = (kPacked && !kWide) ? (R + 1) / 2 : R;
     static constexpr int NCH = (NW + 3) / 4;
     static constexpr int kChunkRowBytes = LANES * 16;            // chunk k of lane l at k*kChunkRowBytes + l*16
     static constexpr int kRowBytes = NCH * kChunkRowBytes;
@@ -414,11 +434,17 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         // independent work (score lookup and diagonal term of the rows ahead, the E update, the maximum) is
         // written in between the links of the chain.
         auto score = [&](int r) -> u32 {
-            if constexpr (A::kPacked) return __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+            if constexpr (G::kWide) return 0u;
+            else if constexpr (A::kPacked) return __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
             else return wa[r];
         };
+        // diagonal term of row r: d + score(s)
+        auto diag_term = [&](int r, u32 d, u32 sc) -> u32 {
+            if constexpr (G::kWide) return A::add_pair(wa[r], wb[r], d);
+            else return A::add(d, sc);
+        };
         u32 s_next = score(0);
-        u32 t_next = A::add(diag, s_next);
+        u32 t_next = diag_term(0, diag, s_next);
         s_next = R > 1 ? score(1) : 0u;
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -429,7 +455,7 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
             const u32 s1 = s_next;
             if (r + 2 < R) s_next = score(r + 2);
             const u32 hg = A::gap(h, gop);  // gop + a
-            if (r + 1 < R) t_next = A::add(st.H[r], s1);  // the row's old H is the next row's diagonal
+            if (r + 1 < R) t_next = diag_term(r + 1, st.H[r], s1);  // the row's old H is the next row's diagonal
             const u32 fm = A::max3(F, hg, zop);
             st.E[r] = A::max3(st.E[r], hg, zop);
             if (c == P - 1) F = A::gap(fm, wrapP);          // class P-1 -> class 0: lower by a*P
@@ -466,14 +492,15 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
     u32 maxv = st.maxv[0];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        u32 s;
-        if constexpr (A::kPacked) {
+        u32 t;
+        if constexpr (G::kWide) {
+            t = A::add_pair(wa[r], wb[r], diag);
+        } else if constexpr (A::kPacked) {
             // (score of subject A, score of subject B) for query row r
-            s = __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+            t = A::add(diag, __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u));
         } else {
-            s = wa[r];
+            t = A::add(diag, wa[r]);
         }
-        const u32 t = A::add(diag, s);
         diag = st.H[r];
         const u32 h = A::cell_h(t, st.E[r], F);
         const u32 hg = A::gap(h, gop);
@@ -840,7 +867,8 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
                 const int cls = row_in_lane % P, above = (row_in_lane == 0 ? R - 1 : row_in_lane - 1) % P;
                 return A::encode_score((int)matrix21[qc * kLetters + letter] + shift * (1 + cls - above));
             };
-            if constexpr (A::kPacked) v = entry(2 * w) | (entry(2 * w + 1) << 16);
+            if constexpr (G::kWide) v = w < R ? (entry(w) | (A::kOne << 16)) : 0u;
+            else if constexpr (A::kPacked) v = entry(2 * w) | (entry(2 * w + 1) << 16);
             else v = entry(w);
         }
         out[i] = v;

@@ -52,7 +52,9 @@ hipError_t launch_scan_ro(bool multi, bool ldsf, int grid, hipStream_t stream, c
     } else {
         if (multi) {
             if constexpr (2 * R > kMaxR) {
-                if constexpr (Arith<KIND>::kPacked && LANES == 16) {
+                // the LDS border needs room next to the profile tile for two workgroups per CU
+                if constexpr (Arith<KIND>::kPacked && LANES == 16 &&
+                              Geometry<KIND, R, LANES>::kTileBytes + 16 * kLdsFStride * 4 + 256 <= 80 * 1024) {
                     if (ldsf) {
                         hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, true, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
                         return hipGetLastError();
