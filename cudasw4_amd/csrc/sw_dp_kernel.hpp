@@ -345,6 +345,29 @@ constexpr int frame_classes(bool packed, int R, int lanes) {
     return P;
 }
 
+// the words of two letters, chunk by chunk (A's chunk k, B's chunk k, ...): LDS answers in order, so the first rows'
+// score words arrive after two reads instead of after all of A's
+template <int NW, int CHUNK_ROW_BYTES>
+__device__ __forceinline__ void lds_read_words2(u32 (&da)[NW], u32 (&db)[NW], const unsigned char* pa, const unsigned char* pb) {
+    constexpr int N4 = NW / 4, REM = NW % 4;
+#pragma unroll
+    for (int k = 0; k < N4; k++) {
+        const uint4 va = *reinterpret_cast<const uint4*>(pa + k * CHUNK_ROW_BYTES);
+        const uint4 vb = *reinterpret_cast<const uint4*>(pb + k * CHUNK_ROW_BYTES);
+        da[4 * k + 0] = va.x; da[4 * k + 1] = va.y; da[4 * k + 2] = va.z; da[4 * k + 3] = va.w;
+        db[4 * k + 0] = vb.x; db[4 * k + 1] = vb.y; db[4 * k + 2] = vb.z; db[4 * k + 3] = vb.w;
+        __builtin_amdgcn_sched_barrier(0);  // keep this issue order (the scheduler would sort the reads by register)
+    }
+    if constexpr (REM != 0) {
+        u32 ta[REM], tb[REM];
+        lds_read_words<REM, CHUNK_ROW_BYTES>(ta, pa + N4 * CHUNK_ROW_BYTES);
+        lds_read_words<REM, CHUNK_ROW_BYTES>(tb, pb + N4 * CHUNK_ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < REM; i++) { da[4 * N4 + i] = ta[i]; db[4 * N4 + i] = tb[i]; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Per-group DP state that lives across the steps of one stripe.
 template <int KIND, int R, int P = 1>
 struct StripeState {
@@ -391,8 +414,7 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         constexpr u32 kSel2 = ((u32)(4 + BYTE) << 24) | 0x000c000cu | ((u32)BYTE << 8);  // B's byte -> 31:24, A's -> 15:8
         const u32 inj = __builtin_amdgcn_perm(lettersB, lettersA, kSel2);
         st.yA = dpp<SHR1, false>(inj, st.yA) + 0x00100010u;
-        lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + (st.yA & 0xffffu));
-        lds_read_words<G::NW, G::kChunkRowBytes>(wb, tile + (st.yA >> 16));
+        lds_read_words2<G::NW, G::kChunkRowBytes>(wa, wb, tile + (st.yA & 0xffffu), tile + (st.yA >> 16));
     } else {
         const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel) << kPostShift;
         st.yA = dpp<SHR1, false>(injA, st.yA) + 16u;
@@ -443,19 +465,39 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
             if constexpr (G::kWide) return A::add_pair(wa[r], wb[r], d);
             else return A::add(d, sc);
         };
+        // Wide words: the diagonal terms run kAhead rows ahead of the chain and the scheduler may only reorder within
+        // four rows (it would otherwise compute all of them first, in register order, and so wait for the LAST LDS
+        // chunk at the top of the step): a row needs its score words only when the chain is kAhead rows away.
+#ifndef SWK_LOOKAHEAD
+#define SWK_LOOKAHEAD 12
+#endif
+        constexpr int kAhead = G::kWide ? (SWK_LOOKAHEAD < R ? SWK_LOOKAHEAD : R) : 1;
+        u32 tq[G::kWide ? R : 1];
+        if constexpr (G::kWide) {
+#pragma unroll
+            for (int r = 0; r < kAhead; r++) tq[r] = A::add_pair(wa[r], wb[r], r == 0 ? diag : st.H[r - 1]);
+        }
         u32 s_next = score(0);
-        u32 t_next = diag_term(0, diag, s_next);
+        u32 t_next = G::kWide ? 0u : diag_term(0, diag, s_next);
         s_next = R > 1 ? score(1) : 0u;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int c = r % P;
             const u32 zop = st.Zc[c + 1];
+            if constexpr (G::kWide) {
+                if (r % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                t_next = tq[r];
+            }
             const u32 t = t_next;
             const u32 h = A::cell_h(t, st.E[r], F);
             const u32 s1 = s_next;
             if (r + 2 < R) s_next = score(r + 2);
             const u32 hg = A::gap(h, gop);  // gop + a
-            if (r + 1 < R) t_next = diag_term(r + 1, st.H[r], s1);  // the row's old H is the next row's diagonal
+            if constexpr (G::kWide) {
+                if (r + kAhead < R) tq[r + kAhead] = A::add_pair(wa[r + kAhead], wb[r + kAhead], st.H[r + kAhead - 1]);
+            } else {
+                if (r + 1 < R) t_next = diag_term(r + 1, st.H[r], s1);  // the row's old H is the next row's diagonal
+            }
             const u32 fm = A::max3(F, hg, zop);
             st.E[r] = A::max3(st.E[r], hg, zop);
             if (c == P - 1) F = A::gap(fm, wrapP);          // class P-1 -> class 0: lower by a*P
