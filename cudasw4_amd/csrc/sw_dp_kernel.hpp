@@ -18,9 +18,13 @@
 //     bank of an access depends on the lane only -> conflict-free for any mix of letters;
 //   * packed kinds run two subjects per group in the two 16-bit halves (v_pk_add_f16 / v_pk_maximum3_f16; the int16
 //     kind adds with v_pk_add_u16 / v_pk_sub_u16 and compares its biased bit patterns with the same fp16 maximum);
+//     with 16-lane groups their profile entries are WIDE words (score, 1), so that one v_pk_fma_f16 / v_pk_mad_u16
+//     with op_sel pairs the two subjects' scores AND adds them to the diagonal (Arith::add_pair);
 //   * the recurrence runs in a column-offset frame (dp_step<OFFS>): every value of subject column j is kept raised by
-//     |gex| * (j mod K + LANES), which takes the "+ gex" out of the horizontal gap state — 7.5 instead of 8.5
-//     instructions per cell pair; the plain form remains for gap-extension scores too large for any K;
+//     |gex| * (j mod K + LANES), which takes the "+ gex" out of the horizontal gap state, and lane-local row r by a
+//     further |gex| * (r mod P) (row classes), which takes it out of the vertical gap state except where the class
+//     wraps: 5.8 instead of 8.5 instructions per cell pair; the plain form remains for gap-extension scores too
+//     large for any K;
 //   * queries longer than one stripe are processed stripe after stripe by the same group; the H/F
 //     row at the stripe border is spilled to a small global scratch (branch-free: 8 bytes stored per
 //     step, 32 bytes loaded per four steps), the analogue of the reference's devTempHcol2/devTempEcol2;
@@ -597,9 +601,14 @@ constexpr int border_junk_words() { return LANES == 16 ? 128 : 320; }  // >= 4*(
 #ifndef SWK_MIN_WAVES_SCALAR
 #define SWK_MIN_WAVES_SCALAR 0
 #endif
+#ifndef SWK_WAVES3_MAX_R
+#define SWK_WAVES3_MAX_R 0
+#endif
 template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
-    if (Arith<KIND>::kPacked) return 2;  // 256 VGPRs: what the tallest multi-stripe kernels need; 3 would spill them
+    // packed kinds: 2 waves/SIMD (256 VGPRs) for the tall kernels; up to SWK_WAVES3_MAX_R rows a third wave is asked for
+    // (168 VGPRs): two waves cover each other's wait states only ~92 % of the time, three reach the issue peak
+    if (Arith<KIND>::kPacked) return (LANES == 16 && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
     // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
     return (R <= 16 && !MULTI && LANES == 16) ? 4 : 3;

@@ -14,7 +14,7 @@ constexpr int kRowsGranule = 1;
 #ifndef SWK_MAX_ROWS_PACKED
 #define SWK_MAX_ROWS_PACKED 44
 #endif
-constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 704 query rows, 31.5 KB tile; 251 VGPRs as a multi-stripe kernel (2 waves/SIMD)
+constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 704 query rows, 59 KB tile of wide words; 256 VGPRs as a multi-stripe kernel (2 waves/SIMD)
 #ifndef SWK_MAX_ROWS_SCALAR
 #define SWK_MAX_ROWS_SCALAR 32
 #endif

@@ -1,7 +1,15 @@
+#!/bin/bash
+# scratch: full round-1 measurement pass on the GPU box (results under gpurun_out/final/)
 export TMPDIR=/tmp
-for V in r40 r36 p6 p3; do echo lib_$V; CUDASW4_AMD_LIB=$PWD/cudasw4_amd/lib_$V/libcudasw4_amd.so python tools/peak_sweep.py --lengths 512 --kernels half2 2>&1 | grep kernel; done > gpurun_out/ps_wvar.txt 2>&1
-for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY"; do
-  N=$(echo $C | cut -d" " -f1)
-  timeout 300 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$N -o q -- python3 tools/one_query.py --query-index 19 --length 512 --reps 2 > /tmp/pmc_$N.log 2>&1
-  python3 tools/rocprof_summary.py pmc /tmp/pmc_$N/q_results.db "swk::sw_s" >> gpurun_out/pmc_wide_q19.txt 2>&1
-done
+O=gpurun_out/final; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
+python bench.py > $O/bench_line.json 2> $O/bench_err.txt
+python tools/peak_sweep.py --json $O/peak_sweep.json > $O/peak_sweep.txt 2>&1
+python tools/synth_db_bench.py --config dpx > $O/synth_dpx.txt 2>&1
+python tools/synth_db_bench.py --config half2 > $O/synth_half2.txt 2>&1
+A=cudasw4_amd/lib/align
+$A --query tests/golden/allqueries.fasta --pseudodb 1000000 512 --top 0 --verbose --uploadFull --prefetchDBFile --mat blosum62 --singlePassType Half2 --manyPassType_small Half2 --manyPassType_large Float --overflowType Float > $O/align_peak.txt 2>&1
+$A --query tests/golden/allqueries.fasta --pseudodb 1000000 512 --top 0 --verbose --maxGpuMem 600M --maxBatchBytes 32M --mat blosum62 --singlePassType Half2 --manyPassType_small Half2 --manyPassType_large Float --overflowType Float > $O/align_stream.txt 2>&1
+bash tools/collect_profiles.sh r01 > $O/collect.txt 2>&1
+cp gpurun_out/profiles_r01/* $O/ 2>/dev/null
+tail -3 $O/pytest_gpu.txt; cat $O/bench_line.json; tail -2 $O/align_peak.txt $O/align_stream.txt
