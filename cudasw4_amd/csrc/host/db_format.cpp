@@ -10,6 +10,8 @@
 #include <fstream>
 #include <limits>
 #include <numeric>
+#include <parallel/algorithm>
+#include <cstdlib>
 #include <random>
 
 #include "sequence_codec.hpp"
@@ -81,7 +83,15 @@ void write_database(const std::string& prefix, SequenceBatch& batch) {
     // that equal-length ties land in the same libstdc++-specific order and the files match byte for byte
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](const auto& l, const auto& r) { return batch.lengths[l] < batch.lengths[r]; });
+    // Large inputs (UniRef / TrEMBL scale: 10^7..10^8 sequences) are sorted in parallel (libstdc++ parallel mode,
+    // OpenMP): a stable multiway merge sort, i.e. equal lengths keep their input order.  The reference's single-threaded
+    // std::sort leaves ties in an unspecified order, so any tie order is a valid DB; below the threshold the very same
+    // call is kept for byte-equal files.  CUDASW4_AMD_PARALLEL_SORT_MIN overrides the threshold (tests).
+    size_t parallel_min = size_t(1) << 20;
+    if (const char* e = std::getenv("CUDASW4_AMD_PARALLEL_SORT_MIN")) parallel_min = size_t(std::strtoull(e, nullptr, 10));
+    auto by_length = [&](const auto& l, const auto& r) { return batch.lengths[l] < batch.lengths[r]; };
+    if (n >= parallel_min) __gnu_parallel::stable_sort(order.begin(), order.end(), by_length);
+    else std::sort(order.begin(), order.end(), by_length);
 
     const auto& bounds = length_partition_bounds();
     std::array<uint64_t, kNumLengthPartitions> counts{};

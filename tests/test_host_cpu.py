@@ -95,6 +95,36 @@ def test_makedb_memory_limit_spills_and_matches(tmp_path):
     assert list(tmpd.iterdir()) == []
 
 
+def test_makedb_parallel_sort_is_stable_and_equivalent(tmp_path):
+    """The parallel sort (inputs of 2^20 sequences and more; forced here by the environment override) keeps equal
+    lengths in input order and otherwise writes the same DB: same lengths, same multiset of (header, sequence)."""
+    rng = np.random.default_rng(31)
+    fasta = str(tmp_path / "in.fa")
+    _random_fasta(fasta, rng, 2000)
+    serial = run_makedb(MAKEDB, fasta, str(tmp_path / "ser"))
+    env = dict(os.environ, CUDASW4_AMD_PARALLEL_SORT_MIN="1", OMP_NUM_THREADS="4")
+    out = subprocess.run([MAKEDB, fasta, str(tmp_path / "par")], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    par = {f: open(str(tmp_path / "par") + f, "rb").read() for f in DB_FILES}
+    assert par["0lengths"] == serial["0lengths"] and par["0metadata"] == serial["0metadata"]
+    assert len(par["0chars"]) == len(serial["0chars"]) and par["0offsets"] == serial["0offsets"]
+
+    def records(db):
+        lengths = np.frombuffer(db["0lengths"], dtype=np.int32)
+        offsets = np.frombuffer(db["0offsets"], dtype=np.uint64)
+        hoff = np.frombuffer(db["0headeroffsets"], dtype=np.uint64)
+        return [(int(lengths[i]), db["0headers"][int(hoff[i]):int(hoff[i + 1])],
+                 db["0chars"][int(offsets[i]):int(offsets[i + 1])]) for i in range(len(lengths))]
+
+    rp, rs = records(par), records(serial)
+    assert sorted(rp) == sorted(rs)
+    # stability: among equal lengths the input order (the header carries the input index) is kept
+    headers, _ = O.read_fasta(fasta)
+    pos = {h.encode(): i for i, h in enumerate(headers)}
+    for (l0, h0, _), (l1, h1, _) in zip(rp, rp[1:]):
+        assert l0 < l1 or (l0 == l1 and pos[h0] < pos[h1])
+
+
 def test_makedb_roundtrip_content(tmp_path):
     """Without the reference: decoded DB content equals the input, sorted by length, padded to 4 with 20."""
     rng = np.random.default_rng(5)
