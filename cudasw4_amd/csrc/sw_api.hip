@@ -408,8 +408,16 @@ int sw_rescore_overflow(sw_ctx* ctx, int kind, const int32_t* ovf_pos, const int
 }
 
 // ------------------------------------------------------------------ top-K
-// v1: stable descending radix sort of (score, id) pairs, first k copied out.  Stability keeps the
-// input order among equal scores, i.e. ascending id for the driver's position-ordered result lists.
+// Replaces the reference's thrust sort_by_key / merge_by_key over ALL scores (cudasw4.cuh:1376-1401).
+//   * small inputs, or k >= n: stable descending radix sort of (score, id) pairs, first k copied out;
+//   * otherwise a radix SELECT: the composite key (orderable score bits, ~position) is unique, so exactly k
+//     elements lie at or above the k-th largest key.  Six histogram passes of 11/11/10 bits (three over the
+//     score, three over the position among the ties at the threshold score — skipped on the device when the
+//     ties are all taken) find that key reading 4 bytes per element per pass; one more pass compacts the k
+//     winners, which are then sorted by their 64-bit keys.  No host round trip: every decision is taken by a
+//     one-workgroup kernel that updates a small state block.
+// Both paths return the same list: descending score, equal scores in input (position) order — the order the
+// driver's position-ordered result lists turn into ascending ids.
 
 namespace {
 struct TopkLayout {
@@ -435,12 +443,138 @@ __global__ void topk_copy_kernel(const float* keys, const int32_t* vals, int64_t
         out_i[i] = i < n ? vals[i] : -1;
     }
 }
+
+// ---- radix select
+constexpr int kSelBins = 2048;
+constexpr int kSelPasses = 6;                      // digits of the 64-bit composite key, most significant first
+__constant__ const int kSelShift[kSelPasses] = {53, 42, 32, 21, 10, 0};
+__constant__ const int kSelBits[kSelPasses] = {11, 11, 10, 11, 11, 10};
+
+struct TopkState {
+    unsigned long long prefix;      // digits of the k-th largest key decided so far (high bits)
+    unsigned long long decided;     // mask of the decided bits
+    unsigned long long remaining;   // how many elements are still to be taken from the current bucket
+    unsigned int skip_rest;         // the whole current bucket is taken: no further passes needed
+    unsigned int out_count;         // compaction cursor
+    unsigned int hist[kSelBins];
+};
+
+__device__ __forceinline__ unsigned long long topk_key(float score, unsigned int pos) {
+    unsigned int u = __float_as_uint(score);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;  // monotonic: larger float -> larger unsigned
+    return ((unsigned long long)u << 32) | (unsigned long long)(~pos);
+}
+
+__global__ void topk_init_kernel(TopkState* st, int k) {
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) st->hist[i] = 0;
+    if (threadIdx.x == 0) { st->prefix = 0; st->decided = 0; st->remaining = (unsigned long long)k; st->skip_rest = 0; st->out_count = 0; }
+}
+
+__global__ void __launch_bounds__(256) topk_hist_kernel(const float* __restrict__ scores, int64_t n, TopkState* st, int pass) {
+    if (st->skip_rest) return;
+    __shared__ unsigned int h[kSelBins];
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const unsigned long long prefix = st->prefix, decided = st->decided;
+    const int shift = kSelShift[pass];
+    const unsigned int mask = (1u << kSelBits[pass]) - 1u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = topk_key(scores[i], (unsigned int)i);
+        if ((key & decided) == prefix) atomicAdd(&h[(unsigned int)(key >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x)
+        if (h[i]) atomicAdd(&st->hist[i], h[i]);
+}
+
+// one workgroup: walk the histogram from the top bin down to the bin that holds the `remaining`-th element
+__global__ void __launch_bounds__(256) topk_pick_kernel(TopkState* st, int pass) {
+    if (st->skip_rest) return;
+    __shared__ unsigned int h[kSelBins];
+    __shared__ unsigned long long part[256];
+    const int nb = 1 << kSelBits[pass];
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) { h[i] = i < nb ? st->hist[i] : 0u; }
+    __syncthreads();
+    // thread t owns bins [nb - 8(t+1), nb - 8t) (descending): sum, then a serial scan over 256 partial sums by thread 0
+    constexpr int per = kSelBins / 256;
+    unsigned long long mine = 0;
+    for (int j = 0; j < per; j++) { const int b = kSelBins - 1 - (threadIdx.x * per + j); mine += h[b]; }
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long need = st->remaining, above = 0;
+        int t = 0;
+        while (t < 255 && above + part[t] < need) { above += part[t]; t++; }
+        int b = kSelBins - 1 - t * per;
+        for (int j = 0; j < per - 1 && above + h[b] < need; j++) { above += h[b]; b--; }
+        // bin b holds the element: everything above it is taken
+        const int shift = kSelShift[pass];
+        st->prefix |= (unsigned long long)b << shift;
+        st->decided |= (unsigned long long)((1u << kSelBits[pass]) - 1u) << shift;
+        st->remaining = need - above;
+        if (st->remaining == h[b]) st->skip_rest = 1;  // the whole bin is taken: its elements need no further ordering
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) st->hist[i] = 0;
+}
+
+// winners: keys above the decided prefix, or inside it (all of them when skip_rest, else the prefix is a full key)
+__global__ void __launch_bounds__(256) topk_compact_kernel(const float* __restrict__ scores, const int32_t* __restrict__ ids, int64_t n,
+                                                           TopkState* st, int k, unsigned long long* out_keys, int32_t* out_ids) {
+    const unsigned long long prefix = st->prefix, decided = st->decided;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = topk_key(scores[i], (unsigned int)i);
+        if ((key & decided) >= prefix) {
+            const unsigned int slot = atomicAdd(&st->out_count, 1u);
+            if (slot < (unsigned int)k) { out_keys[slot] = key; out_ids[slot] = ids[i]; }
+        }
+    }
+}
+
+__global__ void topk_emit_kernel(const unsigned long long* keys, const int32_t* vals, int k, float* out_s, int32_t* out_i) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) {
+        unsigned int u = (unsigned int)(keys[i] >> 32);
+        u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+        out_s[i] = __uint_as_float(u);
+        out_i[i] = vals[i];
+    }
+}
+
+struct SelectLayout {
+    size_t state_off, keys_a, keys_b, vals_a, vals_b, cub_off, cub_bytes, total;
+};
+SelectLayout select_layout(int k) {
+    SelectLayout L{};
+    size_t cub = 0;
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                       (const int32_t*)nullptr, (int32_t*)nullptr, std::max(k, 1));
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    L.state_off = 0;
+    L.keys_a = al(sizeof(TopkState));
+    L.keys_b = L.keys_a + al((size_t)k * 8);
+    L.vals_a = L.keys_b + al((size_t)k * 8);
+    L.vals_b = L.vals_a + al((size_t)k * 4);
+    L.cub_off = L.vals_b + al((size_t)k * 4);
+    L.cub_bytes = cub;
+    L.total = L.cub_off + al(cub);
+    return L;
+}
+
+// the select pays off once the sort's passes over all n pairs dominate; CUDASW4_AMD_TOPK=sort|select forces a path (tests)
+bool use_select(int64_t n, int k) {
+    const char* force = getenv("CUDASW4_AMD_TOPK");
+    if (k >= n) return false;
+    if (force && force[0] == 's' && force[1] == 'o') return false;
+    if (force && force[0] == 's' && force[1] == 'e') return true;
+    return n >= (int64_t(1) << 17) && (int64_t)k * 8 <= n;
+}
 }  // namespace
 
 size_t sw_topk_temp_bytes(int64_t n, int k) {
-    (void)k;
-    if (n <= 0) return 0;
-    return topk_layout(n).total;
+    if (n <= 0 || k <= 0) return 0;
+    // sized for either path, so that a forced path (tests) never outgrows a buffer sized by this call
+    return std::max(topk_layout(n).total, k < n ? select_layout(k).total : size_t(0));
 }
 
 int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int k, float* out_scores,
@@ -451,10 +585,33 @@ int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int
     if (!out_scores || !out_ids) return fail(SW_ERR_INVALID, "null output");
     SW_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n > 0 && (!scores || !ids)) return fail(SW_ERR_INVALID, "null input");
+    if (n > 0 && use_select(n, k)) {
+        const SelectLayout L = select_layout(k);
+        if (!temp || temp_bytes < L.total) return fail(SW_ERR_TEMP, "temp buffer too small for top-K");
+        char* base = static_cast<char*>(temp);
+        TopkState* st = reinterpret_cast<TopkState*>(base + L.state_off);
+        auto* keys_a = reinterpret_cast<unsigned long long*>(base + L.keys_a);
+        auto* keys_b = reinterpret_cast<unsigned long long*>(base + L.keys_b);
+        auto* vals_a = reinterpret_cast<int32_t*>(base + L.vals_a);
+        auto* vals_b = reinterpret_cast<int32_t*>(base + L.vals_b);
+        const int grid = (int)std::min<int64_t>((n + 256 * 16 - 1) / (256 * 16), (int64_t)std::max(1, ctx->num_cus) * 8);
+        hipLaunchKernelGGL(topk_init_kernel, dim3(1), dim3(256), 0, s, st, k);
+        for (int pass = 0; pass < kSelPasses; pass++) {
+            hipLaunchKernelGGL(topk_hist_kernel, dim3(grid), dim3(256), 0, s, scores, n, st, pass);
+            hipLaunchKernelGGL(topk_pick_kernel, dim3(1), dim3(256), 0, s, st, pass);
+        }
+        hipLaunchKernelGGL(topk_compact_kernel, dim3(grid), dim3(256), 0, s, scores, ids, n, st, k, keys_a, vals_a);
+        SW_HIP(hipGetLastError());
+        size_t cub = L.cub_bytes;
+        SW_HIP(hipcub::DeviceRadixSort::SortPairsDescending(base + L.cub_off, cub, keys_a, keys_b, vals_a, vals_b, k, 0, 64, s));
+        hipLaunchKernelGGL(topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, s, keys_b, vals_b, k, out_scores, out_ids);
+        SW_HIP(hipGetLastError());
+        return SW_OK;
+    }
     float* keys = nullptr;
     int32_t* vals = nullptr;
     if (n > 0) {
-        if (!scores || !ids) return fail(SW_ERR_INVALID, "null input");
         const TopkLayout L = topk_layout(n);
         if (!temp || temp_bytes < L.total) return fail(SW_ERR_TEMP, "temp buffer too small for top-K");
         char* base = static_cast<char*>(temp);

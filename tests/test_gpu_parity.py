@@ -156,6 +156,33 @@ def test_topk_matches_oracle_order():
     assert res.reference_ids.tolist() == ei.tolist()
 
 
+@pytest.mark.parametrize("n,k,hi", [(200_000, 10, 40), (200_000, 1000, 3000), (300_001, 25, 2), (1_000_000, 10, 1),
+                                    (150_000, 7, 1 << 20), (131_072, 16_384, 50)])
+def test_topk_select_equals_sort_and_oracle(n, k, hi, monkeypatch):
+    """sw_topk's radix select (large n) against its full-sort path and the oracle's top-K: heavy ties (few distinct
+    scores: the ties at the threshold are broken by position), all-equal scores, nearly distinct scores, a large k."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(n + k)
+    scores_i = rng.integers(0, hi, n).astype(np.int32)
+    es, ei = O.topk(scores_i, k)
+    ctx = capi.Context(0)
+    d_s = torch.from_numpy(scores_i.astype(np.float32)).cuda()
+    d_i = torch.arange(1000, 1000 + n, dtype=torch.int32, device="cuda")  # ids need not equal positions
+    got = {}
+    for path in ("sort", "select"):
+        monkeypatch.setenv("CUDASW4_AMD_TOPK", path)
+        tb = capi.topk_temp_bytes(n, k)
+        temp = torch.empty(tb, dtype=torch.uint8, device="cuda")
+        out_s = torch.full((k,), -7.0, dtype=torch.float32, device="cuda")
+        out_i = torch.full((k,), -7, dtype=torch.int32, device="cuda")
+        ctx.topk(d_s.data_ptr(), d_i.data_ptr(), n, k, out_s.data_ptr(), out_i.data_ptr(), temp.data_ptr(), tb, 0)
+        torch.cuda.synchronize()
+        got[path] = (out_s.cpu().numpy().astype(np.int64).tolist(), (out_i.cpu().numpy().astype(np.int64) - 1000).tolist())
+    assert got["select"] == got["sort"]
+    assert got["select"][0] == es.tolist() and got["select"][1] == ei.tolist()
+    ctx.close()
+
+
 def test_full_size_peak_db_property():
     """BASELINE config 2 at full size (10^6 x 512): every subject is the same sequence, so every
     one of the 10^6 scores must equal the reference-DP golden score; a checksum covers all slots."""
