@@ -441,7 +441,9 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         u32 upH, F;
         if constexpr (MULTI) {
             upH = dpp<SHR1, false>(first ? bH : inH, st.Hlast);
-            F = dpp<SHR1, false>(first ? 0u : inF, st.Fout);
+            // no select for F: in the first stripe lane 0 reads the zeros array (the kind's unraised zero pattern),
+            // which lies below every zero level — "no vertical gap" as well as any other value down there
+            F = dpp<SHR1, false>(inF, st.Fout);
         } else {
             upH = dpp<SHR1, false>(bH, st.Hlast);
             // any F below the column's zero level is "no vertical gap": bound_ctrl zero fill (pattern 0 is below every

@@ -1,5 +1,6 @@
 #!/bin/bash
-# scratch: full round-1 measurement pass on the GPU box (results under gpurun_out/final/)
+# Full measurement pass on the GPU box (via gpurun): GPU tests, bench line, peak sweep, Swiss-Prot-like DB, the align
+# command line resident and streamed, rocprof stats + PMC.  Results under gpurun_out/final/ (copy what is to be kept into profiles/).
 export TMPDIR=/tmp
 O=gpurun_out/final; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
