@@ -98,6 +98,7 @@ struct Arith<I16X2> {
     static constexpr bool kPacked = true;
     static constexpr int kSubjects = 2;
     static constexpr int kLimit = 25000;  // kernels.cuh:5 MAX_ACC_SHORT
+    static constexpr bool kWindow = true;  // StripeState: zero levels and maxima as windows over a quad
     static constexpr int kBias = 1024;
     static constexpr u32 kZero = (u32)kBias | ((u32)kBias << 16);  // the value 0 in both halves
     // gap scores are <= 0; magnitudes are subtracted (|g| <= 1000 keeps E~ - |g| non-negative)
@@ -146,6 +147,7 @@ struct Arith<F16X2> {
     static constexpr bool kPacked = true;
     static constexpr int kSubjects = 2;
     static constexpr int kLimit = 2048;  // kernels.cuh:4 MAX_ACC_HALF2
+    static constexpr bool kWindow = true;
     static constexpr u32 kZero = 0u;
     static __host__ __device__ u32 half_bits(int v) {
         // exact conversion of a small integer |v| < 2048 to IEEE binary16 bits
@@ -200,6 +202,7 @@ struct Arith<I32> {
     static constexpr bool kPacked = false;
     static constexpr int kSubjects = 1;
     static constexpr int kLimit = 0x7fffffff;
+    static constexpr bool kWindow = true;
     static constexpr u32 kZero = 0u;
     static __host__ __device__ u32 encode_gap(int g) { return (u32)g; }
     static __host__ __device__ u32 encode_score(int s) { return (u32)s; }
@@ -237,6 +240,9 @@ struct Arith<F32> {
     static constexpr bool kPacked = false;
     static constexpr int kSubjects = 1;
     static constexpr int kLimit = 0x7fffffff;
+    // the fp32 kernels (168 VGPRs for three waves per SIMD) spill in their loops with the 7 extra window registers
+    // (7.9 -> 1.6 TCUPS): they add a per step to P zero levels and P maxima instead
+    static constexpr bool kWindow = false;
     static constexpr u32 kZero = 0u;
     static __host__ __device__ u32 encode_gap(int g) { return __builtin_bit_cast(u32, (float)g); }
     static __host__ __device__ u32 encode_score(int s) { return __builtin_bit_cast(u32, (float)s); }
@@ -382,8 +388,13 @@ struct StripeState {
     u32 Fout;      // vertical gap state leaving the lane's bottom row after the last step
     u32 yA, yB;    // LDS byte address (+16 bias) of the lane's chunk for the current letter(s); packed kinds with
                    // 16-lane groups keep both in yA (B's address in the upper half)
-    u32 maxv[P];   // running maximum (OFFS: one per row class, each in its class's frame)
-    u32 Zc[P + 1]; // OFFS: Zc[k] = zero level of the column this lane enters next, raised by a*k (k = class, or class + 1)
+    // OFFS: windows over the four steps of a quad.  With j0 the column the lane works on in the quad's first step,
+    //   Zc[i]   = zero level of column j0 raised by a*i: step q uses Zc[q + k] for class k (or class + 1) — the zero levels
+    //             of consecutive columns and classes are the same numbers, so nothing is added per step;
+    //   maxv[d] = running maximum of all cells whose frame is a*(c_j0 + d): step q folds class c into maxv[q + c].
+    // Both move up by 4a once per quad (2P + 7 additions instead of 8P per quad).  The plain form uses maxv[0] only.
+    u32 maxv[P + 3];
+    u32 Zc[P + 4];
 };
 
 // One anti-diagonal step of one lane: R cells (or R cell pairs).
@@ -437,7 +448,8 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         // max3).  What a lane passes on (Hlast) stays in the frame of its last row's class; the profile entry of a row
         // carries s + a*(1 + class - class of the row above) (sw_build_profile_kernel), which makes row 0 consistent.
         constexpr int kLastClass = (R - 1) % P;
-        const u32 bH = st.Zc[kLastClass];  // the local-alignment boundary H = 0 as row 0's diagonal expects it
+        constexpr int Q = A::kWindow ? BYTE : 0;  // step within the quad == which letter byte feeds lane 0
+        const u32 bH = st.Zc[Q + kLastClass];  // the local-alignment boundary H = 0 as row 0's diagonal expects it
         u32 upH, F;
         if constexpr (MULTI) {
             upH = dpp<SHR1, false>(first ? bH : inH, st.Hlast);
@@ -454,9 +466,11 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         st.upH_prev = upH;
         // the running maxima travel in the moving frame: raised by a per step like everything else, so the rows'
         // maxima fold straight into them (converted back to true scores once per stripe)
+        // the running maxima live in moving frames (st.maxv): the rows' maxima fold straight into the accumulator of
+        // their frame (converted back to true scores once per stripe)
         u32 m[P];
 #pragma unroll
-        for (int c = 0; c < P; c++) m[c] = A::add(st.maxv[c], apos);
+        for (int c = 0; c < P; c++) m[c] = A::kWindow ? st.maxv[Q + c] : A::add(st.maxv[c], apos);
         // The rows are software-pipelined by hand: the chain h -> h+G -> max3 -> next row's h is serial, and on
         // gfx950 a packed op that reads the result of the instruction right before it costs a wait state, so the
         // independent work (score lookup and diagonal term of the rows ahead, the E update, the maximum) is
@@ -489,7 +503,7 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int c = r % P;
-            const u32 zop = st.Zc[c + 1];
+            const u32 zop = st.Zc[Q + c + 1];
             if constexpr (G::kWide) {
                 if (r % 4 == 0) __builtin_amdgcn_sched_barrier(0);
                 t_next = tq[r];
@@ -514,9 +528,11 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
             st.H[r] = h;
         }
 #pragma unroll
-        for (int c = 0; c < P; c++) st.maxv[c] = m[c];
+        for (int c = 0; c < P; c++) st.maxv[Q + c] = m[c];
+        if constexpr (!A::kWindow) {
 #pragma unroll
-        for (int k = (kLastClass == 0 ? 0 : 1); k <= P; k++) st.Zc[k] = A::add(st.Zc[k], apos);
+            for (int k = (kLastClass == 0 ? 0 : 1); k <= P; k++) st.Zc[k] = A::add(st.Zc[k], apos);
+        }
         st.Hlast = st.H[R - 1];
         st.Fout = F;
         return;
@@ -665,6 +681,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 
     // OFFS: a lane starts every stripe "at column -lane": zero level a*(LANES - lane), +a per step
     const u32 apos = OFFS ? A::pos_word(p.gex_mag) : 0u;
+    const u32 apos4 = OFFS ? A::pos_word(4 * p.gex_mag) : 0u;
     // frame lowering exists in the packed kernels only: a 32-bit frame has room for any subject (a second copy of the
     // loop body would only cost the occupancy-bounded 32-bit kernels registers)
     constexpr bool kLowers = OFFS && A::kPacked;
@@ -721,18 +738,18 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             StripeState<KIND, R, P> st;
             {
                 // zero levels of the column before the lane's first one, per class (zc[k] = zbefore + a*k)
-                u32 zc[P + 2];
+                u32 zc[P + 5];
                 zc[0] = zbefore; zc[1] = zstart;
 #pragma unroll
-                for (int k = 2; k < P + 2; k++) zc[k] = A::add(zc[k - 1], apos);
+                for (int k = 2; k < P + 5; k++) zc[k] = A::add(zc[k - 1], apos);
 #pragma unroll
                 for (int r = 0; r < R; r++) { st.H[r] = zc[r % P]; st.E[r] = zc[r % P + 1]; }
                 st.upH_prev = zc[(R - 1) % P]; st.Hlast = zc[(R - 1) % P]; st.Fout = zbefore;
 #pragma unroll
-                for (int k = 0; k <= P; k++) st.Zc[k] = zc[k + 1];
+                for (int k = 0; k < P + 4; k++) st.Zc[k] = zc[k + 1];
                 // OFFS: true score -> frame of the column before the first
 #pragma unroll
-                for (int c = 0; c < P; c++) st.maxv[c] = OFFS ? A::add(maxv, zc[c]) : maxv;
+                for (int d = 0; d < P + 3; d++) st.maxv[d] = OFFS ? A::add(maxv, zc[A::kWindow ? d + 1 : d]) : maxv;
             }
             st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
             st.yB = st.yA;
@@ -793,9 +810,9 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     for (int r = 0; r < R; r++) { st.H[r] = A::gap(st.H[r], gw); st.E[r] = A::gap(st.E[r], gw); }
                     st.upH_prev = A::gap(st.upH_prev, gw);
 #pragma unroll
-                    for (int k = 0; k <= P; k++) st.Zc[k] = A::gap(st.Zc[k], gw);
+                    for (int k = 0; k < P + 4; k++) st.Zc[k] = A::gap(st.Zc[k], gw);
 #pragma unroll
-                    for (int c = 0; c < P; c++) st.maxv[c] = A::gap(st.maxv[c], gw);
+                    for (int d = 0; d < P + 3; d++) st.maxv[d] = A::gap(st.maxv[d], gw);
                 };
                 if constexpr (LOWER) lower_frame(lower_lane + 0);
                 dp_step<KIND, R, LANES, 0, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first, p.wrap_class, p.wrap_last);
@@ -811,6 +828,12 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 if constexpr (MULTI) { outH[3] = st.Hlast; outF[3] = st.Fout; outH += walkOut; outF += walkOut; }
                 lettersA = dpp<SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
+                if constexpr (OFFS && A::kWindow) {  // the windows move on by four columns
+#pragma unroll
+                    for (int k = 0; k < P + 4; k++) st.Zc[k] = A::add(st.Zc[k], apos4);
+#pragma unroll
+                    for (int d = 0; d < P + 3; d++) st.maxv[d] = A::add(st.maxv[d], apos4);
+                }
             };
             // the quads in which lanes lower their frame (the first LANES/4 of every K/4 quads but the first) run a second
             // copy of the loop body, so that the others pay nothing for it
@@ -836,11 +859,18 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 }
             }
             if constexpr (OFFS) {
-                // frames of the lane's last column -> true score (Zc[c + 1] is the NEXT column's level of class c + 1: 2a above)
-                maxv = A::true_of(st.maxv[0], A::gap(A::gap(st.Zc[1], p.gex), p.gex));
+                if constexpr (A::kWindow) {
+                    // accumulator d and zero level d are in the same frame -> true scores
+                    maxv = A::true_of(st.maxv[0], st.Zc[0]);
 #pragma unroll
-                for (int c = 1; c < P; c++)
-                    maxv = A::true_max(maxv, A::true_of(st.maxv[c], A::gap(A::gap(st.Zc[c + 1], p.gex), p.gex)));
+                    for (int d = 1; d < P + 3; d++) maxv = A::true_max(maxv, A::true_of(st.maxv[d], st.Zc[d]));
+                } else {
+                    // Zc[c + 1] is the NEXT column's level of class c + 1: 2a above the accumulator's frame
+                    maxv = A::true_of(st.maxv[0], A::gap(A::gap(st.Zc[1], p.gex), p.gex));
+#pragma unroll
+                    for (int c = 1; c < P; c++)
+                        maxv = A::true_max(maxv, A::true_of(st.maxv[c], A::gap(A::gap(st.Zc[c + 1], p.gex), p.gex)));
+                }
             } else {
                 maxv = st.maxv[0];
             }
