@@ -342,14 +342,20 @@ __device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned ch
 // Row classes of the column-offset frame (dp_step<OFFS>): lane-local row r belongs to class r mod P and is kept raised
 // by a further a * (r mod P).  P = 1 is the plain column frame.
 #ifndef SWK_CLASSES_PACKED
-#define SWK_CLASSES_PACKED 4
+#define SWK_CLASSES_PACKED 8
+#endif
+#ifndef SWK_CLASSES_PACKED_SMALL
+#define SWK_CLASSES_PACKED_SMALL 4
 #endif
 #ifndef SWK_CLASSES_SCALAR
 #define SWK_CLASSES_SCALAR 4
 #endif
 constexpr int frame_classes(bool packed, int R, int lanes) {
     (void)lanes;
-    const int want = packed ? SWK_CLASSES_PACKED : SWK_CLASSES_SCALAR;
+    // packed kinds: 8 classes for the tall kernels (two waves per SIMD anyway: 0.125 instead of 0.25 wrap subtractions per
+    // cell pair for 8 more registers, +0.8 % on the peak benchmark); up to R = 24 four, which keeps those kernels at
+    // three waves per SIMD.  32-bit kinds: four (register-bound by their occupancy).
+    const int want = packed ? (R >= 25 ? SWK_CLASSES_PACKED : SWK_CLASSES_PACKED_SMALL) : SWK_CLASSES_SCALAR;
     int P = want;
     while (P > 1 && 2 * P > R) P--;  // at least two rows per class, so that the running maximum still folds two rows per max3
     return P;
