@@ -205,8 +205,8 @@ def main():
             valu_peak_instr = 256 * 99.5 * 2.4e9
         # VALU instructions the kernel issues per cell (pair), static count from the gfx950 ISA of the loop bodies
         # the 20 queries run (column-offset recurrence with row classes, wide profile words for the packed kinds;
-        # multi-stripe R = 32..44: 6.34..6.48 incl. per-step overhead; 32-bit kinds R = 32: 6.40), DESIGN.md §2
-        instr_per_unit = {0: 6.4, 1: 6.4, 2: 6.4, 3: 6.4}[kind]
+        # multi-stripe R = 32..44: 6.11..6.3 incl. per-step overhead; 32-bit kinds R = 32: 6.25 int32, 6.40 fp32), DESIGN.md §2
+        instr_per_unit = {0: 6.2, 1: 6.2, 2: 6.25, 3: 6.4}[kind]
         units_per_s = kern_gcups * 1e9 / (2 if packed else 1)
         achieved_instr = units_per_s * instr_per_unit
         traffic = None
