@@ -450,8 +450,8 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
     if constexpr (OFFS) {
         // Row classes: lane-local row r (class p = r mod P) is kept raised by a further a*p.  F then needs its "- a" only
         // where the class wraps (every P rows, and after the lane's last row: by a*(p+1), back to class 0), E and F of a
-        // row share the zero level Zc[p+1], and the running maximum is kept per class (rows r and r+P fold into one
-        // max3).  What a lane passes on (Hlast) stays in the frame of its last row's class; the profile entry of a row
+        // row share the zero level Zc[Q+p+1], and the running maximum is kept per class (rows r and r+P fold into one
+        // max3; StripeState explains the windows Zc / maxv and the step index Q).  What a lane passes on (Hlast) stays in the frame of its last row's class; the profile entry of a row
         // carries s + a*(1 + class - class of the row above) (sw_build_profile_kernel), which makes row 0 consistent.
         constexpr int kLastClass = (R - 1) % P;
         constexpr int Q = A::kWindow ? BYTE : 0;  // step within the quad == which letter byte feeds lane 0
@@ -470,8 +470,6 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         }
         u32 diag = st.upH_prev;
         st.upH_prev = upH;
-        // the running maxima travel in the moving frame: raised by a per step like everything else, so the rows'
-        // maxima fold straight into them (converted back to true scores once per stripe)
         // the running maxima live in moving frames (st.maxv): the rows' maxima fold straight into the accumulator of
         // their frame (converted back to true scores once per stripe)
         u32 m[P];
