@@ -384,6 +384,25 @@ __device__ __forceinline__ void lds_read_words2(u32 (&da)[NW], u32 (&db)[NW], co
     }
 }
 
+// one 16-byte chunk (the last one may be shorter) of both letters; k folds to a constant in the unrolled callers
+template <int NW, int CHUNK_ROW_BYTES>
+__device__ __forceinline__ void lds_read_chunk2(u32 (&da)[NW], u32 (&db)[NW], const unsigned char* pa, const unsigned char* pb, int k) {
+    constexpr int N4 = NW / 4, REM = NW % 4;
+    if (k < N4) {
+        const uint4 va = *reinterpret_cast<const uint4*>(pa + k * CHUNK_ROW_BYTES);
+        const uint4 vb = *reinterpret_cast<const uint4*>(pb + k * CHUNK_ROW_BYTES);
+        da[4 * k + 0] = va.x; da[4 * k + 1] = va.y; da[4 * k + 2] = va.z; da[4 * k + 3] = va.w;
+        db[4 * k + 0] = vb.x; db[4 * k + 1] = vb.y; db[4 * k + 2] = vb.z; db[4 * k + 3] = vb.w;
+    } else if (REM != 0 && k == N4) {
+        u32 ta[REM ? REM : 1], tb[REM ? REM : 1];
+        lds_read_words<(REM ? REM : 1), CHUNK_ROW_BYTES>(ta, pa + N4 * CHUNK_ROW_BYTES);
+        lds_read_words<(REM ? REM : 1), CHUNK_ROW_BYTES>(tb, pb + N4 * CHUNK_ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < REM; i++) { da[4 * N4 + i] = ta[i]; db[4 * N4 + i] = tb[i]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep this issue order (the scheduler would sort the reads by register)
+}
+
 // Per-group DP state that lives across the steps of one stripe.
 template <int KIND, int R, int P = 1>
 struct StripeState {
@@ -435,7 +454,7 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         constexpr u32 kSel2 = ((u32)(4 + BYTE) << 24) | 0x000c000cu | ((u32)BYTE << 8);  // B's byte -> 31:24, A's -> 15:8
         const u32 inj = __builtin_amdgcn_perm(lettersB, lettersA, kSel2);
         st.yA = dpp<SHR1, false>(inj, st.yA) + 0x00100010u;
-        lds_read_words2<G::NW, G::kChunkRowBytes>(wa, wb, tile + (st.yA & 0xffffu), tile + (st.yA >> 16));
+        if constexpr (!OFFS) lds_read_words2<G::NW, G::kChunkRowBytes>(wa, wb, tile + (st.yA & 0xffffu), tile + (st.yA >> 16));
     } else {
         const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel) << kPostShift;
         st.yA = dpp<SHR1, false>(injA, st.yA) + 16u;
@@ -496,8 +515,16 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
 #define SWK_LOOKAHEAD 12
 #endif
         constexpr int kAhead = G::kWide ? (SWK_LOOKAHEAD < R ? SWK_LOOKAHEAD : R) : 1;
+        // ... and the LDS reads themselves are issued progressively: the chunks the first kAhead + 4 rows need at the top
+        // of the step, chunk k + kChunks0 when the chain reaches row 4k — a few chunks are in flight instead of all
+        // (2R registers), which is what lets R go up to 48
+        constexpr int kChunks0 = kAhead / 4 + 1, kChunksAll = (G::NW + 3) / 4;
+        const unsigned char* const pa = tile + (st.yA & 0xffffu);
+        const unsigned char* const pb = tile + (st.yA >> 16);
         u32 tq[G::kWide ? R : 1];
         if constexpr (G::kWide) {
+#pragma unroll
+            for (int k = 0; k < kChunks0 && k < kChunksAll; k++) lds_read_chunk2<G::NW, G::kChunkRowBytes>(wa, wb, pa, pb, k);
 #pragma unroll
             for (int r = 0; r < kAhead; r++) tq[r] = A::add_pair(wa[r], wb[r], r == 0 ? diag : st.H[r - 1]);
         }
@@ -509,7 +536,10 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
             const int c = r % P;
             const u32 zop = st.Zc[Q + c + 1];
             if constexpr (G::kWide) {
-                if (r % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                if (r % 4 == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r / 4 + kChunks0 < kChunksAll) lds_read_chunk2<G::NW, G::kChunkRowBytes>(wa, wb, pa, pb, r / 4 + kChunks0);
+                }
                 t_next = tq[r];
             }
             const u32 t = t_next;

@@ -12,9 +12,9 @@ namespace swk {
 constexpr int kRowsGranule = 1;
 // standard shape (16-lane groups)
 #ifndef SWK_MAX_ROWS_PACKED
-#define SWK_MAX_ROWS_PACKED 44
+#define SWK_MAX_ROWS_PACKED 48
 #endif
-constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 704 query rows, 59 KB tile of wide words; 256 VGPRs as a multi-stripe kernel (2 waves/SIMD)
+constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 768 query rows, 63 KB tile of wide words (two workgroups per CU, LDS addresses stay below 64 KB); 256 VGPRs (2 waves/SIMD)
 #ifndef SWK_MAX_ROWS_SCALAR
 #define SWK_MAX_ROWS_SCALAR 32
 #endif
@@ -98,7 +98,7 @@ constexpr size_t tile_bytes_r() {
 }
 
 #define SWK_FOR_EACH_R_PACKED(X) \
-    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44)
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48)
 #define SWK_FOR_EACH_R_SCALAR(X) \
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 

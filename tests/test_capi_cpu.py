@@ -40,8 +40,8 @@ def test_version_and_plan_without_gpu(built):
     for kind in (capi.KIND_F16X2, capi.KIND_I16X2):
         for q in (1, 63, 64, 65, 144, 512, 513, 5478, 40000):
             r, s = capi.plan_query(kind, q)
-            assert 1 <= r <= 44 and 16 * r * s >= q > 16 * r * s - 16 * s   # padding below one row per lane and stripe
-            assert (q + 703) // 704 <= s <= (q + 703) // 704 + 2
+            assert 1 <= r <= 48 and 16 * r * s >= q > 16 * r * s - 16 * s   # padding below one row per lane and stripe
+            assert (q + 767) // 768 <= s <= (q + 767) // 768 + 2
     for kind in (capi.KIND_I32, capi.KIND_F32):
         for q in (1, 256, 257, 5478):
             r, s = capi.plan_query(kind, q)
