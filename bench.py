@@ -203,10 +203,11 @@ def main():
             # fp32 kind: v_add_f32 (VOP2) co-issues with v_max3_f32 (VOP3); the 8:7 mix of the loop sustains
             # 99.5 lanes/clk/CU in tools/ubench/mix_rate.hip
             valu_peak_instr = 256 * 99.5 * 2.4e9
-        # VALU instructions the kernel issues per cell (pair), static count from the gfx950 ISA of the loop bodies
-        # the 20 queries run (column-offset recurrence with row classes, wide profile words for the packed kinds;
-        # multi-stripe R = 32..44: 6.11..6.3 incl. per-step overhead; 32-bit kinds R = 32: 6.25 int32, 6.40 fp32), DESIGN.md §2
-        instr_per_unit = {0: 6.2, 1: 6.2, 2: 6.25, 3: 6.4}[kind]
+        # VALU instructions issued per USEFUL cell (pair).  Packed kinds: measured over the whole 20-query pass with PMC
+        # (SQ_INSTS_VALU x 64 lanes / cell pairs, profiles/r01_bench_half2_pmc.txt: 6.34; it contains row padding,
+        # pipeline fill and the per-step work; the static count of the loop bodies is 6.05..6.3 per cell pair for
+        # R = 32..48).  32-bit kinds: static count from the gfx950 ISA at R = 32
+        instr_per_unit = {0: 6.34, 1: 6.34, 2: 6.25, 3: 6.4}[kind]
         units_per_s = kern_gcups * 1e9 / (2 if packed else 1)
         achieved_instr = units_per_s * instr_per_unit
         traffic = None
