@@ -226,7 +226,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
         }
         p.gex_mag = a;
         {   // row classes of the kernel that plan (rows, lanes) selects: lowering words at the class wrap / the last row
-            const int P = swk::frame_classes(kl->packed, pl.rows, lanes);
+            const int P = swk::frame_classes(kl->packed, pl.rows, lanes, multi);
             const int wrap = -a * P, wrap_last = -a * ((pl.rows - 1) % P + 1);
             switch (kind) {
                 case SW_KIND_F16X2: p.wrap_class = swk::Arith<swk::F16X2>::encode_gap(wrap); p.wrap_last = swk::Arith<swk::F16X2>::encode_gap(wrap_last); break;

@@ -341,6 +341,12 @@ __device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned ch
 
 // Row classes of the column-offset frame (dp_step<OFFS>): lane-local row r belongs to class r mod P and is kept raised
 // by a further a * (r mod P).  P = 1 is the plain column frame.
+// Packed single-stripe kernels up to this many rows per lane are bound to 168 VGPRs = three waves per SIMD (two waves
+// fill 93.5 % of the issue slots at best, three 97 %: tools/ubench/dep_chain.hip); the multi-stripe kernels of the same
+// height would spill (their border state), taller ones need the registers.
+#ifndef SWK_WAVES3_MAX_R
+#define SWK_WAVES3_MAX_R 36
+#endif
 #ifndef SWK_CLASSES_PACKED
 #define SWK_CLASSES_PACKED 8
 #endif
@@ -350,12 +356,13 @@ __device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned ch
 #ifndef SWK_CLASSES_SCALAR
 #define SWK_CLASSES_SCALAR 4
 #endif
-constexpr int frame_classes(bool packed, int R, int lanes) {
+constexpr int frame_classes(bool packed, int R, int lanes, bool multi) {
     (void)lanes;
     // packed kinds: 8 classes for the tall kernels (two waves per SIMD anyway: 0.125 instead of 0.25 wrap subtractions per
-    // cell pair for 8 more registers, +0.8 % on the peak benchmark); up to R = 24 four, which keeps those kernels at
-    // three waves per SIMD.  32-bit kinds: four (register-bound by their occupancy).
-    const int want = packed ? (R >= 25 ? SWK_CLASSES_PACKED : SWK_CLASSES_PACKED_SMALL) : SWK_CLASSES_SCALAR;
+    // cell pair for 8 more registers, +0.8 % on the peak benchmark); the single-stripe kernels up to R = SWK_WAVES3_MAX_R and
+    // everything below R = 25 four, which keeps those at three (or more) waves per SIMD.  32-bit kinds: four (register-bound by their occupancy).
+    const int want = packed ? ((R > SWK_WAVES3_MAX_R || (multi && R >= 25)) ? SWK_CLASSES_PACKED : SWK_CLASSES_PACKED_SMALL)
+                            : SWK_CLASSES_SCALAR;
     int P = want;
     while (P > 1 && 2 * P > R) P--;  // at least two rows per class, so that the running maximum still folds two rows per max3
     return P;
@@ -653,14 +660,11 @@ constexpr int border_junk_words() { return LANES == 16 ? 128 : 320; }  // >= 4*(
 #ifndef SWK_MIN_WAVES_SCALAR
 #define SWK_MIN_WAVES_SCALAR 0
 #endif
-#ifndef SWK_WAVES3_MAX_R
-#define SWK_WAVES3_MAX_R 0
-#endif
 template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
     // packed kinds: 2 waves/SIMD (256 VGPRs) for the tall kernels; up to SWK_WAVES3_MAX_R rows a third wave is asked for
     // (168 VGPRs): two waves cover each other's wait states only ~92 % of the time, three reach the issue peak
-    if (Arith<KIND>::kPacked) return (LANES == 16 && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
+    if (Arith<KIND>::kPacked) return (LANES == 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
     // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
     return (R <= 16 && !MULTI && LANES == 16) ? 4 : 3;
@@ -683,7 +687,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     constexpr int kJunkF = LDSF ? kLdsFJunk : kJunk;
     constexpr int SHL1 = Shift<LANES>::kShl1;
     constexpr int kQuadsPerLetterBlock = LANES;  // a lane holds 4 letters: LANES quads per reload
-    constexpr int P = OFFS ? frame_classes(A::kPacked, R, LANES) : 1;  // row classes of the column-offset frame
+    constexpr int P = OFFS ? frame_classes(A::kPacked, R, LANES, MULTI) : 1;  // row classes of the column-offset frame
     __shared__ __attribute__((aligned(16))) unsigned char lds[16 + G::kTileBytes];
     __shared__ __attribute__((aligned(16))) u32 ldsF[LDSF ? kGroups * kLdsFStride + 16 : 4];
 
@@ -980,7 +984,7 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
                 const int qc = row < qlen ? (int)query[row] : kPadLetter;
                 // OFFS kernels (shift = a): the diagonal step raises the frame by a per column and by a per row class;
                 // the row above lane-local row 0 is the previous lane's last row (dp_step<OFFS>)
-                constexpr int P = frame_classes(A::kPacked, R, LANES);
+                const int P = frame_classes(A::kPacked, R, LANES, nstripes > 1);  // the scan kernel's (MULTI == more than one stripe)
                 const int cls = row_in_lane % P, above = (row_in_lane == 0 ? R - 1 : row_in_lane - 1) % P;
                 return A::encode_score((int)matrix21[qc * kLetters + letter] + shift * (1 + cls - above));
             };
