@@ -347,6 +347,9 @@ __device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned ch
 #ifndef SWK_WAVES3_MAX_R
 #define SWK_WAVES3_MAX_R 36
 #endif
+#ifndef SWK_WAVES4_MAX_R
+#define SWK_WAVES4_MAX_R 22   // ... and up to this many to 128 VGPRs = four waves per SIMD (+1 % at R = 17..22, -0.4 % at 24)
+#endif
 #ifndef SWK_CLASSES_PACKED
 #define SWK_CLASSES_PACKED 8
 #endif
@@ -664,7 +667,7 @@ template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
     // packed kinds: 2 waves/SIMD (256 VGPRs) for the tall kernels; up to SWK_WAVES3_MAX_R rows a third wave is asked for
     // (168 VGPRs): two waves cover each other's wait states only ~92 % of the time, three reach the issue peak
-    if (Arith<KIND>::kPacked) return (LANES == 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
+    if (Arith<KIND>::kPacked) return (LANES == 16 && !MULTI && R <= SWK_WAVES4_MAX_R) ? 4 : (LANES == 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
     // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
     return (R <= 16 && !MULTI && LANES == 16) ? 4 : 3;
