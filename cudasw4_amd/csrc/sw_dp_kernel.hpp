@@ -413,6 +413,22 @@ __device__ __forceinline__ void lds_read_chunk2(u32 (&da)[NW], u32 (&db)[NW], co
     __builtin_amdgcn_sched_barrier(0);  // keep this issue order (the scheduler would sort the reads by register)
 }
 
+// the same for one letter (32-bit kinds)
+template <int NW, int CHUNK_ROW_BYTES>
+__device__ __forceinline__ void lds_read_chunk1(u32 (&da)[NW], const unsigned char* pa, int k) {
+    constexpr int N4 = NW / 4, REM = NW % 4;
+    if (k < N4) {
+        const uint4 va = *reinterpret_cast<const uint4*>(pa + k * CHUNK_ROW_BYTES);
+        da[4 * k + 0] = va.x; da[4 * k + 1] = va.y; da[4 * k + 2] = va.z; da[4 * k + 3] = va.w;
+    } else if (REM != 0 && k == N4) {
+        u32 ta[REM ? REM : 1];
+        lds_read_words<(REM ? REM : 1), CHUNK_ROW_BYTES>(ta, pa + N4 * CHUNK_ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < REM; i++) da[4 * N4 + i] = ta[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Per-group DP state that lives across the steps of one stripe.
 template <int KIND, int R, int P = 1>
 struct StripeState {
@@ -456,6 +472,11 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
     constexpr u32 kSel = 0x0c0c000cu | ((u32)BYTE << 8);  // letter byte BYTE -> bits 15:8
     constexpr int kPostShift = G::kLetterShift - 8;        // row offset = byte << kLetterShift
 
+    // 32-bit kinds, column-offset form: progressive LDS reads like the wide kernels (SWK_PROG_SCALAR=0: all at the top)
+#ifndef SWK_PROG_SCALAR
+#define SWK_PROG_SCALAR 1
+#endif
+    constexpr bool kProgScalar = SWK_PROG_SCALAR != 0;
     // subject letter(s): shift along the group, lane 0 takes the next letter of its subject
     u32 wa[G::NW];
     u32 wb[G::NW];
@@ -468,7 +489,7 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
     } else {
         const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel) << kPostShift;
         st.yA = dpp<SHR1, false>(injA, st.yA) + 16u;
-        lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + st.yA);
+        if constexpr (A::kPacked || !OFFS || !kProgScalar) lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + st.yA);
         if constexpr (A::kPacked) {
             const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel) << kPostShift;
             st.yB = dpp<SHR1, false>(injB, st.yB) + 16u;
@@ -538,6 +559,12 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
 #pragma unroll
             for (int r = 0; r < kAhead; r++) tq[r] = A::add_pair(wa[r], wb[r], r == 0 ? diag : st.H[r - 1]);
         }
+        constexpr bool kProg1 = !A::kPacked && kProgScalar;
+        constexpr int kChunks0S = 2;  // rows 0..7 at the top of the step, chunk k + 2 when the chain reaches row 4k
+        if constexpr (kProg1) {
+#pragma unroll
+            for (int k = 0; k < kChunks0S && k < (G::NW + 3) / 4; k++) lds_read_chunk1<G::NW, G::kChunkRowBytes>(wa, tile + st.yA, k);
+        }
         u32 s_next = score(0);
         u32 t_next = G::kWide ? 0u : diag_term(0, diag, s_next);
         s_next = R > 1 ? score(1) : 0u;
@@ -551,6 +578,12 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
                     if (r / 4 + kChunks0 < kChunksAll) lds_read_chunk2<G::NW, G::kChunkRowBytes>(wa, wb, pa, pb, r / 4 + kChunks0);
                 }
                 t_next = tq[r];
+            }
+            if constexpr (kProg1) {
+                if (r % 4 == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r / 4 + kChunks0S < (G::NW + 3) / 4) lds_read_chunk1<G::NW, G::kChunkRowBytes>(wa, tile + st.yA, r / 4 + kChunks0S);
+                }
             }
             const u32 t = t_next;
             const u32 h = A::cell_h(t, st.E[r], F);
