@@ -80,6 +80,9 @@ __device__ __forceinline__ u32 dpp(u32 old, u32 src) {
 // (E' = max(E,0), F' = max(F,0)), which leaves H = max(diag+s, E', F') unchanged and makes the
 // explicit max(.,0) of the reference recurrence (half2_kernels.cuh:176) free.
 // ------------------------------------------------------------------------------------------------
+#ifndef SWK_F32_WINDOW
+#define SWK_F32_WINDOW 0
+#endif
 template <int KIND>
 struct Arith;
 
@@ -242,7 +245,7 @@ struct Arith<F32> {
     static constexpr int kLimit = 0x7fffffff;
     // the fp32 kernels (168 VGPRs for three waves per SIMD) spill in their loops with the 7 extra window registers
     // (7.9 -> 1.6 TCUPS): they add a per step to P zero levels and P maxima instead
-    static constexpr bool kWindow = false;
+    static constexpr bool kWindow = SWK_F32_WINDOW != 0;
     static constexpr u32 kZero = 0u;
     static __host__ __device__ u32 encode_gap(int g) { return __builtin_bit_cast(u32, (float)g); }
     static __host__ __device__ u32 encode_score(int s) { return __builtin_bit_cast(u32, (float)s); }
