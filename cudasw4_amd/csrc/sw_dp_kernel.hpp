@@ -504,8 +504,9 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         // Row classes: lane-local row r (class p = r mod P) is kept raised by a further a*p.  F then needs its "- a" only
         // where the class wraps (every P rows, and after the lane's last row: by a*(p+1), back to class 0), E and F of a
         // row share the zero level Zc[Q+p+1], and the running maximum is kept per class (rows r and r+P fold into one
-        // max3; StripeState explains the windows Zc / maxv and the step index Q).  What a lane passes on (Hlast) stays in the frame of its last row's class; the profile entry of a row
-        // carries s + a*(1 + class - class of the row above) (sw_build_profile_kernel), which makes row 0 consistent.
+        // max3; StripeState explains the windows Zc / maxv and the step index Q).  What a lane passes on (Hlast) stays
+        // in the frame of its last row's class; the profile entry of a row carries s + a*(1 + class - class of the row
+        // above) (sw_build_profile_kernel), which makes row 0 consistent.
         constexpr int kLastClass = (R - 1) % P;
         constexpr int Q = A::kWindow ? BYTE : 0;  // step within the quad == which letter byte feeds lane 0
         const u32 bH = st.Zc[Q + kLastClass];  // the local-alignment boundary H = 0 as row 0's diagonal expects it
@@ -537,11 +538,8 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
             else if constexpr (A::kPacked) return __builtin_amdgcn_perm(wb[r >> 1], wa[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
             else return wa[r];
         };
-        // diagonal term of row r: d + score(s)
-        auto diag_term = [&](int r, u32 d, u32 sc) -> u32 {
-            if constexpr (G::kWide) return A::add_pair(wa[r], wb[r], d);
-            else return A::add(d, sc);
-        };
+        // diagonal term of a row: d + score (the wide kernels pair and add in one instruction, see tq below)
+        auto diag_term = [&](int, u32 d, u32 sc) -> u32 { return A::add(d, sc); };
         // Wide words: the diagonal terms run kAhead rows ahead of the chain and the scheduler may only reorder within
         // four rows (it would otherwise compute all of them first, in register order, and so wait for the LAST LDS
         // chunk at the top of the step): a row needs its score words only when the chain is kAhead rows away.
