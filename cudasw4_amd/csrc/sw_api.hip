@@ -105,6 +105,7 @@ struct sw_ctx {
     bool have_query = false;
     Profile profiles[4][2][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups][plain | column-offset recurrence]
     bool use_offs = true;        // CUDASW4_AMD_NO_OFFS=1: always the plain recurrence (A/B measurements)
+    int64_t long16_min = -1;     // CUDASW4_AMD_LONG16_MIN: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
 };
 
 namespace {
@@ -114,13 +115,17 @@ int max_grid(const sw_ctx* ctx) { return std::max(1, ctx->num_cus) * ctx->grid_m
 // Reference partitions 34 (1281..8000) and 35 (> 8000) hold the long subjects.  When there are only a few
 // of them (the tail of a real DB) they get the wave-wide group shape: 4x the lanes per alignment, so the
 // giants finish 4x sooner.  When the partition alone can fill the GPU several times (e.g. the L=2048
-// peak DB) the 16-lane shape is more efficient (more rows per lane, less per-step overhead).
+// peak DB) the 16-lane shape is more efficient (more rows per lane, less per-step overhead, wide profile words).
+// Partition 34 takes the 16-lane shape already from 512 subjects up: in a Swiss-Prot-like DB it holds 2.4 % of the
+// sequences but 11 % of the residues, its launch runs next to the bulk launch on a side stream, and a subject of at
+// most 8000 residues is no tail there (Swiss-Prot-like DB: 10.7 -> 11.05 TCUPS).
 // overflowed subjects can have any length: long ones would dominate a 16-lane launch
 int rescore_lanes(int32_t max_subject_len) { return max_subject_len > 1280 ? 64 : 16; }
 
 int lanes_for_partition(const sw_ctx* ctx, int part_id, int32_t n) {
     if (part_id < SW_NUM_LENGTH_PARTITIONS - 2) return 16;
     const int64_t fills_gpu_twice = (int64_t)2 * std::max(1, ctx->num_cus) * 4 * 32;
+    if (part_id == SW_NUM_LENGTH_PARTITIONS - 2) return n >= (ctx->long16_min >= 0 ? ctx->long16_min : 512) ? 16 : 64;
     return n >= fills_gpu_twice ? 16 : 64;
 }
 
@@ -292,6 +297,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     ctx->num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
+    if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = atoll(e);
     hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
