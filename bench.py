@@ -1,24 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py — the reference's peak benchmark (runpeakbenchmark.sh) on MI355X.
+"""bench.py — the reference's benchmarks (runpeakbenchmark.sh / runsprotbenchmark.sh) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload peak|sprot-like] [--scaling strong|weak]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): all 20 queries of allqueries.fasta against the simulated
-equal-length DB (`--pseudodb 1000000 512`: one mt19937(42) sequence replicated 10^6 times, resident
-in HBM), half2 kernel (kind f16x2), BLOSUM62, gop -11, gex -1, --top 0.
-A STEP is one pass of the whole query set over the resident DB (20 scans), the unit the reference's
-"Total time ... GCUPS" line is computed over (main.cu:257-260).  GCUPS = sum |q| * sum |s| / 1e9 / s
-with true lengths (cudasw4.cuh:2264-2271).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a torch.distributed.run child,
+before this process touches the GPU); under torchrun the ranks come from the environment and must match --gpus.
 
-Multi-GPU: the DB is sharded over the ranks (each rank holds --db-size subjects: weak scaling),
-no data-path collective; per-rank top-K lists are merged on the host (search.merge_topk).
+Workloads
+  peak        BASELINE.json configs[1]: all 20 queries of allqueries.fasta against the simulated equal-length DB
+              (`--pseudodb 1000000 512`: one mt19937(42) sequence replicated 10^6 times), half2 kernel (f16x2).
+  sprot-like  configs[2] with a synthetic stand-in for uniprot_sprot (no network): 570 000 sequences, log-normal
+              lengths with a 35 k-residue tail (cudasw4_amd/synthdb.py, seeded), packed-int16 kernels (--dpx).
+Everything runs through the C++ host driver (libcudasw4_host.so == `align`'s SearchDriver) on top of the C ABI;
+BLOSUM62, gop -11, gex -1, DB resident in HBM (--uploadFull), top-K inside the timed region.
 
-Prints ONE JSON line on rank 0 (see the driver contract), including `roofline` and `cpu_baseline`.
+A STEP is one pass of the whole query set over the DB (20 scans incl. overflow re-score, per-GPU top-K and its copy
+to the host, then ONE gather of the per-rank lists and the host-side merge) — the unit the reference's
+"Total time ... GCUPS" line is computed over (main.cu:257-260).  GCUPS = sum |q| * sum |s| / 1e9 / s with true
+lengths (cudasw4.cuh:2264-2271).
+
+Multi-GPU: `--scaling strong` (default): ONE DB is cut into char-balanced shards per length partition
+(partitionDBAmongstGpus, cudasw4.cuh:928-1004), rank r scans shard r; no data-path collective, the per-rank top-K
+lists are merged on the host of rank 0.  `--scaling weak`: every rank scans its own --db-size subjects.
+
+After the timed region every query is scanned once more and EVERY score is checked (peak: against the reference's
+golden scores in tests/golden/ref_scores.json; sprot-like: against the CPU oracle on the cpu_baseline sample, or
+packed-vs-int32 equality of all scores when there is no CPU leg) -> "verified".
+
+Prints ONE JSON line on rank 0 (driver contract), including `roofline` and `cpu_baseline`.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,55 +47,121 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 KIND_BY_NAME = {"half2": 0, "dpxs16": 1, "dpxs32": 2, "float": 3}
 DTYPE_BY_KIND = {0: "f16x2", 1: "i16x2", 2: "i32", 3: "f32"}
+KERNEL_SOURCES = ["cudasw4_amd/csrc/sw_dp_kernel.hpp", "cudasw4_amd/csrc/sw_launch.hpp", "cudasw4_amd/csrc/sw_api.hip",
+                  "cudasw4_amd/csrc/Makefile"]
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--db-size", type=int, default=1_000_000, help="pseudo-DB subjects per GPU")
-    ap.add_argument("--db-length", type=int, default=512, help="pseudo-DB subject length")
-    ap.add_argument("--kernel", choices=sorted(KIND_BY_NAME), default="half2")
-    ap.add_argument("--top", type=int, default=0, help="top-K per query (reference benchmark uses 0)")
+    ap.add_argument("--workload", choices=["peak", "sprot-like"], default="peak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: shard ONE DB over the ranks (strong, default) or give every rank its own DB (weak)")
+    ap.add_argument("--db-size", type=int, default=None, help="subjects of the DB (peak: 1000000, sprot-like: 570000)")
+    ap.add_argument("--db-length", type=int, default=512, help="peak: pseudo-DB subject length")
+    ap.add_argument("--kernel", choices=sorted(KIND_BY_NAME) + ["dpx"], default=None,
+                    help="kernel configuration (peak default: half2; sprot-like default: dpx = DPXs16/DPXs16/DPXs32/DPXs32)")
+    ap.add_argument("--top", type=int, default=10, help="top-K per query inside the timed region (reference scripts: 0)")
+    ap.add_argument("--max-gpu-mem", default="0", help="per-GPU memory limit (K/M/G suffix); small values force batch streaming")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-subjects", type=int, default=60000)
-    return ap.parse_args()
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--cpu-sample-subjects", type=int, default=None)
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(queries, L, nsubj):
-    """Oracle's inter-sequence SIMD scan (kind 'port') on the host cores, bounded sample of the same
-    workload: all 20 queries x `nsubj` pseudo subjects of length L.  The thread count is picked by a short
-    calibration (containers often cap CPU time below the number of visible hardware threads, where more
-    threads only add throttling); `cores` reports the threads actually used."""
+def parse_size(s):
+    s = str(s).strip()
+    mult = {"K": 1 << 10, "M": 1 << 20, "G": 1 << 30}.get(s[-1:].upper(), 1)
+    return int(float(s[:-1]) * mult) if mult > 1 else int(s)
+
+
+def spawn_command(n, argv, port):
+    """The command line that starts n ranks of this script (what the round driver runs itself for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(spawn_command(n, argv, port), env=env)
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_counters():
+    """PMC-derived constants (VALU instructions per cell pair, HBM traffic per launch) are only valid for the kernel
+    sources they were measured on: profiles/kernel_counters.json records the sha of those sources; on a mismatch the
+    fields are reported as null with a note instead of a stale number."""
+    path = os.path.join(ROOT, "profiles", "kernel_counters.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/kernel_counters.json missing"
+    sha = kernel_source_sha()
+    if c.get("kernel_src_sha16") != sha:
+        return None, "profiles/kernel_counters.json was measured on kernel sources %s, these are %s: re-run tools/collect_profiles.sh" % (
+            c.get("kernel_src_sha16"), sha)
+    return c, None
+
+
+def kinds_for(args):
+    name = args.kernel or ("half2" if args.workload == "peak" else "dpx")
+    if name == "dpx":
+        return name, (1, 1, 2, 2)
+    k = KIND_BY_NAME[name]
+    big = 3 if k in (0, 3) else 2
+    small = k if k in (0, 1) else (0 if k == 3 else 1)
+    return name, (k, small, big, big)
+
+
+# ------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(queries, chars, offsets, lengths, what):
+    """Oracle's SIMD scans (kind 'port') on the host cores over a bounded sample of the same workload: all 20 queries
+    x the sample DB.  The thread count is picked by a short calibration (containers often cap CPU time below the
+    number of visible hardware threads); `cores` reports the threads actually used.  Returns (json object,
+    scores[query][subject] of the sample) — the scores double as the checker of the GPU results."""
     import oracle_lib as O
-    codes = O.pseudodb_codes(L, 42)
     m = O.blosum21(62)
-    cal = O.make_db([codes] * 6000)
+    ncal = min(len(lengths), 6000)
+    cal = (chars[:int(offsets[ncal])], offsets[:ncal + 1], lengths[:ncal])
     best_nt, best_rate = 1, 0.0
     nt = O.max_threads()
     while nt >= 1:
         O.scan(queries[9], *cal, m21=m, simd=True, nthreads=nt)  # warm-up of this team size
         t0 = time.perf_counter()
         O.scan(queries[9], *cal, m21=m, simd=True, nthreads=nt)
-        rate = len(queries[9]) * 6000.0 * L / (time.perf_counter() - t0)
+        rate = 1.0 / (time.perf_counter() - t0)
         if rate > best_rate:
             best_nt, best_rate = nt, rate
         nt //= 2
-    chars, offsets, lengths = O.make_db([codes] * nsubj)
-    cells = float(sum(len(q) for q in queries)) * float(nsubj) * float(L)
-    rates = {}
+    cells = float(sum(len(q) for q in queries)) * float(lengths.astype(np.int64).sum())
+    rates, scores = {}, None
     for name, kw in (("striped", dict(striped=True)), ("interseq", dict(simd=True))):
         t0 = time.perf_counter()
-        for q in queries:
-            O.scan(q, chars, offsets, lengths, m21=m, nthreads=best_nt, **kw)
+        out = [O.scan(q, chars, offsets, lengths, m21=m, nthreads=best_nt, **kw) for q in queries]
         rates[name] = (cells / 1e9 / (time.perf_counter() - t0), time.perf_counter() - t0)
+        if scores is not None and any((a != b).any() for a, b in zip(scores, out)):
+            raise SystemExit("bench.py: the two CPU ports disagree")
+        scores = out
     # the reference's own scalar int32 DP (cudasw4.cuh:2331-2392 restated), one core, a few hundred subjects
-    ns = 300
-    sc = O.make_db([codes] * ns)
+    ns = min(300, len(lengths))
     t0 = time.perf_counter()
-    O.scan(queries[9], *sc, m21=m, nthreads=1)
-    scalar_rate = len(queries[9]) * float(ns) * L / 1e9 / (time.perf_counter() - t0)
+    O.scan(queries[9], chars[:int(offsets[ns])], offsets[:ns + 1], lengths[:ns], m21=m, nthreads=1)
+    scalar_rate = len(queries[9]) * float(lengths[:ns].astype(np.int64).sum()) / 1e9 / (time.perf_counter() - t0)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -86,17 +169,17 @@ def cpu_baseline(queries, L, nsubj):
     except OSError:
         pass
     best = max(rates, key=lambda k: rates[k][0])
-    return {"value": round(rates[best][0], 3), "unit": "GCUPS", "cores": best_nt, "kind": "port",
-            "algorithm": best, "striped_gcups": round(rates["striped"][0], 3), "interseq_gcups": round(rates["interseq"][0], 3),
-            "scalar_1core_gcups": round(scalar_rate, 4), "cpu_model": model,
-            "sample": "20 queries x %d pseudo subjects of length %d; oracle ports with int16 lanes (gcc, AVX-512 or AVX2 "
-                      "build picked by cpuid): Farrar striped SW %.1f s, inter-sequence SIMD %.1f s; %d of %d hardware "
-                      "threads (best of a calibration sweep)"
-                      % (nsubj, L, rates["striped"][1], rates["interseq"][1], best_nt, O.max_threads())}
+    obj = {"value": round(rates[best][0], 3), "unit": "GCUPS", "cores": best_nt, "kind": "port", "algorithm": best,
+           "striped_gcups": round(rates["striped"][0], 3), "interseq_gcups": round(rates["interseq"][0], 3),
+           "scalar_1core_gcups": round(scalar_rate, 4), "cpu_model": model,
+           "sample": "20 queries x %s; oracle ports with int16 lanes (gcc, AVX-512 or AVX2 build picked by cpuid): Farrar "
+                     "striped SW %.1f s, inter-sequence SIMD %.1f s; %d of %d hardware threads (best of a calibration sweep)"
+                     % (what, rates["striped"][1], rates["interseq"][1], best_nt, O.max_threads())}
+    return obj, scores
 
 
-def main():
-    args = parse_args()
+# ------------------------------------------------------------------------------------------------- one rank
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
@@ -112,6 +195,7 @@ def main():
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
+    comm_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -119,42 +203,65 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # inputs come from the product's own host library (FASTA reader, encoder, pseudo-DB generator, matrix);
+    # inputs come from the product's own host library (FASTA reader, encoder, pseudo-DB generator);
     # oracle/ is touched only inside cpu_baseline()
-    from cudasw4_amd import capi, driver, search
+    from cudasw4_amd import capi, driver, search, synthdb
 
     _, query_letters = driver.read_sequences(os.path.join(ROOT, "tests", "golden", "allqueries.fasta"))
     queries = [driver.encode(q) for q in query_letters]
-    kind = KIND_BY_NAME[args.kernel]
-    L, num = args.db_length, args.db_size
-    codes = driver.pseudo_sequence(L, 42)
-    db = search.DeviceDB.pseudo(num, L, codes, device=local_rank)
-    db.id_offset = rank * num  # global subject ids of this shard
-    big = capi.KIND_F32 if kind in (0, 3) else capi.KIND_I32
-    small = kind if kind in (0, 1) else (0 if kind == 3 else 1)
-    kt = search.KernelTypeConfig(single_pass=kind, many_pass_small=small, many_pass_large=big, overflow=big)
-    s = search.Searcher(device=local_rank, num_top=args.top, matrix=driver.matrix(62), kernel_types=kt)
-    s.set_database(db)
-    s.record_kernel_events = False
+    sum_q = sum(len(q) for q in queries)
+    kernel_name, kinds = kinds_for(args)
+    strong = args.scaling == "strong" or not distributed
+    K = max(args.top, 0)
 
-    merged_last = []
+    drv = driver.Driver(devices=[local_rank], num_top=K, matrix=62, kinds=kinds, max_gpu_mem=parse_size(args.max_gpu_mem))
+    host_db = None
+    if args.workload == "peak":
+        num = args.db_size or 1_000_000
+        L = args.db_length
+        drv.set_shard(rank, world, 0) if strong else drv.set_shard(0, 1, rank * num)
+        drv.pseudo_db(num, L)
+        total_residues = float(num) * L * (1 if strong else world)
+        total_subjects = num * (1 if strong else world)
+        what = "pseudo DB %d x %d%s" % (num, L, "" if strong else " per GPU")
+    else:
+        num = args.db_size or synthdb.SPROT_SEQUENCES
+        host_db = synthdb.sprot_like(num)
+        drv.set_shard(rank, world, 0) if strong else drv.set_shard(0, 1, rank * num)
+        drv.db_from_arrays(*host_db)
+        total_residues = float(host_db[2].astype(np.int64).sum()) * (1 if strong else world)
+        total_subjects = num * (1 if strong else world)
+        what = "Swiss-Prot-like synthetic DB (%d sequences, %d residues, log-normal lengths, max %d)%s" % (
+            num, int(host_db[2].astype(np.int64).sum()), int(host_db[2].max()), "" if strong else " per GPU")
+    drv.upload()
+    info = drv.shard_info(0)
+
+    merged = [None] * len(queries)
 
     def one_step():
-        """20 scans.  With --top K > 0 every query also pays the per-rank top-K, its copy to the host and the
-        host-side merge over ranks (the only cross-rank step of the path: K (score, id) pairs per rank)."""
-        pending = [s.scan(q, timed=False, sync=False) for q in queries]
-        if args.top > 0:
-            merged_last.clear()
-            for res in pending:
-                s.finish(res)
-                mine = (res.scores.tolist(), res.reference_ids.tolist())
-                if distributed:
-                    gathered = [None] * world if rank == 0 else None
-                    dist.gather_object(mine, gathered, dst=0)
-                    if rank == 0:
-                        merged_last.append(search.merge_topk(gathered, args.top))
-                else:
-                    merged_last.append(search.merge_topk([mine], args.top))
+        """20 scans through the C++ driver (each returns this rank's top-K on the host), then ONE exchange of the
+        per-rank lists — K (score, id) pairs per query and rank — and the host-side merge on rank 0."""
+        mine = np.full((len(queries), max(K, 1), 2), -1, dtype=np.int64)
+        for qi, q in enumerate(query_letters):
+            r = drv.scan(q)
+            n = len(r["scores"])
+            mine[qi, :n, 0] = r["scores"]
+            mine[qi, :n, 1] = r["ids"]
+        if K == 0:
+            return
+        if distributed:
+            t = torch.from_numpy(mine).to(comm_dev)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            if rank == 0:
+                allp = [p.cpu().numpy() for p in parts]
+                for qi in range(len(queries)):
+                    lists = [(p[qi, :, 0][p[qi, :, 1] >= 0], p[qi, :, 1][p[qi, :, 1] >= 0]) for p in allp]
+                    merged[qi] = search.merge_topk(lists, K)
+        else:
+            for qi in range(len(queries)):
+                keep = mine[qi, :, 1] >= 0
+                merged[qi] = search.merge_topk([(mine[qi, keep, 0], mine[qi, keep, 1])], K)
 
     def barrier():
         if distributed:
@@ -164,88 +271,176 @@ def main():
     for _ in range(args.warmup):
         one_step()
     barrier()
-    s.record_kernel_events = True
-    s.kernel_events = []
+    drv.record_kernel_events(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     barrier()
     dt = time.perf_counter() - t0
-    s.record_kernel_events = False
+    drv.record_kernel_events(False)
+    events = drv.take_kernel_events()
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    gcups = float(sum_q) * total_residues * args.steps / 1e9 / dt_max
 
-    # dominant kernel: the DP scan launch; durations from HIP events on the launch stream
-    kern_ms = [a.elapsed_time(b) for (a, b, _) in s.kernel_events]
-    kern_cells = [c for (_, _, c) in s.kernel_events]
-    sum_q = sum(len(q) for q in queries)
-    cells_per_step = float(sum_q) * float(num) * float(L)
-    total_cells = cells_per_step * args.steps * world
-    gcups = total_cells / 1e9 / dt_max
+    # ---- verification: one more pass, every score of every query (outside the timed region)
+    verified, verify_note, cpu_obj = None, None, None
+    want_cpu = not args.no_cpu_baseline and world == 1
+    if not args.no_verify:
+        ok = True
+        if args.workload == "peak":
+            golden = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_scores.json")))["pseudo"].get(str(args.db_length))
+            if golden is None:
+                ok, verify_note = None, "no golden scores for pseudo-DB length %d" % args.db_length
+            else:
+                nloc = info["subjects"]
+                for qi, q in enumerate(query_letters):
+                    drv.scan(q)
+                    sc, ids = drv.last_scores(0)
+                    ok = ok and len(sc) == nloc and int(sc.min()) == int(sc.max()) == int(golden[qi])
+                    if rank == 0 and K > 0:
+                        kk = min(K, total_subjects)
+                        base = [r * num for r in range(world)] if not strong else [0]
+                        # all scores tie: the K lowest ids win (weak scaling: the replicas' ids are r*num + i)
+                        want_ids = sorted(b + i for b in base for i in range(min(kk, num)))[:kk]
+                        ok = ok and merged[qi][0].tolist() == [int(golden[qi])] * kk and merged[qi][1].tolist() == want_ids
+                verify_note = "all %d scores of every query equal the reference's golden score; merged top-%d scores and ids as expected" % (nloc, K)
+        else:
+            gpu_scores = []
+            for q in query_letters:
+                drv.scan(q)
+                gpu_scores.append(drv.last_scores(0))
+            if want_cpu:
+                # the CPU leg scores a seeded sample of the DB (plus the longest subjects): timing AND checker
+                chars, offsets, lengths = host_db
+                rng = np.random.default_rng(1)
+                ns = args.cpu_sample_subjects or 6000
+                pick = np.unique(np.concatenate([rng.choice(num, min(ns, num), replace=False), np.arange(max(0, num - 4), num)]))
+                sub = search.build_shard(chars, offsets, lengths, [(int(i), int(i) + 1) for i in pick])
+                cpu_obj, cpu_scores = cpu_baseline(queries, sub[0], sub[1], sub[2],
+                                                   "%d sampled subjects (%d residues, incl. the 4 longest) of the same DB" % (len(pick), int(sub[2].astype(np.int64).sum())))
+                for qi in range(len(queries)):
+                    sc, ids = gpu_scores[qi]
+                    order = np.argsort(ids)
+                    ok = ok and (sc[order][pick] == cpu_scores[qi]).all()
+                    top = search.merge_topk([(sc, ids)], K) if K > 0 else None
+                    ok = ok and (K == 0 or (merged[qi][0].tolist() == top[0].tolist() and merged[qi][1].tolist() == top[1].tolist()))
+                verify_note = "every score of %d sampled subjects x 20 queries equals the CPU oracle; top-%d equals the top of all scores" % (len(pick), K)
+            else:
+                # no CPU leg: an independent arithmetic path — all scores again with the int32 kernels only
+                d2 = driver.Driver(devices=[local_rank], num_top=0, matrix=62, kinds=(2, 1, 2, 2))
+                d2.set_shard(rank, world, 0) if strong else d2.set_shard(0, 1, rank * num)
+                d2.db_from_arrays(*host_db)
+                d2.upload()
+                for qi, q in enumerate(query_letters):
+                    d2.scan(q)
+                    sc2, ids2 = d2.last_scores(0)
+                    ok = ok and (sc2 == gpu_scores[qi][0]).all() and (ids2 == gpu_scores[qi][1]).all()
+                d2.close()
+                verify_note = "all scores of every query equal between the %s and the int32 kernel configuration" % kernel_name
+        if ok is not None and distributed:
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=comm_dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            ok = bool(f.item())
+        verified = ok
 
     if rank == 0:
-        n_launch = max(len(kern_ms), 1)
-        avg_ms = sum(kern_ms) / n_launch
-        # algorithmic HBM bytes of one scan launch: chars + lengths + offsets + scores/ids + query
-        lpad = (L + 3) // 4 * 4
-        avg_q = sum_q / len(queries)
-        bytes_per_launch = num * lpad + 4 * num + 8 * (num + 1) + 8 * num + (avg_q + 3) // 4 * 4 + 128
-        hbm_gbs = bytes_per_launch / 1e9 / (avg_ms * 1e-3)
-        kern_gcups = (sum(kern_cells) / 1e9) / (sum(kern_ms) * 1e-3) if kern_ms else 0.0
-        packed = kind in (0, 1)
-        # VALU issue ceiling (tools/ubench/valu_rate.hip): every op of the loop issues at one
-        # wave64 instruction per 4 cycles per SIMD = 64 lanes/clk/CU; 256 CUs at 2.4 GHz.
-        valu_peak_instr = 256 * 64 * 2.4e9
-        if kind == 3:
-            # fp32 kind: v_add_f32 (VOP2) co-issues with v_max3_f32 (VOP3); the 8:7 mix of the loop sustains
-            # 99.5 lanes/clk/CU in tools/ubench/mix_rate.hip
-            valu_peak_instr = 256 * 99.5 * 2.4e9
-        # VALU instructions issued per USEFUL cell (pair).  Packed kinds: measured over the whole 20-query pass with PMC
-        # (SQ_INSTS_VALU x 64 lanes / cell pairs, profiles/r01_bench_half2_pmc.txt: 6.34; it contains row padding,
-        # pipeline fill and the per-step work; the static count of the loop bodies is 6.05..6.3 per cell pair for
-        # R = 32..48).  32-bit kinds: static count from the gfx950 ISA at R = 32
-        instr_per_unit = {0: 6.34, 1: 6.34, 2: 6.25, 3: 6.4}[kind]
-        units_per_s = kern_gcups * 1e9 / (2 if packed else 1)
-        achieved_instr = units_per_s * instr_per_unit
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "bench_traffic.json")
-        if os.path.exists(tpath) and kind == 0 and num == 1_000_000 and L == 512:
-            try:
-                traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # dominant kernel: group the HIP-event timed launches by kernel instantiation (kind, rows per lane, stripes, shape)
+        groups = {}
+        for e in events:
+            rows, ns = capi.plan_query(e["kind"], e["qlen"])
+            key = (e["kind"], rows, ns > 1, e["part_id"] >= 34)
+            groups.setdefault(key, []).append(e)
+        roof, valu = None, None
+        if groups:
+            key = max(groups, key=lambda k: sum(e["ms"] for e in groups[k]))
+            ev = groups[key]
+            kind = key[0]
+            avg_ms = sum(e["ms"] for e in ev) / len(ev)
+            # algorithmic HBM bytes of one launch: chars + lengths + offsets + scores/ids + query
+            bytes_per_launch = sum(e["chars"] + 4 * e["subjects"] + 8 * (e["subjects"] + 1) + 8 * e["subjects"] + (e["qlen"] + 3) // 4 * 4 + 128
+                                   for e in ev) / len(ev)
+            hbm_gbs = bytes_per_launch / 1e9 / (avg_ms * 1e-3)
+            counters, cnote = load_counters()
+            kname = "sw_scan_kernel<%s, R=%d, %s, %s>" % (DTYPE_BY_KIND[kind], key[1], "16 lanes" if not key[3] else "long-subject shape",
+                                                         "multi-stripe" if key[2] else "single stripe")
+            traffic = None
+            if counters:
+                traffic = (counters.get("traffic_bytes_per_launch") or {}).get("%s:%s:R%d" % (args.workload, DTYPE_BY_KIND[kind], key[1]))
+            roof = {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(hbm_gbs / 8000.0, 6), "traffic": traffic, "kernel": kname,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": len(ev), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "share_of_kernel_time": round(sum(e["ms"] for e in ev) / sum(e["ms"] for e in events), 3)}
+            if cnote:
+                roof["traffic_note"] = cnote
+            # the binding bound: VALU issue.  Peak: one wave64 instruction per 4 cycles per SIMD =
+            # 64 lanes/clk/CU, 256 CUs at 2.4 GHz; fp32 kind: v_add_f32 co-issues with v_max3_f32 (99.5 lanes/clk/CU)
+            packed = kind in (0, 1)
+            all_ms = sum(e["ms"] for e in events if e["kind"] == kind)
+            all_cells = sum(e["cells"] for e in events if e["kind"] == kind)
+            kern_gcups = all_cells / 1e9 / (all_ms * 1e-3)
+            valu_peak = 256 * (99.5 if kind == 3 else 64) * 2.4e9
+            ipu = (counters.get("valu_instr_per_unit") or {}).get("%s:%s" % (args.workload, DTYPE_BY_KIND[kind])) if counters else None
+            valu = {"bound": "valu-issue", "peak": round(valu_peak / 1e12, 3), "unit": "T lane-instr/s",
+                    "kernel_gcups": round(kern_gcups, 1),
+                    "note": "the binding bound of this path (DESIGN.md §3): the DP recurrence is VALU-issue bound, not HBM "
+                            "bound; roofline.frac above is the HBM view the contract asks for"}
+            if ipu:
+                ach = kern_gcups * 1e9 / (2 if packed else 1) * ipu
+                valu.update({"achieved": round(ach / 1e12, 3), "frac": round(ach / valu_peak, 4),
+                             "instr_per_cell_pair" if packed else "instr_per_cell": ipu,
+                             "counters": counters.get("source")})
+            else:
+                valu.update({"achieved": None, "frac": None, "counters_note": cnote or "no PMC figure for this workload/kind"})
         out = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_BY_KIND[kind], "data": "synthetic",
-            "config": {"workload": "allqueries.fasta (20 queries, 41752 residues) vs pseudo DB %d x %d per GPU, "
-                                   "%s kernel, blosum62, gop -11 gex -1, top %d" % (num, L, args.kernel, args.top),
-                       "db_subjects_per_gpu": num, "db_length": L, "queries": len(queries), "kernel": args.kernel,
-                       "parallelism": "db-shard x%d, host top-K merge" % world},
-            "roofline": {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(hbm_gbs / 8000.0, 6), "traffic": traffic,
-                         "kernel": "sw_scan_kernel<%s>" % DTYPE_BY_KIND[kind], "avg_launch_ms": round(avg_ms, 4),
-                         "launches": len(kern_ms), "algorithmic_bytes_per_launch": int(bytes_per_launch)},
-            "valu_roofline": {"bound": "valu-issue", "achieved": round(achieved_instr / 1e12, 3),
-                              "peak": round(valu_peak_instr / 1e12, 3), "unit": "T lane-instr/s",
-                              "frac": round(achieved_instr / valu_peak_instr, 4), "kernel_gcups": round(kern_gcups, 1),
-                              "instr_per_cell_pair" if packed else "instr_per_cell": instr_per_unit,
-                              "note": "the binding bound of this path (DESIGN.md §3): the DP recurrence is VALU-issue "
-                                      "bound, not HBM bound; roofline.frac above is the HBM view the contract asks for"},
+            "scaling": "strong" if (strong and distributed) else "weak", "vs_baseline": None,
+            "dtype": DTYPE_BY_KIND[kinds[0]], "data": "synthetic", "verified": verified, "verified_how": verify_note,
+            "config": {"workload": "%s: allqueries.fasta (20 queries, %d residues) vs %s, %s kernel configuration, blosum62, "
+                                   "gop -11 gex -1, top %d, C++ host driver" % (args.workload, sum_q, what, kernel_name, K),
+                       "db_subjects": total_subjects, "db_residues": int(total_residues), "queries": len(queries),
+                       "kernel": kernel_name, "host": "libcudasw4_host.so (SearchDriver)",
+                       "resident": info["resident"],
+                       "parallelism": "db-shard x%d (%s), one top-K gather per step + host merge" % (world, "one DB sharded" if strong else "one DB per rank")},
+            "roofline": roof, "valu_roofline": valu,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(queries, L, args.cpu_sample_subjects)
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None
-        if args.top > 0 and merged_last:
-            out["config"]["top_merged_example"] = {"query": len(queries) - 1, "scores": merged_last[-1][0].tolist(),
-                                                   "ids": merged_last[-1][1].tolist()}
+        if want_cpu and cpu_obj is None:
+            # peak workload: a bounded sample of the same DB (identical subjects)
+            import oracle_lib as O
+            ns = args.cpu_sample_subjects or 60000
+            codes = driver.pseudo_sequence(args.db_length, 42)
+            sample = O.make_db([codes] * ns)
+            cpu_obj, cpu_scores = cpu_baseline(queries, *sample, "%d pseudo subjects of length %d" % (ns, args.db_length))
+            if verified and args.workload == "peak":
+                golden = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_scores.json")))["pseudo"].get(str(args.db_length))
+                if golden is not None and any(int(s[0]) != int(g) for s, g in zip(cpu_scores, golden)):
+                    out["verified"] = False
+        out["cpu_baseline"] = cpu_obj
+        if K > 0 and merged[-1] is not None:
+            out["config"]["top_merged_example"] = {"query": len(queries) - 1, "scores": merged[-1][0].tolist(),
+                                                   "ids": merged[-1][1].tolist()}
         print(json.dumps(out))
+        sys.stdout.flush()
+    drv.close()
     if distributed:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # start the ranks BEFORE anything here touches the GPU (a process that has initialised the GPU must not be
+        # replaced or forked); the child prints the JSON line
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with matching values\n" % (args.gpus, world))
+        sys.exit(2)
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -256,11 +256,10 @@ std::string Database::sequence_letters(size_t i) const {
 
 // ------------------------------------------------------------------ sharding
 
-std::vector<std::array<ShardRange, kNumLengthPartitions>> shard_database(const Database& db, int num_shards) {
+std::vector<std::array<ShardRange, kNumLengthPartitions>> shard_ranges(const uint64_t* off, const size_t* partBegin, int num_shards) {
     std::vector<std::array<ShardRange, kNumLengthPartitions>> result(size_t(std::max(num_shards, 1)));
-    const uint64_t* off = db.offsets();
     for (int p = 0; p < kNumLengthPartitions; p++) {
-        const size_t pb = db.partition_begin(p), pe = pb + db.partition_counts()[p];
+        const size_t pb = partBegin[p], pe = partBegin[p + 1];
         for (auto& r : result) r[p] = ShardRange{pb, pb};
         if (pe == pb) continue;
         const uint64_t chars_total = off[pe] - off[pb];
@@ -286,6 +285,13 @@ std::vector<std::array<ShardRange, kNumLengthPartitions>> shard_database(const D
         }
     }
     return result;
+}
+
+std::vector<std::array<ShardRange, kNumLengthPartitions>> shard_database(const Database& db, int num_shards) {
+    size_t partBegin[kNumLengthPartitions + 1];
+    for (int p = 0; p < kNumLengthPartitions; p++) partBegin[p] = db.partition_begin(p);
+    partBegin[kNumLengthPartitions] = db.num_sequences();
+    return shard_ranges(db.offsets(), partBegin, num_shards);
 }
 
 }  // namespace swh

@@ -116,5 +116,7 @@ struct ShardRange {
 // contiguous, char-balanced ranges (dbdata.cpp:265-292) so that each GPU sees every length class.
 // result[shard][partition]
 std::vector<std::array<ShardRange, kNumLengthPartitions>> shard_database(const Database& db, int num_shards);
+// the same on raw arrays: offsets[n+1] and the first subject of every length partition (partBegin[36] = n)
+std::vector<std::array<ShardRange, kNumLengthPartitions>> shard_ranges(const uint64_t* offsets, const size_t* partBegin, int num_shards);
 
 }  // namespace swh

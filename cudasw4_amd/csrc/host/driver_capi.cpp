@@ -1,6 +1,7 @@
 // driver_capi.cpp — C ABI (include/cudasw4_amd_driver.h) around SearchDriver.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 
@@ -93,6 +94,23 @@ int swdrv_pseudo_db(swdrv* d, size_t num, int32_t length) {
     });
 }
 
+int swdrv_db_from_arrays(swdrv* d, const int8_t* chars, size_t nchars, const uint64_t* offsets, const int32_t* lengths, size_t n) {
+    return guarded([&] {
+        if (!chars || !offsets || !lengths) throw std::runtime_error("null array");
+        if (n && offsets[n] - offsets[0] > nchars) throw std::runtime_error("chars array shorter than the last offset");
+        std::vector<int8_t> c(chars, chars + nchars);
+        std::vector<uint64_t> o(offsets, offsets + n + 1), ho(n + 1);
+        for (size_t i = 0; i <= n; i++) { o[i] -= offsets[0]; ho[i] = i; }
+        std::vector<int32_t> l(lengths, lengths + n);
+        d->db = Database::from_vectors(std::move(c), std::move(o), std::move(l), std::vector<char>(n, 'S'), std::move(ho));
+        d->driver->setDatabase(d->db);
+    });
+}
+
+int swdrv_set_shard(swdrv* d, int rank, int world, int64_t id_base) {
+    return guarded([&] { d->driver->setShard(rank, world, id_base); });
+}
+
 int swdrv_upload(swdrv* d) {
     return guarded([&] { d->driver->prefetchDBToGpus(); });
 }
@@ -117,6 +135,103 @@ int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64
         if (num_overflows) *num_overflows = r.stats.numOverflows;
         if (seconds) *seconds = r.stats.seconds;
         if (gcups) *gcups = r.stats.gcups;
+    });
+}
+
+int swdrv_record_kernel_events(swdrv* d, int on) {
+    return guarded([&] { d->driver->recordKernelEvents(on != 0); });
+}
+
+int swdrv_take_kernel_events(swdrv* d, double* out, int cap) {
+    int n = -1;
+    const int rc = guarded([&] {
+        const auto ev = d->driver->takeKernelEvents();
+        n = int(ev.size());
+        for (int i = 0; i < n && i < cap; i++) {
+            double* o = out + size_t(i) * 8;
+            const KernelEvent& e = ev[size_t(i)];
+            o[0] = e.gpu; o[1] = e.kind; o[2] = e.part_id; o[3] = e.qlen; o[4] = double(e.subjects); o[5] = e.cells; o[6] = e.chars; o[7] = e.ms;
+        }
+    });
+    return rc == 0 ? n : -1;
+}
+
+int swdrv_shard_info(swdrv* d, int gpu, int64_t* num_local, int64_t* residues, int64_t* chars, int* resident) {
+    return guarded([&] {
+        if (num_local) *num_local = int64_t(d->driver->numLocal(gpu));
+        if (residues) *residues = int64_t(d->driver->localResidues(gpu));
+        if (chars) *chars = int64_t(d->driver->localChars(gpu));
+        if (resident) *resident = d->driver->isResident(gpu) ? 1 : 0;
+    });
+}
+
+int swdrv_last_scores(swdrv* d, int gpu, float* scores, int64_t* ids) {
+    return guarded([&] { d->driver->lastScores(gpu, scores, ids); });
+}
+
+int swdrv_batch_intervals(swdrv* d, float* out, int cap) {
+    int n = -1;
+    const int rc = guarded([&] {
+        const auto iv = d->driver->lastBatchIntervals();
+        n = int(iv.size());
+        for (int i = 0; i < n && i < cap; i++) { out[3 * i] = float(iv[size_t(i)].gpu); out[3 * i + 1] = iv[size_t(i)].begin_ms; out[3 * i + 2] = iv[size_t(i)].end_ms; }
+    });
+    return rc == 0 ? n : -1;
+}
+
+int swdrv_gpu_spans(swdrv* d, double* out, int cap) {
+    int n = -1;
+    const int rc = guarded([&] {
+        const auto sp = d->driver->lastGpuSpans();
+        n = int(sp.size());
+        for (int i = 0; i < n && i < cap; i++) { out[2 * i] = sp[size_t(i)].begin_s; out[2 * i + 1] = sp[size_t(i)].end_s; }
+    });
+    return rc == 0 ? n : -1;
+}
+
+int swdrv_plan_runs(const int32_t* sorted_lengths, size_t n, int kind_single, int kind_many_small, int kind_many_large,
+                    int64_t* out, int cap) {
+    int nruns = -1;
+    const int rc = guarded([&] {
+        for (int k : {kind_single, kind_many_small, kind_many_large})
+            if (k < 0 || k > 3) throw std::runtime_error("unknown kernel type");
+        KernelTypeConfig kc{KernelType(kind_single), KernelType(kind_many_small), KernelType(kind_many_large), KernelType::Float};
+        const auto& bounds = length_partition_bounds();
+        size_t partBegin[kNumLengthPartitions + 1];
+        partBegin[0] = 0;
+        const int32_t* first = sorted_lengths;
+        for (int p = 0; p < kNumLengthPartitions; p++) {
+            first = std::upper_bound(first, sorted_lengths + n, bounds[size_t(p)]);
+            partBegin[p + 1] = size_t(first - sorted_lengths);
+        }
+        const auto runs = plan_launch_runs(kc, partBegin, 0, n, [&](size_t pos) { return sorted_lengths[pos]; });
+        nruns = int(runs.size());
+        for (int i = 0; i < nruns && i < cap; i++) {
+            int64_t* o = out + size_t(i) * 5;
+            o[0] = int64_t(runs[size_t(i)].kind); o[1] = runs[size_t(i)].part_id; o[2] = int64_t(runs[size_t(i)].begin);
+            o[3] = int64_t(runs[size_t(i)].end); o[4] = runs[size_t(i)].maxlen;
+        }
+    });
+    return rc == 0 ? nruns : -1;
+}
+
+int swdrv_shard_ranges(const int32_t* sorted_lengths, const uint64_t* offsets, size_t n, int world, int64_t* out) {
+    return guarded([&] {
+        if (world < 1) throw std::runtime_error("world must be positive");
+        const auto& bounds = length_partition_bounds();
+        size_t partBegin[kNumLengthPartitions + 1];
+        partBegin[0] = 0;
+        const int32_t* first = sorted_lengths;
+        for (int p = 0; p < kNumLengthPartitions; p++) {
+            first = std::upper_bound(first, sorted_lengths + n, bounds[size_t(p)]);
+            partBegin[p + 1] = size_t(first - sorted_lengths);
+        }
+        const auto sh = shard_ranges(offsets, partBegin, world);
+        for (int r = 0; r < world; r++)
+            for (int p = 0; p < kNumLengthPartitions; p++) {
+                out[(size_t(r) * kNumLengthPartitions + size_t(p)) * 2] = int64_t(sh[size_t(r)][size_t(p)].begin);
+                out[(size_t(r) * kNumLengthPartitions + size_t(p)) * 2 + 1] = int64_t(sh[size_t(r)][size_t(p)].end);
+            }
     });
 }
 

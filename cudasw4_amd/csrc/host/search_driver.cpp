@@ -4,10 +4,15 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iostream>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 #include "../../../include/cudasw4_amd.h"
 
@@ -64,43 +69,54 @@ KernelType KernelTypeConfig::for_partition(int part_id) const {
     return part_id == kNumLengthPartitions - 2 ? manyPassType_small : manyPassType_large;
 }
 
-// One launch of the scan kernel: a run of adjacent length partitions that use the same kind.
-struct Run {
-    KernelType kind;
-    int part_id;       // largest partition of the run
-    size_t begin, end; // shard-local subject range
-    int32_t maxlen;
+// A batch of a streamed shard: the shard-local subjects [lbegin, lend), which may span several length
+// partitions (each partition's slice is one contiguous piece of the DB's chars file).
+struct Batch {
+    size_t lbegin = 0, lend = 0;
+    uint64_t bytes = 0;  // padded subject bytes == localOffsets[lend] - localOffsets[lbegin]
+    int32_t maxLen = 0;
 };
 
-struct DeviceBatch {  // a contiguous shard-local subject range resident (or staged) on the device
-    int8_t* chars = nullptr;
-    uint64_t* offsets = nullptr;
-    int32_t* lengths = nullptr;
-    size_t chars_capacity = 0, seq_capacity = 0;
+struct TimedLaunch {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int kind = 0, part_id = 0;
+    int32_t qlen = 0;
+    size_t lbegin = 0, lend = 0;
 };
 
 struct SearchDriver::Gpu {
+    int index = 0;   // position in gpus_
     int device = 0;
     sw_ctx* ctx = nullptr;
     hipStream_t stream = nullptr, copyStream = nullptr;
     std::array<ShardRange, kNumLengthPartitions> ranges{};
     std::array<size_t, kNumLengthPartitions + 1> localBegin{};
     size_t numLocal = 0;
-    uint64_t localChars = 0;
+    uint64_t localChars = 0, localResidues = 0;
     int32_t maxLen = 0;
+    std::vector<uint64_t> localOffsets;   // [numLocal + 1] byte offsets into the shard's concatenated chars
+    std::vector<uint64_t> resPrefix;      // lazily: prefix sums of true lengths (kernel-event statistics)
+    // subject metadata is always resident (12 bytes per subject); only the chars are streamed when the shard
+    // does not fit the memory limit
+    uint64_t* d_offsets = nullptr;
+    int32_t* d_lengths = nullptr;
+    int8_t* d_chars = nullptr;
     bool resident = false, wantResident = false;
-    DeviceBatch residentDb;
-    DeviceBatch staging[2];
-    hipEvent_t stagingFree[2] = {nullptr, nullptr}, stagingReady[2] = {nullptr, nullptr};
-    int8_t* h_pinnedChars[2] = {nullptr, nullptr};
-    uint64_t* h_pinnedOffsets[2] = {nullptr, nullptr};
-    int32_t* h_pinnedLengths[2] = {nullptr, nullptr};
-    size_t pinnedCharsCap[2] = {0, 0}, pinnedSeqCap[2] = {0, 0};
-    int32_t* h_ovfSlot = nullptr;  // pinned [2]: per-batch overflow counts of the two staging slots
+    // streaming: two device staging buffers fed from the (registered) DB mapping, or through pinned host buffers
+    std::vector<Batch> batches;
+    int8_t* d_staging[2] = {nullptr, nullptr};
+    size_t stagingCap = 0;
+    int8_t* h_pinned[2] = {nullptr, nullptr};
+    size_t pinnedCap = 0;
+    hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> batchEv;  // 2 per batch of the last streamed scan (intervals for tests / tuning)
+    hipEvent_t scanStartEv = nullptr;
+    int32_t* h_ovfBatch = nullptr;    // pinned: overflow count of every batch of the current query
+    size_t ovfBatchCap = 0;
     float* d_scores = nullptr;
     int32_t* d_ids = nullptr;
     int32_t* d_ovfPos = nullptr;
-    int32_t* d_ovfCount = nullptr;   // [0] per batch, [1] running total of the query
+    int32_t* d_ovfCount = nullptr;
     // Launches that run concurrently need their own stripe-border scratch: slot 0 = work stream,
     // slots 1.. = auxiliary streams (the reference round-robins 10 work streams, cudasw4.cuh:293,1745-1748)
     static constexpr int kAux = 2;
@@ -115,18 +131,65 @@ struct SearchDriver::Gpu {
     int topCapacity = 0;
     float* h_topS = nullptr;
     int32_t* h_topI = nullptr;
-    int32_t* h_ovf = nullptr;
     int lastTop = 0;
+    int lastOverflows = 0;
+    int32_t qlen = 0;
+    double spanBegin = 0, spanEnd = 0;  // host clock, seconds since the scan started
+    std::vector<TimedLaunch> timed;     // launches recorded since the last takeKernelEvents
+    std::vector<TimedLaunch> freeTimed; // event pairs to reuse
 
     void use() const { HIPCHECK(hipSetDevice(device)); }
 
-    // shard-local index -> global subject id (HostGpuPartitionOffsets, cudasw4.cuh:103-213)
+    // shard-local index -> subject index in the DB (HostGpuPartitionOffsets, cudasw4.cuh:103-213)
     int64_t toGlobal(int64_t local) const {
         const int p = int(std::upper_bound(localBegin.begin(), localBegin.end(), size_t(local)) - localBegin.begin()) - 1;
         return int64_t(ranges[p].begin + (size_t(local) - localBegin[p]));
     }
-    int partitionOfLocal(size_t local) const {
-        return int(std::upper_bound(localBegin.begin(), localBegin.end(), local) - localBegin.begin()) - 1;
+};
+
+// One host thread per GPU (multi-GPU drivers only): runs the tasks posted to it on its own device.
+struct SearchDriver::Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> task;
+    bool pending = false, busy = false, stop = false;
+    std::exception_ptr err;
+
+    Worker() {
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this] { return pending || stop; });
+                if (stop) return;
+                pending = false;
+                auto fn = std::move(task);
+                lk.unlock();
+                std::exception_ptr e;
+                try { fn(); } catch (...) { e = std::current_exception(); }
+                lk.lock();
+                err = e;
+                busy = false;
+                cv.notify_all();
+            }
+        });
+    }
+    ~Worker() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void post(std::function<void()> fn) {
+        std::lock_guard<std::mutex> lk(m);
+        task = std::move(fn);
+        pending = true;
+        busy = true;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return !busy; });
+        if (err) { auto e = err; err = nullptr; std::rethrow_exception(e); }
     }
 };
 
@@ -139,6 +202,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
     if (deviceIds.empty()) throw std::runtime_error("No GPU found");
     for (int dev : deviceIds) {
         auto g = std::make_unique<Gpu>();
+        g->index = int(gpus_.size());
         g->device = dev;
         g->use();
         SWCHECK(sw_ctx_create(dev, &g->ctx));
@@ -146,30 +210,40 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&g->forkEvent, hipEventDisableTiming));
+        HIPCHECK(hipEventCreate(&g->scanStartEv));
         for (int i = 0; i < Gpu::kAux; i++) {
             HIPCHECK(hipStreamCreateWithFlags(&g->aux[i], hipStreamNonBlocking));
             HIPCHECK(hipEventCreateWithFlags(&g->joinEvent[i], hipEventDisableTiming));
         }
-        HIPCHECK(hipMalloc(&g->d_ovfCount, 2 * sizeof(int32_t)));
-        HIPCHECK(hipHostMalloc(&g->h_ovf, 2 * sizeof(int32_t)));
-        HIPCHECK(hipHostMalloc(&g->h_ovfSlot, 2 * sizeof(int32_t)));
+        for (int i = 0; i < 2; i++) {
+            HIPCHECK(hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&g->scanned[i], hipEventDisableTiming));
+        }
+        HIPCHECK(hipMalloc(&g->d_ovfCount, sizeof(int32_t)));
         gpus_.push_back(std::move(g));
     }
+    if (gpus_.size() > 1)
+        for (size_t i = 0; i < gpus_.size(); i++) workers_.push_back(std::make_unique<Worker>());
 }
 
 SearchDriver::~SearchDriver() {
+    workers_.clear();  // joins the worker threads
     for (auto& gp : gpus_) {
         Gpu& g = *gp;
         (void)hipSetDevice(g.device);
         (void)hipDeviceSynchronize();
-        auto freeBatch = [](DeviceBatch& b) { (void)hipFree(b.chars); (void)hipFree(b.offsets); (void)hipFree(b.lengths); };
-        freeBatch(g.residentDb);
+        (void)hipFree(g.d_offsets); (void)hipFree(g.d_lengths); (void)hipFree(g.d_chars);
         for (int i = 0; i < 2; i++) {
-            freeBatch(g.staging[i]);
-            (void)hipHostFree(g.h_pinnedChars[i]); (void)hipHostFree(g.h_pinnedOffsets[i]); (void)hipHostFree(g.h_pinnedLengths[i]);
-            if (g.stagingFree[i]) (void)hipEventDestroy(g.stagingFree[i]);
-            if (g.stagingReady[i]) (void)hipEventDestroy(g.stagingReady[i]);
+            (void)hipFree(g.d_staging[i]);
+            (void)hipHostFree(g.h_pinned[i]);
+            if (g.copied[i]) (void)hipEventDestroy(g.copied[i]);
+            if (g.scanned[i]) (void)hipEventDestroy(g.scanned[i]);
         }
+        for (hipEvent_t e : g.batchEv) (void)hipEventDestroy(e);
+        if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
+        for (auto* v : {&g.timed, &g.freeTimed})
+            for (TimedLaunch& t : *v) { (void)hipEventDestroy(t.ev0); (void)hipEventDestroy(t.ev1); }
+        (void)hipHostFree(g.h_ovfBatch);
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos); (void)hipFree(g.d_ovfCount);
         for (int i = 0; i <= Gpu::kAux; i++) (void)hipFree(g.d_temp[i]);
         for (int i = 0; i < Gpu::kAux; i++) {
@@ -178,90 +252,134 @@ SearchDriver::~SearchDriver() {
         }
         if (g.forkEvent) (void)hipEventDestroy(g.forkEvent);
         (void)hipFree(g.d_topkTemp); (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
-        (void)hipHostFree(g.h_topS); (void)hipHostFree(g.h_topI); (void)hipHostFree(g.h_ovf); (void)hipHostFree(g.h_ovfSlot);
+        (void)hipHostFree(g.h_topS); (void)hipHostFree(g.h_topI);
         if (g.stream) (void)hipStreamDestroy(g.stream);
         if (g.copyStream) (void)hipStreamDestroy(g.copyStream);
         if (g.ctx) sw_ctx_destroy(g.ctx);
     }
+    if (db_ && dbRegistered_) (void)hipHostUnregister(const_cast<int8_t*>(db_->chars()));
+}
+
+void SearchDriver::setShard(int rank, int world, int64_t idBase) {
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("bad shard rank / world size");
+    shardRank_ = rank;
+    shardWorld_ = world;
+    idBase_ = idBase;
 }
 
 void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
+    if (db_ && dbRegistered_) { (void)hipHostUnregister(const_cast<int8_t*>(db_->chars())); dbRegistered_ = false; }
     db_ = std::move(db);
     if (db_->num_sequences() > size_t(INT32_MAX) - 1) throw std::runtime_error("Too many sequences in DB");
-    const auto shards = shard_database(*db_, int(gpus_.size()));
-    for (size_t gi = 0; gi < gpus_.size(); gi++) {
-        Gpu& g = *gpus_[gi];
+    const int ngpu = int(gpus_.size());
+    const auto shards = shard_database(*db_, ngpu * shardWorld_);
+    bool anyStreamed = false;
+    for (int gi = 0; gi < ngpu; gi++) {
+        Gpu& g = *gpus_[size_t(gi)];
         g.use();
-        g.ranges = shards[gi];
+        g.ranges = shards[size_t(shardRank_ * ngpu + gi)];
         g.localBegin[0] = 0;
-        g.localChars = 0;
         g.maxLen = 0;
         for (int p = 0; p < kNumLengthPartitions; p++) {
             g.localBegin[p + 1] = g.localBegin[p] + g.ranges[p].size();
-            if (g.ranges[p].size()) {
-                g.localChars += db_->offsets()[g.ranges[p].end] - db_->offsets()[g.ranges[p].begin];
-                g.maxLen = std::max(g.maxLen, db_->length(g.ranges[p].end - 1));
-            }
+            if (g.ranges[p].size()) g.maxLen = std::max(g.maxLen, db_->length(g.ranges[p].end - 1));
         }
         g.numLocal = g.localBegin[kNumLengthPartitions];
         g.resident = false;
+        g.resPrefix.clear();
+        // shard-local byte offsets (the pieces of the partitions follow each other) and true residues
+        g.localOffsets.assign(g.numLocal + 1, 0);
+        const uint64_t* off = db_->offsets();
+        uint64_t charPos = 0, residues = 0;
+        for (int p = 0; p < kNumLengthPartitions; p++) {
+            const ShardRange r = g.ranges[p];
+            for (size_t i = 0; i < r.size(); i++) {
+                g.localOffsets[g.localBegin[p] + i] = charPos + (off[r.begin + i] - off[r.begin]);
+                residues += uint64_t(db_->length(r.begin + i));
+            }
+            if (r.size()) charPos += off[r.end] - off[r.begin];
+        }
+        g.localOffsets[g.numLocal] = charPos;
+        g.localChars = charPos;
+        g.localResidues = residues;
+
         const size_t n = std::max<size_t>(g.numLocal, 1);
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos);
+        (void)hipFree(g.d_offsets); (void)hipFree(g.d_lengths); (void)hipFree(g.d_chars);
+        g.d_chars = nullptr;
         HIPCHECK(hipMalloc(&g.d_scores, n * sizeof(float)));
         HIPCHECK(hipMalloc(&g.d_ids, n * sizeof(int32_t)));
         HIPCHECK(hipMalloc(&g.d_ovfPos, n * sizeof(int32_t)));
-        // residency decision (GpuWorkingSet, cudasw4.cuh:317-392): whole shard if it fits the limit
+        HIPCHECK(hipMalloc(&g.d_offsets, (n + 1) * sizeof(uint64_t)));
+        HIPCHECK(hipMalloc(&g.d_lengths, n * sizeof(int32_t)));
+        HIPCHECK(hipMemcpyAsync(g.d_offsets, g.localOffsets.data(), (g.numLocal + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+        for (int p = 0; p < kNumLengthPartitions; p++) {
+            const ShardRange r = g.ranges[p];
+            if (!r.size()) continue;
+            HIPCHECK(hipMemcpyAsync(g.d_lengths + g.localBegin[p], db_->lengths() + r.begin, r.size() * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
+        }
+        HIPCHECK(hipStreamSynchronize(g.stream));
+        // residency decision (GpuWorkingSet, cudasw4.cuh:317-392): the whole shard if it fits the limit
         size_t freeMem = 0, totalMem = 0;
         HIPCHECK(hipMemGetInfo(&freeMem, &totalMem));
         size_t limit = std::min(memory_.maxGpuMem, freeMem);
         const size_t safety = size_t(256) << 20;  // cudasw4.cuh:1020-1026
         limit = limit > safety ? limit - safety : 0;
-        const size_t shardBytes = g.localChars + 64 + (g.numLocal + 1) * sizeof(uint64_t) + g.numLocal * sizeof(int32_t);
-        const size_t fixed = n * (sizeof(float) + 2 * sizeof(int32_t)) + std::min(memory_.maxTempBytes, size_t(1) << 30);
-        g.wantResident = shardBytes + fixed <= limit;
+        const size_t fixed = std::min(memory_.maxTempBytes, size_t(1) << 30);
+        g.wantResident = g.localChars + 64 + fixed <= limit;
+        g.batches.clear();
+        if (!g.wantResident) { planBatches(g); anyStreamed = true; }
         if (verbose_) {
             std::cout << "gpu " << g.device << ": " << g.numLocal << " sequences, " << g.localChars << " chars, "
-                      << (g.wantResident ? "resident" : "streamed in batches") << "\n";
+                      << (g.wantResident ? "resident" : "streamed in " + std::to_string(g.batches.size()) + " batches") << "\n";
         }
     }
-}
-
-namespace {
-
-void allocBatch(DeviceBatch& b, size_t chars, size_t seqs) {
-    if (chars + 64 > b.chars_capacity) {
-        (void)hipFree(b.chars);
-        HIPCHECK(hipMalloc(&b.chars, chars + 64));
-        b.chars_capacity = chars + 64;
-    }
-    if (seqs + 1 > b.seq_capacity) {
-        (void)hipFree(b.offsets); (void)hipFree(b.lengths);
-        HIPCHECK(hipMalloc(&b.offsets, (seqs + 1) * sizeof(uint64_t)));
-        HIPCHECK(hipMalloc(&b.lengths, std::max<size_t>(seqs, 1) * sizeof(int32_t)));
-        b.seq_capacity = seqs + 1;
+    // Streamed shards read the DB's chars straight from the host mapping when it can be registered with the
+    // runtime (hipHostRegister: the copies become asynchronous DMA from the page cache, no staging memcpy);
+    // otherwise they go through two pinned staging buffers per GPU.  CUDASW4_AMD_NO_HOSTREGISTER=1 forces the latter.
+    if (anyStreamed && db_->num_chars() > 0) {
+        const char* no = std::getenv("CUDASW4_AMD_NO_HOSTREGISTER");
+        if (!(no && no[0] == '1')) {
+            const hipError_t e = hipHostRegister(const_cast<int8_t*>(db_->chars()), db_->num_chars(), hipHostRegisterPortable);
+            dbRegistered_ = e == hipSuccess;
+            if (!dbRegistered_) (void)hipGetLastError();
+        }
+        if (verbose_) std::cout << "DB chars " << (dbRegistered_ ? "registered for direct DMA" : "staged through pinned buffers") << "\n";
     }
 }
 
-}  // namespace
+// Batches of a streamed shard (computeDbCopyPlan, cudasw4.cuh:1177-1277): consecutive shard-local subjects up to
+// maxBatchBytes / maxBatchSequences; a batch may span adjacent length partitions (its scan is then several launches).
+void SearchDriver::planBatches(Gpu& g) {
+    const size_t maxSeq = std::max<size_t>(1, memory_.maxBatchSequences);
+    const uint64_t maxBytes = std::max<uint64_t>(memory_.maxBatchBytes, uint64_t(g.maxLen) + 4);
+    size_t cur = 0;
+    while (cur < g.numLocal) {
+        // largest e with offsets[e] - offsets[cur] <= maxBytes and e - cur <= maxSeq
+        const uint64_t target = g.localOffsets[cur] + maxBytes;
+        size_t e = size_t(std::upper_bound(g.localOffsets.begin() + long(cur), g.localOffsets.end(), target) - g.localOffsets.begin()) - 1;
+        e = std::min(e, cur + maxSeq);
+        e = std::min(std::max(e, cur + 1), g.numLocal);
+        Batch b;
+        b.lbegin = cur; b.lend = e;
+        b.bytes = g.localOffsets[e] - g.localOffsets[cur];
+        b.maxLen = db_->length(size_t(g.toGlobal(int64_t(e - 1))));
+        g.batches.push_back(b);
+        cur = e;
+    }
+}
 
 void SearchDriver::uploadShard(Gpu& g) {
     g.use();
-    allocBatch(g.residentDb, g.localChars, g.numLocal);
-    std::vector<uint64_t> offsets(g.numLocal + 1);
-    uint64_t charPos = 0;
+    if (!g.d_chars) HIPCHECK(hipMalloc(&g.d_chars, g.localChars + 64));
+    const uint64_t* off = db_->offsets();
     for (int p = 0; p < kNumLengthPartitions; p++) {
         const ShardRange r = g.ranges[p];
         if (!r.size()) continue;
-        const uint64_t* off = db_->offsets();
-        const uint64_t bytes = off[r.end] - off[r.begin];
-        HIPCHECK(hipMemcpyAsync(g.residentDb.chars + charPos, db_->chars() + (off[r.begin] - off[0]), bytes, hipMemcpyHostToDevice, g.stream));
-        HIPCHECK(hipMemcpyAsync(g.residentDb.lengths + g.localBegin[p], db_->lengths() + r.begin, r.size() * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
-        for (size_t i = 0; i < r.size(); i++) offsets[g.localBegin[p] + i] = charPos + (off[r.begin + i] - off[r.begin]);
-        charPos += bytes;
+        HIPCHECK(hipMemcpyAsync(g.d_chars + g.localOffsets[g.localBegin[p]], db_->chars() + (off[r.begin] - off[0]),
+                                off[r.end] - off[r.begin], hipMemcpyHostToDevice, g.stream));
     }
-    offsets[g.numLocal] = charPos;
-    HIPCHECK(hipMemsetAsync(g.residentDb.chars + charPos, kOtherCode, 64, g.stream));
-    HIPCHECK(hipMemcpyAsync(g.residentDb.offsets, offsets.data(), offsets.size() * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+    HIPCHECK(hipMemsetAsync(g.d_chars + g.localChars, kOtherCode, 64, g.stream));
     HIPCHECK(hipStreamSynchronize(g.stream));
     g.resident = true;
 }
@@ -269,40 +387,12 @@ void SearchDriver::uploadShard(Gpu& g) {
 void SearchDriver::prefetchDBToGpus() {
     if (!db_) throw std::runtime_error("setDatabase first");
     for (auto& g : gpus_)
-        if (g->wantResident && !g->resident) uploadShard(*g);
+        if (g->wantResident && !g->resident && g->numLocal) uploadShard(*g);
 }
 
 namespace {
 
-// Partition walk of runAlignmentKernels (cudasw4.cuh:1742-2103) over the shard-local range
-// [begin, end): largest partition first, adjacent partitions of equal kind merged into one launch.
-std::vector<Run> plan_runs(const KernelTypeConfig& kt,
-                           const std::array<size_t, kNumLengthPartitions + 1>& localBegin, size_t begin, size_t end,
-                           const Database& db, const std::array<ShardRange, kNumLengthPartitions>& ranges) {
-    std::vector<Run> runs;
-    for (int p = kNumLengthPartitions - 1; p >= 0; p--) {
-        const size_t b = std::max(begin, localBegin[p]), e = std::min(end, localBegin[p + 1]);
-        if (e <= b) continue;
-        const KernelType kind = kt.for_partition(p);
-        const int32_t maxlen = db.length(ranges[p].begin + (e - 1 - localBegin[p]));
-        // partitions 34/35 (long subjects) use the wave-wide group shape: never merged with 0..33
-        const bool sameShape = !runs.empty() && (runs.back().part_id >= kNumLengthPartitions - 2) == (p >= kNumLengthPartitions - 2);
-        if (!runs.empty() && runs.back().kind == kind && runs.back().begin == e && sameShape) {
-            runs.back().begin = b;
-        } else {
-            runs.push_back(Run{kind, p, b, e, maxlen});
-        }
-    }
-    return runs;
-}
-
-}  // namespace
-
-// Enqueue the scan of the runs of one batch whose data sits in `batch` starting at batch-local
-// position 0 (shard-local position batchBegin).  The run with the most subjects goes to the work
-// stream; the others (few long subjects) are launched FIRST on auxiliary streams so that they hold
-// their handful of workgroups while the bulk run fills the rest of the GPU.
-static void* ensure_temp(void*& ptr, size_t& have, size_t need, size_t cap) {
+void* ensure_temp(void*& ptr, size_t& have, size_t need, size_t cap) {
     need = std::min(need, cap);
     if (need > have) {
         (void)hipFree(ptr);
@@ -314,25 +404,43 @@ static void* ensure_temp(void*& ptr, size_t& have, size_t need, size_t cap) {
     return ptr;
 }
 
+}  // namespace
+
+// Enqueue the scan of the shard-local subjects [lbegin, lend) whose chars start at `chars` (device).  The run
+// with the most subjects goes to the work stream; the others (few long subjects) are launched FIRST on auxiliary
+// streams so that they hold their handful of workgroups while the bulk run fills the rest of the GPU.
 template <class GpuT>
-static void enqueue_batch(GpuT& g, const DeviceBatch& batch, size_t batchBegin, const std::vector<Run>& runs,
-                          const KernelTypeConfig& kt, const MemoryConfig& mem, int gop, int gex, int32_t maxLen) {
+static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t lend, int32_t maxLen, const Database& db,
+                          const KernelTypeConfig& kt, const MemoryConfig& mem, int gop, int gex, bool record) {
+    const auto runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, lend,
+                                       [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); });
+    const uint64_t* offsets = g.d_offsets + lbegin;
+    const int32_t* lengths = g.d_lengths + lbegin;
     bool packedUsed = false;
     HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, sizeof(int32_t), g.stream));
     size_t mainIdx = 0;
     for (size_t i = 1; i < runs.size(); i++)
         if (runs[i].end - runs[i].begin > runs[mainIdx].end - runs[mainIdx].begin) mainIdx = i;
-    const bool fork = runs.size() > 1;
-    if (fork) HIPCHECK(hipEventRecord(g.forkEvent, g.stream));
-    auto launch = [&](const Run& r, hipStream_t stream, int slot) {
+    if (runs.size() > 1) HIPCHECK(hipEventRecord(g.forkEvent, g.stream));
+    auto launch = [&](const LaunchRun& r, hipStream_t stream, int slot) {
         packedUsed |= is_packed(r.kind);
         const int32_t n = int32_t(r.end - r.begin);
         const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, r.maxlen);
         void* temp = ensure_temp(g.d_temp[slot], g.tempBytes[slot], need, mem.maxTempBytes);
-        SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, batch.chars, batch.offsets, batch.lengths,
-                                  int32_t(r.begin - batchBegin), n, r.maxlen, gop, gex, g.d_scores + batchBegin,
-                                  g.d_ids + batchBegin, int64_t(batchBegin), g.d_ovfPos, g.d_ovfCount,
-                                  is_packed(r.kind) ? 1 : 0, temp, g.tempBytes[slot], stream));
+        TimedLaunch t;
+        if (record) {
+            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
+            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
+            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end;
+            HIPCHECK(hipEventRecord(t.ev0, stream));
+        }
+        SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, chars, offsets, lengths, int32_t(r.begin - lbegin), n,
+                                  r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), g.d_ovfPos,
+                                  g.d_ovfCount, is_packed(r.kind) ? 1 : 0, temp, g.tempBytes[slot], stream));
+        if (record) {
+            HIPCHECK(hipEventRecord(t.ev1, stream));
+            g.timed.push_back(t);
+        }
     };
     int auxUsed = 0;
     bool auxBusy[GpuT::kAux] = {};
@@ -350,102 +458,148 @@ static void enqueue_batch(GpuT& g, const DeviceBatch& batch, size_t batchBegin, 
         HIPCHECK(hipStreamWaitEvent(g.stream, g.joinEvent[a], 0));
     }
     if (packedUsed) {
-        size_t n = 0;
-        for (const Run& r : runs) n += r.end - r.begin;
+        const size_t n = lend - lbegin;
         const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, int32_t(n), maxLen);
         void* temp = ensure_temp(g.d_temp[0], g.tempBytes[0], need, mem.maxTempBytes);
-        SWCHECK(sw_rescore_overflow(g.ctx, int(kt.overflowType), g.d_ovfPos, g.d_ovfCount, int32_t(n), batch.chars,
-                                    batch.offsets, batch.lengths, maxLen, gop, gex, g.d_scores + batchBegin,
-                                    g.d_ids + batchBegin, int64_t(batchBegin), temp, g.tempBytes[0], g.stream));
+        SWCHECK(sw_rescore_overflow(g.ctx, int(kt.overflowType), g.d_ovfPos, g.d_ovfCount, int32_t(n), chars, offsets,
+                                    lengths, maxLen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), temp,
+                                    g.tempBytes[0], g.stream));
     }
 }
 
-void SearchDriver::scanResident(Gpu& g, int32_t /*qlen*/) {
-    const auto runs = plan_runs(kernels_, g.localBegin, 0, g.numLocal, *db_, g.ranges);
-    enqueue_batch(g, g.residentDb, 0, runs, kernels_, memory_, gop_, gex_, g.maxLen);
-    // running total of the query (addKernel, cudasw4.cuh:46-49,2175): a single batch -> copy
-    HIPCHECK(hipMemcpyAsync(g.d_ovfCount + 1, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToDevice, g.stream));
+static void ensure_ovf_slots(int32_t*& h, size_t& cap, size_t need) {
+    if (need <= cap) return;
+    (void)hipHostFree(h);
+    h = nullptr; cap = 0;
+    HIPCHECK(hipHostMalloc(&h, need * sizeof(int32_t)));
+    cap = need;
 }
 
-// DB shard larger than the memory limit: stream it in batches through two staging buffers
-// (pinned host -> device on the copy stream, scan on the work stream), cf. cudasw4.cuh:1560-1712.
-void SearchDriver::scanStreamed(Gpu& g, int32_t /*qlen*/) {
+void SearchDriver::scanResident(Gpu& g) {
+    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, 1);
+    enqueue_batch(g, g.d_chars, 0, g.numLocal, g.maxLen, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
+    // per-query total (addKernel, cudasw4.cuh:46-49,2175): a single batch -> its count
+    HIPCHECK(hipMemcpyAsync(g.h_ovfBatch, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+}
+
+// DB shard larger than the memory limit: its chars stream through two device staging buffers (copy stream ->
+// work stream), cf. cudasw4.cuh:1560-1712; offsets and lengths are resident.  Batches run longest subjects first,
+// so the tail of the query consists of short subjects.  With the DB mapping registered the whole scan is enqueued
+// without blocking the host; the pinned fallback blocks only on its own two host buffers.
+void SearchDriver::scanStreamed(Gpu& g) {
     const uint64_t* off = db_->offsets();
-    // batch limits
-    const size_t maxSeq = std::max<size_t>(1, memory_.maxBatchSequences);
-    const size_t maxBytes = std::max<size_t>(memory_.maxBatchBytes, size_t(g.maxLen) + 4);
-    for (int i = 0; i < 2; i++) {
-        if (!g.stagingFree[i]) {
-            HIPCHECK(hipEventCreateWithFlags(&g.stagingFree[i], hipEventDisableTiming));
-            HIPCHECK(hipEventCreateWithFlags(&g.stagingReady[i], hipEventDisableTiming));
+    const size_t nb = g.batches.size();
+    uint64_t maxBytes = 0;
+    for (const Batch& b : g.batches) maxBytes = std::max(maxBytes, b.bytes);
+    if (maxBytes + 64 > g.stagingCap) {
+        for (int i = 0; i < 2; i++) {
+            (void)hipFree(g.d_staging[i]);
+            g.d_staging[i] = nullptr;
+            HIPCHECK(hipMalloc(&g.d_staging[i], maxBytes + 64));
         }
+        g.stagingCap = maxBytes + 64;
     }
-    int32_t total = 0;
+    if (!dbRegistered_ && maxBytes + 64 > g.pinnedCap) {
+        for (int i = 0; i < 2; i++) {
+            (void)hipHostFree(g.h_pinned[i]);
+            g.h_pinned[i] = nullptr;
+            HIPCHECK(hipHostMalloc(&g.h_pinned[i], maxBytes + 64));
+        }
+        g.pinnedCap = maxBytes + 64;
+    }
+    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, nb);
+    while (g.batchEv.size() < 2 * nb) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreate(&e));
+        g.batchEv.push_back(e);
+    }
+    HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
+    bool slotUsed[2] = {false, false};
     int slot = 0;
-    std::vector<bool> slotUsed(2, false);
-    for (int p = 0; p < kNumLengthPartitions; p++) {
-        const ShardRange r = g.ranges[p];
-        size_t cur = r.begin;
-        while (cur < r.end) {
-            // batch = [cur, e) of partition p within the byte / sequence limits
-            size_t e = cur;
-            while (e < r.end && e - cur < maxSeq && (off[e + 1] - off[cur]) <= maxBytes) e++;
-            if (e == cur) e = cur + 1;
-            const size_t nseq = e - cur;
-            const uint64_t bytes = off[e] - off[cur];
-            const size_t localBegin = g.localBegin[p] + (cur - r.begin);
-            DeviceBatch& b = g.staging[slot];
-            if (slotUsed[slot]) {
-                // the scan that last used this slot has finished: device and pinned buffers are free again
-                HIPCHECK(hipEventSynchronize(g.stagingFree[slot]));
-                total += g.h_ovfSlot[slot];
-            }
-            allocBatch(b, bytes, nseq);
-            if (bytes + 64 > g.pinnedCharsCap[slot]) {
-                (void)hipHostFree(g.h_pinnedChars[slot]);
-                HIPCHECK(hipHostMalloc(&g.h_pinnedChars[slot], bytes + 64));
-                g.pinnedCharsCap[slot] = bytes + 64;
-            }
-            if (nseq + 1 > g.pinnedSeqCap[slot]) {
-                (void)hipHostFree(g.h_pinnedOffsets[slot]); (void)hipHostFree(g.h_pinnedLengths[slot]);
-                HIPCHECK(hipHostMalloc(&g.h_pinnedOffsets[slot], (nseq + 1) * sizeof(uint64_t)));
-                HIPCHECK(hipHostMalloc(&g.h_pinnedLengths[slot], nseq * sizeof(int32_t)));
-                g.pinnedSeqCap[slot] = nseq + 1;
-            }
-            {   // page cache / mmap -> pinned staging, in parallel chunks (one thread saturates ~6 GB/s only)
-                const int8_t* src = db_->chars() + (off[cur] - off[0]);
+    for (size_t k = 0; k < nb; k++) {
+        const size_t bi = nb - 1 - k;
+        const Batch& b = g.batches[bi];
+        int8_t* dst = g.d_staging[slot];
+        // the scan that last used this device buffer must have finished before the copy overwrites it
+        if (slotUsed[slot]) HIPCHECK(hipStreamWaitEvent(g.copyStream, g.scanned[slot], 0));
+        if (!dbRegistered_ && slotUsed[slot]) HIPCHECK(hipEventSynchronize(g.copied[slot]));  // pinned buffer free again
+        // the batch's pieces: one contiguous slice of the chars file per length partition it touches
+        uint64_t pos = 0;
+        for (int p = 0; p < kNumLengthPartitions; p++) {
+            const size_t lb = std::max(b.lbegin, g.localBegin[p]), le = std::min(b.lend, g.localBegin[p + 1]);
+            if (le <= lb) continue;
+            const size_t gb = g.ranges[p].begin + (lb - g.localBegin[p]), ge = gb + (le - lb);
+            const uint64_t bytes = off[ge] - off[gb];
+            const int8_t* src = db_->chars() + (off[gb] - off[0]);
+            if (dbRegistered_) {
+                HIPCHECK(hipMemcpyAsync(dst + pos, src, bytes, hipMemcpyHostToDevice, g.copyStream));
+            } else {
+                // page cache / mmap -> pinned staging, in parallel chunks (one thread moves ~6 GB/s only)
                 const size_t chunk = size_t(4) << 20;
                 const long nchunks = long((bytes + chunk - 1) / chunk);
-#pragma omp parallel for schedule(static) num_threads(16)
+                int8_t* hdst = g.h_pinned[slot] + pos;
+#pragma omp parallel for schedule(static) num_threads(8)
                 for (long c = 0; c < nchunks; c++) {
-                    const size_t b = size_t(c) * chunk;
-                    std::memcpy(g.h_pinnedChars[slot] + b, src + b, std::min(chunk, size_t(bytes) - b));
+                    const size_t o = size_t(c) * chunk;
+                    std::memcpy(hdst + o, src + o, std::min(chunk, size_t(bytes) - o));
                 }
             }
-            std::memset(g.h_pinnedChars[slot] + bytes, kOtherCode, 64);
-#pragma omp parallel for schedule(static) num_threads(8)
-            for (long i = 0; i <= long(nseq); i++) g.h_pinnedOffsets[slot][i] = off[cur + size_t(i)] - off[cur];
-            std::memcpy(g.h_pinnedLengths[slot], db_->lengths() + cur, nseq * sizeof(int32_t));
-            HIPCHECK(hipMemcpyAsync(b.chars, g.h_pinnedChars[slot], bytes + 64, hipMemcpyHostToDevice, g.copyStream));
-            HIPCHECK(hipMemcpyAsync(b.offsets, g.h_pinnedOffsets[slot], (nseq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.copyStream));
-            HIPCHECK(hipMemcpyAsync(b.lengths, g.h_pinnedLengths[slot], nseq * sizeof(int32_t), hipMemcpyHostToDevice, g.copyStream));
-            HIPCHECK(hipEventRecord(g.stagingReady[slot], g.copyStream));
-            HIPCHECK(hipStreamWaitEvent(g.stream, g.stagingReady[slot], 0));
-            const KernelType kind = kernels_.for_partition(p);
-            std::vector<Run> runs{Run{kind, p, localBegin, localBegin + nseq, db_->length(e - 1)}};
-            enqueue_batch(g, b, localBegin, runs, kernels_, memory_, gop_, gex_, db_->length(e - 1));
-            HIPCHECK(hipMemcpyAsync(g.h_ovfSlot + slot, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
-            HIPCHECK(hipEventRecord(g.stagingFree[slot], g.stream));
-            slotUsed[slot] = true;
-            slot ^= 1;
-            cur = e;
+            pos += bytes;
         }
+        if (!dbRegistered_) HIPCHECK(hipMemcpyAsync(dst, g.h_pinned[slot], b.bytes, hipMemcpyHostToDevice, g.copyStream));
+        HIPCHECK(hipMemsetAsync(dst + b.bytes, kOtherCode, 64, g.copyStream));
+        HIPCHECK(hipEventRecord(g.copied[slot], g.copyStream));
+        HIPCHECK(hipStreamWaitEvent(g.stream, g.copied[slot], 0));
+        HIPCHECK(hipEventRecord(g.batchEv[2 * k], g.stream));
+        enqueue_batch(g, dst, b.lbegin, b.lend, b.maxLen, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
+        HIPCHECK(hipMemcpyAsync(g.h_ovfBatch + k, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipEventRecord(g.batchEv[2 * k + 1], g.stream));
+        HIPCHECK(hipEventRecord(g.scanned[slot], g.stream));
+        slotUsed[slot] = true;
+        slot ^= 1;
+    }
+}
+
+// Everything one GPU does for one query; runs on the GPU's worker thread when there are several GPUs.
+void SearchDriver::scanOnGpu(Gpu& g, int32_t queryLength, int k) {
+    g.lastTop = 0;
+    g.lastOverflows = 0;
+    g.spanBegin = g.spanEnd = now_seconds() - scanT0_;
+    if (g.numLocal == 0) return;
+    g.use();
+    g.qlen = queryLength;
+    if (g.wantResident && !g.resident) uploadShard(g);  // the first query pays the upload unless --uploadFull
+    SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
+    // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
+    size_t nbatches = 1;
+    if (g.resident) scanResident(g);
+    else { scanStreamed(g); nbatches = g.batches.size(); }
+    const int kk = int(std::min<size_t>(size_t(std::max(k, 0)), g.numLocal));
+    if (kk > 0) {
+        if (kk > g.topCapacity) {
+            (void)hipFree(g.d_topS); (void)hipFree(g.d_topI); (void)hipHostFree(g.h_topS); (void)hipHostFree(g.h_topI);
+            HIPCHECK(hipMalloc(&g.d_topS, kk * sizeof(float)));
+            HIPCHECK(hipMalloc(&g.d_topI, kk * sizeof(int32_t)));
+            HIPCHECK(hipHostMalloc(&g.h_topS, kk * sizeof(float)));
+            HIPCHECK(hipHostMalloc(&g.h_topI, kk * sizeof(int32_t)));
+            g.topCapacity = kk;
+        }
+        const size_t tb = sw_topk_temp_bytes(int64_t(g.numLocal), kk);
+        if (tb > g.topkTempBytes) {
+            (void)hipFree(g.d_topkTemp);
+            g.d_topkTemp = nullptr;
+            HIPCHECK(hipMalloc(&g.d_topkTemp, tb));
+            g.topkTempBytes = tb;
+        }
+        SWCHECK(sw_topk(g.ctx, g.d_scores, g.d_ids, int64_t(g.numLocal), kk, g.d_topS, g.d_topI, g.d_topkTemp,
+                        g.topkTempBytes, g.stream));
+        HIPCHECK(hipMemcpyAsync(g.h_topS, g.d_topS, kk * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipMemcpyAsync(g.h_topI, g.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        g.lastTop = kk;
     }
     HIPCHECK(hipStreamSynchronize(g.stream));
-    for (int i = 0; i < 2; i++)
-        if (slotUsed[i]) total += g.h_ovfSlot[i];
-    g.h_ovf[1] = total;
-    HIPCHECK(hipMemcpyAsync(g.d_ovfCount + 1, g.h_ovf + 1, sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
+    for (size_t i = 0; i < nbatches; i++) g.lastOverflows += g.h_ovfBatch[i];
+    g.spanEnd = now_seconds() - scanT0_;
 }
 
 ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
@@ -455,50 +609,21 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
     encodedQuery_.resize(size_t(queryLength));
     for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue(query[i]);
 
-    for (auto& gp : gpus_) { gp->use(); HIPCHECK(hipStreamSynchronize(gp->stream)); }
     const double t0 = now_seconds();
-
+    scanT0_ = t0;
     const int k = numTop_;
-    // the query goes to every GPU first (a short synchronous copy each), then the scans are enqueued: the
-    // GPUs start within microseconds of each other instead of one set-up time apart
-    for (auto& gp : gpus_) {
-        Gpu& g = *gp;
-        g.use();
-        g.lastTop = 0;
-        if (g.numLocal == 0) continue;
-        if (g.wantResident && !g.resident) uploadShard(g);  // first query pays the upload unless --uploadFull
-        SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
-    }
-    for (auto& gp : gpus_) {
-        Gpu& g = *gp;
-        g.use();
-        if (g.numLocal == 0) continue;
-        // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
-        if (g.resident) scanResident(g, queryLength);
-        else scanStreamed(g, queryLength);
-        const int kk = int(std::min<size_t>(size_t(std::max(k, 0)), g.numLocal));
-        if (kk > 0) {
-            if (kk > g.topCapacity) {
-                (void)hipFree(g.d_topS); (void)hipFree(g.d_topI); (void)hipHostFree(g.h_topS); (void)hipHostFree(g.h_topI);
-                HIPCHECK(hipMalloc(&g.d_topS, kk * sizeof(float)));
-                HIPCHECK(hipMalloc(&g.d_topI, kk * sizeof(int32_t)));
-                HIPCHECK(hipHostMalloc(&g.h_topS, kk * sizeof(float)));
-                HIPCHECK(hipHostMalloc(&g.h_topI, kk * sizeof(int32_t)));
-                g.topCapacity = kk;
-            }
-            const size_t tb = sw_topk_temp_bytes(int64_t(g.numLocal), kk);
-            if (tb > g.topkTempBytes) {
-                (void)hipFree(g.d_topkTemp);
-                HIPCHECK(hipMalloc(&g.d_topkTemp, tb));
-                g.topkTempBytes = tb;
-            }
-            SWCHECK(sw_topk(g.ctx, g.d_scores, g.d_ids, int64_t(g.numLocal), kk, g.d_topS, g.d_topI, g.d_topkTemp,
-                            g.topkTempBytes, g.stream));
-            HIPCHECK(hipMemcpyAsync(g.h_topS, g.d_topS, kk * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-            HIPCHECK(hipMemcpyAsync(g.h_topI, g.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
-            g.lastTop = kk;
+    if (workers_.empty()) {
+        scanOnGpu(*gpus_[0], queryLength, k);
+    } else {
+        for (size_t i = 0; i < gpus_.size(); i++) {
+            Gpu* g = gpus_[i].get();
+            workers_[i]->post([this, g, queryLength, k] { scanOnGpu(*g, queryLength, k); });
         }
-        HIPCHECK(hipMemcpyAsync(g.h_ovf + 1, g.d_ovfCount + 1, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        std::exception_ptr first;
+        for (auto& w : workers_) {
+            try { w->wait(); } catch (...) { if (!first) first = std::current_exception(); }
+        }
+        if (first) std::rethrow_exception(first);
     }
 
     ScanResult result;
@@ -506,11 +631,8 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
     std::vector<Hit> hits;
     for (auto& gp : gpus_) {
         Gpu& g = *gp;
-        if (g.numLocal == 0) continue;
-        g.use();
-        HIPCHECK(hipStreamSynchronize(g.stream));
-        result.stats.numOverflows += g.h_ovf[1];
-        for (int i = 0; i < g.lastTop; i++) hits.push_back(Hit{int(g.h_topS[i]), g.toGlobal(g.h_topI[i])});
+        result.stats.numOverflows += g.lastOverflows;
+        for (int i = 0; i < g.lastTop; i++) hits.push_back(Hit{int(g.h_topS[i]), idBase_ + g.toGlobal(g.h_topI[i])});
     }
     // host merge of the per-GPU lists (replaces cudasw4.cuh:1415-1463): score desc, id asc
     std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.score != b.score ? a.score > b.score : a.id < b.id; });
@@ -519,7 +641,9 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
 
     const double t1 = now_seconds();
     result.stats.seconds = t1 - t0;
-    const double cells = double(queryLength) * double(db_->total_residues());
+    uint64_t residues = 0;
+    for (auto& gp : gpus_) residues += gp->localResidues;
+    const double cells = double(queryLength) * double(residues);
     result.stats.gcups = cells / 1e9 / result.stats.seconds;  // cudasw4.cuh:2264-2271
     if (totalRunning_) { totalCells_ += cells; totalOverflows_ += result.stats.numOverflows; }
     return result;
@@ -541,6 +665,72 @@ BenchmarkStats SearchDriver::totalTimerStop() {
     s.numOverflows = totalOverflows_;
     totalRunning_ = false;
     return s;
+}
+
+// ---- measurement / verification hooks
+
+void SearchDriver::recordKernelEvents(bool on) { recordEvents_ = on; }
+
+std::vector<KernelEvent> SearchDriver::takeKernelEvents() {
+    std::vector<KernelEvent> out;
+    for (auto& gp : gpus_) {
+        Gpu& g = *gp;
+        g.use();
+        HIPCHECK(hipDeviceSynchronize());
+        if (!g.timed.empty() && g.resPrefix.empty()) {
+            g.resPrefix.assign(g.numLocal + 1, 0);
+            for (size_t i = 0; i < g.numLocal; i++) g.resPrefix[i + 1] = g.resPrefix[i] + uint64_t(db_->length(size_t(g.toGlobal(int64_t(i)))));
+        }
+        for (TimedLaunch& t : g.timed) {
+            KernelEvent e{};
+            e.gpu = g.index; e.kind = t.kind; e.part_id = t.part_id; e.qlen = t.qlen;
+            e.subjects = int64_t(t.lend - t.lbegin);
+            e.cells = double(t.qlen) * double(g.resPrefix[t.lend] - g.resPrefix[t.lbegin]);
+            e.chars = double(g.localOffsets[t.lend] - g.localOffsets[t.lbegin]);
+            HIPCHECK(hipEventElapsedTime(&e.ms, t.ev0, t.ev1));
+            out.push_back(e);
+            g.freeTimed.push_back(t);
+        }
+        g.timed.clear();
+    }
+    return out;
+}
+
+size_t SearchDriver::numLocal(int gpu) const { return gpus_.at(size_t(gpu))->numLocal; }
+uint64_t SearchDriver::localResidues(int gpu) const { return gpus_.at(size_t(gpu))->localResidues; }
+uint64_t SearchDriver::localChars(int gpu) const { return gpus_.at(size_t(gpu))->localChars; }
+bool SearchDriver::isResident(int gpu) const { return gpus_.at(size_t(gpu))->resident; }
+
+void SearchDriver::lastScores(int gpu, float* scores, int64_t* ids) {
+    Gpu& g = *gpus_.at(size_t(gpu));
+    if (!g.numLocal) return;
+    g.use();
+    HIPCHECK(hipMemcpy(scores, g.d_scores, g.numLocal * sizeof(float), hipMemcpyDeviceToHost));
+    for (int p = 0; p < kNumLengthPartitions; p++)
+        for (size_t i = 0; i < g.ranges[p].size(); i++) ids[g.localBegin[p] + i] = idBase_ + int64_t(g.ranges[p].begin + i);
+}
+
+std::vector<SearchDriver::BatchInterval> SearchDriver::lastBatchIntervals() {
+    std::vector<BatchInterval> out;
+    for (auto& gp : gpus_) {
+        Gpu& g = *gp;
+        if (g.resident || g.batches.empty() || g.batchEv.size() < 2 * g.batches.size()) continue;
+        g.use();
+        HIPCHECK(hipDeviceSynchronize());
+        for (size_t k = 0; k < g.batches.size(); k++) {
+            BatchInterval bi{g.index, 0.f, 0.f};
+            HIPCHECK(hipEventElapsedTime(&bi.begin_ms, g.scanStartEv, g.batchEv[2 * k]));
+            HIPCHECK(hipEventElapsedTime(&bi.end_ms, g.scanStartEv, g.batchEv[2 * k + 1]));
+            out.push_back(bi);
+        }
+    }
+    return out;
+}
+
+std::vector<SearchDriver::GpuSpan> SearchDriver::lastGpuSpans() const {
+    std::vector<GpuSpan> out;
+    for (auto& gp : gpus_) out.push_back(GpuSpan{gp->index, gp->spanBegin, gp->spanEnd});
+    return out;
 }
 
 void SearchDriver::printDBInfo() const {

@@ -1,12 +1,14 @@
-// search_driver.hpp — the C++ host driver: DB sharding over the GPUs of a node, residency, the
-// partition walk, overflow re-score, per-GPU top-K and the host-side merge.
+// search_driver.hpp — the C++ host driver: DB sharding over the GPUs of a node, residency, batch
+// streaming, the partition walk, overflow re-score, per-GPU top-K and the host-side merge.
 //
 // Mirrors the public surface of the reference's class CudaSW4 (cudasw4.cuh:496-839):
 //   SearchDriver(deviceIds, numTop, matrix, KernelTypeConfig, MemoryConfig, verbose)
 //   setDatabase / prefetchDBToGpus / scan / totalTimerStart / totalTimerStop / printDBInfo ...
-// but drives the GPUs only through the C ABI of include/cudasw4_amd.h.  One host thread issues
-// asynchronous work to every GPU (as the reference does); results are merged on the host instead of
-// peer copies to GPU 0 (cudasw4.cuh:1415-1463).
+// but drives the GPUs only through the C ABI of include/cudasw4_amd.h.  With one GPU the calling thread
+// issues everything; with several, one host worker thread per GPU runs that GPU's whole scan (query upload,
+// batches, re-score, top-K, copy back), so streamed shards progress on all GPUs at once — the role of the
+// reference's host-callback staging threads (cudasw4.cuh:1649-1658, dbbatching.cuh:255-276).  Results are merged
+// on the host instead of peer copies to GPU 0 (cudasw4.cuh:1415-1463).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -55,6 +57,48 @@ struct ScanResult {  // cudasw4.cuh:82-86
     BenchmarkStats stats;
 };
 
+// One launch of the scan kernel: a run of adjacent length partitions that use the same arithmetic kind.
+struct LaunchRun {
+    KernelType kind;
+    int part_id;        // largest partition of the run
+    size_t begin, end;  // subject range (shard-local positions)
+    int32_t maxlen;
+};
+
+// Partition walk of runAlignmentKernels (cudasw4.cuh:1742-2103) over the positions [begin, end) of a subject list
+// whose partition p occupies [partBegin[p], partBegin[p+1]): largest partition first, adjacent partitions of equal
+// kind merged into one launch (the kernels take any subject length; partitions 34/35 keep launches of their own
+// because they may use the wave-wide group shape).  maxLenOf(pos) = true length of the subject at pos.
+// The ONE planner: the Python mirror (cudasw4_amd/search.py) calls it through swdrv_plan_runs.
+template <class MaxLenOf>
+std::vector<LaunchRun> plan_launch_runs(const KernelTypeConfig& kt, const size_t* partBegin, size_t begin, size_t end,
+                                        MaxLenOf&& maxLenOf) {
+    std::vector<LaunchRun> runs;
+    for (int p = kNumLengthPartitions - 1; p >= 0; p--) {
+        const size_t b = begin > partBegin[p] ? begin : partBegin[p];
+        const size_t e = end < partBegin[p + 1] ? end : partBegin[p + 1];
+        if (e <= b) continue;
+        const KernelType kind = kt.for_partition(p);
+        const bool sameShape = !runs.empty() && (runs.back().part_id >= kNumLengthPartitions - 2) == (p >= kNumLengthPartitions - 2);
+        if (!runs.empty() && runs.back().kind == kind && runs.back().begin == e && sameShape) {
+            runs.back().begin = b;
+        } else {
+            runs.push_back(LaunchRun{kind, p, b, e, maxLenOf(e - 1)});
+        }
+    }
+    return runs;
+}
+
+// One timed launch (HIP events on the stream the kernel ran on), for bench.py's roofline
+struct KernelEvent {
+    int gpu, kind, part_id;
+    int32_t qlen;
+    int64_t subjects;
+    double cells;       // qlen x true residues of the launch's subjects
+    double chars;       // padded subject bytes read by the launch
+    float ms;
+};
+
 class SearchDriver {
 public:
     SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matrix, KernelTypeConfig kernels, MemoryConfig memory,
@@ -63,6 +107,10 @@ public:
     SearchDriver(const SearchDriver&) = delete;
     SearchDriver& operator=(const SearchDriver&) = delete;
 
+    // One process per GPU (torch.distributed / bench.py): this driver takes shards rank*numGpus .. of world*numGpus
+    // of every length partition (partitionDBAmongstGpus over all GPUs of the job, cudasw4.cuh:928-1004); ids stay
+    // global.  Call before setDatabase.  idBase is added to every reported id (weak-scaling replicas).
+    void setShard(int rank, int world, int64_t idBase = 0);
     void setDatabase(std::shared_ptr<Database> db);  // cudasw4.cuh:552-568
     void prefetchDBToGpus();                         // cudasw4.cuh:651-696 (--uploadFull)
     void setNumTop(int k) { numTop_ = k; }           // cudasw4.cuh:574-587
@@ -73,19 +121,40 @@ public:
     void totalTimerStart();          // cudasw4.cuh:818-824
     BenchmarkStats totalTimerStop(); // cudasw4.cuh:826-839
 
-    std::string_view getReferenceHeader(int64_t id) const { return db_->header(size_t(id)); }
-    int32_t getReferenceLength(int64_t id) const { return db_->length(size_t(id)); }
-    std::string getReferenceSequence(int64_t id) const { return db_->sequence_letters(size_t(id)); }
+    std::string_view getReferenceHeader(int64_t id) const { return db_->header(size_t(id - idBase_)); }
+    int32_t getReferenceLength(int64_t id) const { return db_->length(size_t(id - idBase_)); }
+    std::string getReferenceSequence(int64_t id) const { return db_->sequence_letters(size_t(id - idBase_)); }
     void printDBInfo() const;              // cudasw4.cuh:799-807
     void printDBLengthPartitions() const;  // cudasw4.cuh:809-816
     int numGpus() const { return int(gpus_.size()); }
 
+    // ---- measurement / verification hooks (bench.py, tests) ----
+    void recordKernelEvents(bool on);                 // HIP events around every DP launch from now on
+    std::vector<KernelEvent> takeKernelEvents();      // elapsed times of the launches recorded so far (synchronises)
+    size_t numLocal(int gpu) const;                   // subjects of this GPU's shard
+    uint64_t localResidues(int gpu) const;            // true residues of this GPU's shard
+    uint64_t localChars(int gpu) const;               // padded subject bytes of this GPU's shard
+    bool isResident(int gpu) const;
+    // every score of the last scan on `gpu` (the CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756) with
+    // the global id of each position; both arrays hold numLocal(gpu) entries
+    void lastScores(int gpu, float* scores, int64_t* ids);
+    // per-batch scan intervals of the last streamed scan: (gpu, begin ms, end ms) relative to the scan's start
+    struct BatchInterval { int gpu; float begin_ms, end_ms; };
+    std::vector<BatchInterval> lastBatchIntervals();
+    // host-clock span of every GPU's part of the last scan, in seconds since the scan started: concurrent GPUs overlap
+    struct GpuSpan { int gpu; double begin_s, end_s; };
+    std::vector<GpuSpan> lastGpuSpans() const;
+
 private:
     struct Gpu;
+    struct Worker;
     void uploadShard(Gpu& g);
-    void scanResident(Gpu& g, int32_t qlen);
-    void scanStreamed(Gpu& g, int32_t qlen);
+    void scanResident(Gpu& g);
+    void scanStreamed(Gpu& g);
+    void scanOnGpu(Gpu& g, int32_t queryLength, int k);
+    void planBatches(Gpu& g);
     std::vector<std::unique_ptr<Gpu>> gpus_;
+    std::vector<std::unique_ptr<Worker>> workers_;
     std::shared_ptr<Database> db_;
     int numTop_;
     const SubstitutionMatrix& matrix_;
@@ -93,7 +162,12 @@ private:
     MemoryConfig memory_;
     bool verbose_;
     int gop_, gex_;
+    int shardRank_ = 0, shardWorld_ = 1;
+    int64_t idBase_ = 0;
+    bool recordEvents_ = false;
+    bool dbRegistered_ = false;  // hipHostRegister of the DB's chars mapping succeeded (streamed shards copy from it directly)
     std::vector<int8_t> encodedQuery_;
+    double scanT0_ = 0;
     // total timer
     double totalSeconds_ = 0;
     double totalCells_ = 0;

@@ -15,7 +15,9 @@ ALIGN = os.path.join(_HERE, "lib", "align")
 EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db", "swdrv_pseudo_db", "swdrv_upload",
            "swdrv_num_sequences", "swdrv_num_gpus", "swdrv_set_num_top", "swdrv_scan", "swdrv_reference_length",
            "swdrv_reference_header", "swdrv_encode", "swdrv_pseudo_sequence", "swdrv_matrix", "swdrv_reader_open",
-           "swdrv_reader_next", "swdrv_reader_close"]
+           "swdrv_reader_next", "swdrv_reader_close", "swdrv_db_from_arrays", "swdrv_set_shard",
+           "swdrv_record_kernel_events", "swdrv_take_kernel_events", "swdrv_shard_info", "swdrv_last_scores",
+           "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges"]
 
 
 class DriverError(RuntimeError):
@@ -52,6 +54,18 @@ def _load():
     L.swdrv_reader_next.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
                                     ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz)]
     L.swdrv_reader_close.argtypes = [vp]
+    i64 = ctypes.c_int64
+    L.swdrv_db_from_arrays.argtypes = [vp, vp, sz, vp, vp, sz]
+    L.swdrv_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int, i64]
+    L.swdrv_record_kernel_events.argtypes = [vp, ctypes.c_int]
+    L.swdrv_take_kernel_events.argtypes = [vp, vp, ctypes.c_int]
+    L.swdrv_shard_info.argtypes = [vp, ctypes.c_int, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64),
+                                   ctypes.POINTER(ctypes.c_int)]
+    L.swdrv_last_scores.argtypes = [vp, ctypes.c_int, vp, vp]
+    L.swdrv_batch_intervals.argtypes = [vp, vp, ctypes.c_int]
+    L.swdrv_gpu_spans.argtypes = [vp, vp, ctypes.c_int]
+    L.swdrv_plan_runs.argtypes = [vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
+    L.swdrv_shard_ranges.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     return L
 
 
@@ -104,6 +118,29 @@ def _check(rc):
         raise DriverError(lib.swdrv_last_error().decode())
 
 
+def plan_runs(sorted_lengths, kind_single, kind_many_small, kind_many_large):
+    """The launch planner of the C++ driver (plan_launch_runs; no GPU needed): runs of a length-sorted subject list,
+    largest partition first -> list of dicts (kind, part_id, begin, end, maxlen)."""
+    l = np.ascontiguousarray(sorted_lengths, dtype=np.int32)
+    out = np.zeros(36 * 5, dtype=np.int64)
+    n = lib.swdrv_plan_runs(l.ctypes.data, len(l), kind_single, kind_many_small, kind_many_large, out.ctypes.data, 36)
+    if n < 0:
+        raise DriverError(lib.swdrv_last_error().decode())
+    return [{"kind": int(out[5 * i]), "part_id": int(out[5 * i + 1]), "begin": int(out[5 * i + 2]),
+             "end": int(out[5 * i + 3]), "maxlen": int(out[5 * i + 4])} for i in range(n)]
+
+
+def shard_ranges(offsets, sorted_lengths, world):
+    """partitionDBAmongstGpus as the C++ driver does it (shard_database; no GPU needed):
+    ranges[rank][partition] = (begin, end)."""
+    l = np.ascontiguousarray(sorted_lengths, dtype=np.int32)
+    o = np.ascontiguousarray(offsets, dtype=np.uint64)
+    out = np.zeros(world * 36 * 2, dtype=np.int64)
+    _check(lib.swdrv_shard_ranges(l.ctypes.data, o.ctypes.data, len(l), world, out.ctypes.data))
+    out = out.reshape(world, 36, 2)
+    return [[(int(b), int(e)) for b, e in out[r]] for r in range(world)]
+
+
 class Driver:
     """SearchDriver (C++) == the reference's CudaSW4 as `align` uses it."""
 
@@ -138,8 +175,75 @@ class Driver:
     def pseudo_db(self, num, length):
         _check(lib.swdrv_pseudo_db(self.handle, num, length))
 
+    def db_from_arrays(self, chars, offsets, lengths):
+        """DB from numpy arrays in dbdata layout (sorted by ascending length); the driver copies them."""
+        c = np.ascontiguousarray(chars, dtype=np.int8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        l = np.ascontiguousarray(lengths, dtype=np.int32)
+        _check(lib.swdrv_db_from_arrays(self.handle, c.ctypes.data, len(c), o.ctypes.data, l.ctypes.data, len(l)))
+
+    def set_shard(self, rank, world, id_base=0):
+        """One process per GPU: take shard `rank` of `world` (call before loading the DB)."""
+        _check(lib.swdrv_set_shard(self.handle, rank, world, id_base))
+
     def upload(self):
         _check(lib.swdrv_upload(self.handle))
+
+    def record_kernel_events(self, on=True):
+        _check(lib.swdrv_record_kernel_events(self.handle, int(on)))
+
+    def take_kernel_events(self):
+        """-> list of dicts (gpu, kind, part_id, qlen, subjects, cells, chars, ms), HIP-event timed launches."""
+        cap = 4096
+        while True:
+            buf = np.zeros(cap * 8, dtype=np.float64)
+            n = lib.swdrv_take_kernel_events(self.handle, buf.ctypes.data, cap)
+            if n < 0:
+                raise DriverError(lib.swdrv_last_error().decode())
+            if n <= cap:
+                break
+            raise DriverError("more than %d kernel events between two takes" % cap)
+        keys = ("gpu", "kind", "part_id", "qlen", "subjects", "cells", "chars", "ms")
+        return [dict(zip(keys, (int(v) if k in ("gpu", "kind", "part_id", "qlen", "subjects") else float(v)
+                                for k, v in zip(keys, buf[8 * i:8 * i + 8])))) for i in range(n)]
+
+    def shard_info(self, gpu=0):
+        i64 = ctypes.c_int64
+        n, r, c, res = i64(), i64(), i64(), ctypes.c_int()
+        _check(lib.swdrv_shard_info(self.handle, gpu, ctypes.byref(n), ctypes.byref(r), ctypes.byref(c), ctypes.byref(res)))
+        return {"subjects": n.value, "residues": r.value, "chars": c.value, "resident": bool(res.value)}
+
+    def last_scores(self, gpu=0):
+        """Every score of the last scan on one GPU and the global id of each position."""
+        n = self.shard_info(gpu)["subjects"]
+        s = np.zeros(max(n, 1), dtype=np.float32)
+        i = np.zeros(max(n, 1), dtype=np.int64)
+        _check(lib.swdrv_last_scores(self.handle, gpu, s.ctypes.data, i.ctypes.data))
+        return s[:n].astype(np.int32), i[:n]
+
+    def all_scores(self):
+        """Scores of the last scan for every subject of this driver's shards, indexed by global id -> (ids, scores)."""
+        ids, sc = [], []
+        for g in range(self.num_gpus()):
+            s, i = self.last_scores(g)
+            ids.append(i)
+            sc.append(s)
+        return np.concatenate(ids), np.concatenate(sc)
+
+    def batch_intervals(self):
+        buf = np.zeros(3 * 65536, dtype=np.float32)
+        n = lib.swdrv_batch_intervals(self.handle, buf.ctypes.data, 65536)
+        if n < 0:
+            raise DriverError(lib.swdrv_last_error().decode())
+        n = min(n, 65536)
+        return [(int(buf[3 * i]), float(buf[3 * i + 1]), float(buf[3 * i + 2])) for i in range(n)]
+
+    def gpu_spans(self):
+        buf = np.zeros(2 * 64, dtype=np.float64)
+        n = lib.swdrv_gpu_spans(self.handle, buf.ctypes.data, 64)
+        if n < 0:
+            raise DriverError(lib.swdrv_last_error().decode())
+        return [(float(buf[2 * i]), float(buf[2 * i + 1])) for i in range(n)]
 
     def num_sequences(self):
         return int(lib.swdrv_num_sequences(self.handle))

@@ -193,21 +193,19 @@ class Searcher:
     def _launch_plan(self):
         """Partition walk of runAlignmentKernels (cudasw4.cuh:1742-2103): largest partition first.
         Adjacent partitions that use the same arithmetic kind are merged into one launch: the kernels
-        take any subject length, so the partition only decides the kind."""
+        take any subject length, so the partition only decides the kind.  The merged walk is the C++ driver's
+        own planner (plan_launch_runs through swdrv_plan_runs) — one implementation, no drift; merge_partitions=False
+        keeps one launch per non-empty partition like the reference (tests)."""
         db, kt = self.db, self.kernel_types
+        if self.merge_partitions and db.lengths_host is not None:
+            from . import driver
+            return driver.plan_runs(db.lengths_host, kt.single_pass, kt.many_pass_small, kt.many_pass_large)
         runs = []
         for pid in range(NUM_PARTITIONS - 1, -1, -1):
             b, e = int(db.part_begin[pid]), int(db.part_end[pid])
-            if e <= b:
-                continue
-            kind = kt.kind_for_partition(pid)
-            maxlen = db.partition_max_length(pid)
-            # partitions 34/35 (long subjects) run with wave-wide groups: never merged with 0..33
-            same_shape = bool(runs) and (runs[-1]["part_id"] >= NUM_PARTITIONS - 2) == (pid >= NUM_PARTITIONS - 2)
-            if self.merge_partitions and runs and runs[-1]["kind"] == kind and runs[-1]["begin"] == e and same_shape:
-                runs[-1]["begin"] = b
-            else:
-                runs.append({"kind": kind, "part_id": pid, "begin": b, "end": e, "maxlen": maxlen})
+            if e > b:
+                runs.append({"kind": kt.kind_for_partition(pid), "part_id": pid, "begin": b, "end": e,
+                             "maxlen": db.partition_max_length(pid)})
         return runs
 
     def _ensure_temp(self, nbytes, slot=0):
@@ -335,37 +333,11 @@ class Searcher:
 
 
 def shard_ranges(offsets, lengths, world):
-    """partitionDBAmongstGpus (cudasw4.cuh:928-1004) / shard_database (csrc/host/db_format.cpp): every length
-    partition of the (length-sorted) DB is cut into <= world contiguous, char-balanced subject ranges, so each
-    rank sees every length class.  Returns ranges[rank][partition] = (begin, end)."""
-    offsets = np.asarray(offsets, dtype=np.uint64).astype(np.int64)
-    lengths = np.asarray(lengths, dtype=np.int64)
-    ends = np.searchsorted(lengths, PARTITION_BOUNDARIES, side="right")
-    begins = np.concatenate([[0], ends[:-1]])
-    out = [[(int(b), int(b)) for b in begins] for _ in range(world)]
-    for p in range(NUM_PARTITIONS):
-        pb, pe = int(begins[p]), int(ends[p])
-        if pe <= pb:
-            continue
-        quota = int(offsets[pe] - offsets[pb]) // world
-        cur = pb
-        for r in range(world):
-            if cur >= pe:
-                break
-            if r == world - 1:
-                end = pe
-            else:
-                target = int(offsets[cur]) + quota
-                end = int(np.searchsorted(offsets[cur:pe + 1], target, side="right")) + cur
-                end = min(max(end, cur + 1), pe)
-            out[r][p] = (cur, end)
-            cur = end
-        if cur < pe:
-            for r in range(world - 1, -1, -1):
-                if out[r][p][1] > out[r][p][0]:
-                    out[r][p] = (out[r][p][0], pe)
-                    break
-    return out
+    """partitionDBAmongstGpus (cudasw4.cuh:928-1004): every length partition of the (length-sorted) DB is cut into
+    <= world contiguous, char-balanced subject ranges, so each rank sees every length class.  Returns
+    ranges[rank][partition] = (begin, end).  Computed by the C++ driver's shard_database (csrc/host/db_format.cpp)."""
+    from . import driver
+    return driver.shard_ranges(offsets, lengths, world)
 
 
 def build_shard(chars, offsets, lengths, ranges):

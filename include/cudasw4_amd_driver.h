@@ -37,6 +37,13 @@ int swdrv_destroy(swdrv* d);
 
 int swdrv_open_db(swdrv* d, const char* prefix, int prefetch);
 int swdrv_pseudo_db(swdrv* d, size_t num, int32_t length);
+/* DB from arrays already in dbdata layout (ascending length, every subject padded to a multiple of 4 with code 20);
+ * the arrays are copied.  Subject i gets the header "S". */
+int swdrv_db_from_arrays(swdrv* d, const int8_t* chars, size_t nchars, const uint64_t* offsets, const int32_t* lengths, size_t n);
+/* One process per GPU: this driver scans shards rank*ngpu .. rank*ngpu+ngpu-1 of world*ngpu char-balanced shards of
+ * every length partition (partitionDBAmongstGpus over all GPUs of the job, cudasw4.cuh:928-1004); reported ids stay
+ * global (+ id_base).  Call before swdrv_open_db / swdrv_pseudo_db / swdrv_db_from_arrays. */
+int swdrv_set_shard(swdrv* d, int rank, int world, int64_t id_base);
 int swdrv_upload(swdrv* d);
 int64_t swdrv_num_sequences(swdrv* d);
 int swdrv_num_gpus(swdrv* d);
@@ -45,6 +52,29 @@ int swdrv_set_num_top(swdrv* d, int num_top);
 /* query: residue letters (not encoded).  scores/ids: capacity `cap`; *nres = number of results written. */
 int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64_t* ids, int cap,
                int* nres, int* num_overflows, double* seconds, double* gcups);
+
+/* ---- measurement / verification hooks (bench.py, tests) ----
+ * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 8 doubles per launch
+ * (gpu index, kind, part_id, query length, subjects, cells, padded subject bytes, milliseconds); returns the number
+ * of launches recorded since the last call (may exceed cap), -1 on error. */
+int swdrv_record_kernel_events(swdrv* d, int on);
+int swdrv_take_kernel_events(swdrv* d, double* out, int cap);
+int swdrv_shard_info(swdrv* d, int gpu, int64_t* num_local, int64_t* residues, int64_t* chars, int* resident);
+/* every score of the last scan on GPU `gpu` (shard order) and the global id of every position (the
+ * CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756); num_local entries each */
+int swdrv_last_scores(swdrv* d, int gpu, float* scores, int64_t* ids);
+/* last streamed scan: (gpu index, begin ms, end ms) per batch, device clock relative to that GPU's scan start */
+int swdrv_batch_intervals(swdrv* d, float* out, int cap);
+/* last scan: (begin s, end s) per GPU on the host clock, relative to the scan's start */
+int swdrv_gpu_spans(swdrv* d, double* out, int cap);
+/* The launch planner (no GPU needed): runs of a length-sorted subject list, largest partition first;
+ * 5 int64 per run (kind, part_id, begin, end, max length); returns the number of runs, -1 on error. */
+int swdrv_plan_runs(const int32_t* sorted_lengths, size_t n, int kind_single, int kind_many_small, int kind_many_large,
+                    int64_t* out, int cap);
+
+/* partitionDBAmongstGpus (cudasw4.cuh:928-1004) on raw arrays (no GPU needed): out[(rank*36 + partition)*2 + {0,1}] =
+ * begin / end of the subject range of `rank` in `partition`. */
+int swdrv_shard_ranges(const int32_t* sorted_lengths, const uint64_t* offsets, size_t n, int world, int64_t* out);
 
 /* header / length of a subject by global id (getReferenceHeader / getReferenceLength) */
 int32_t swdrv_reference_length(swdrv* d, int64_t id);

@@ -1,0 +1,170 @@
+"""GPU: BASELINE.json configs 3 and 5 on their own workloads, and bench.py's multi-rank path.
+
+config 3  allqueries vs a Swiss-Prot-sized DB, packed-int16 kernels (runsprotbenchmark.sh:42-44 `--dpx`)
+config 5  a DB above the memory limit: batch streaming per GPU with the int32 kernels everywhere
+          (runtremblbenchmark.sh, cudasw4.cuh:1560-1712), several shards in flight at once
+bench     `bench.py --gpus 2` (two ranks on this box's one GPU through the gloo test hooks): strong scaling shards
+          ONE DB, the merged top-K equals the 1-rank run
+Everything goes through the C++ host driver -> C ABI -> HIP kernels and is compared with the CPU oracle.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = O.ROOT
+FASTA = os.path.join(O.GOLDEN_DIR, "allqueries.fasta")
+
+
+def sample_db(chars, offsets, lengths, pick):
+    from cudasw4_amd import search
+    return search.build_shard(chars, offsets, lengths, [(int(i), int(i) + 1) for i in pick])[:3]
+
+
+@pytest.fixture(scope="module")
+def sprot_db():
+    from cudasw4_amd import synthdb
+    return synthdb.sprot_like()  # 570 000 sequences, ~2e8 residues, seeded
+
+
+def test_config3_sprot_like_dpx_all_queries(sprot_db):
+    """Config 3 at full size: every one of the 20 queries against the 570 k-sequence Swiss-Prot-like DB with the
+    --dpx kernel configuration.  (i) every score of a seeded 2 000-subject sample that includes the whole > 8000
+    tail equals the oracle; (ii) all 570 000 scores equal those of the all-int32 configuration (an independent
+    arithmetic path); (iii) the top-10 equals the top-10 of all scores, whose entries are oracle-checked."""
+    from cudasw4_amd import driver, search
+    chars, offsets, lengths = sprot_db
+    n = len(lengths)
+    _, letters = O.read_fasta(FASTA)
+    queries = [O.encode(q) for q in letters]
+    rng = np.random.default_rng(5)
+    tail = np.nonzero(lengths > 8000)[0]
+    assert len(tail) >= 10 and lengths[-1] > 35000
+    pick = np.unique(np.concatenate([rng.choice(n, 2000, replace=False), tail]))
+    sub = sample_db(chars, offsets, lengths, pick)
+
+    d16 = driver.Driver(devices=[0], num_top=10, kinds=(1, 1, 2, 2))
+    d16.db_from_arrays(chars, offsets, lengths)
+    d16.upload()
+    assert d16.shard_info(0)["resident"] and d16.shard_info(0)["subjects"] == n
+    d32 = driver.Driver(devices=[0], num_top=0, kinds=(2, 1, 2, 2))
+    d32.db_from_arrays(chars, offsets, lengths)
+    d32.upload()
+    total_ovf = 0
+    for qi, q in enumerate(letters):
+        r = d16.scan(q)
+        sc, ids = d16.last_scores(0)
+        assert (ids == np.arange(n)).all()
+        expect = O.scan(queries[qi], *sub, simd=True)
+        assert (sc[pick] == expect).all(), (qi, np.nonzero(sc[pick] != expect)[0][:5])
+        d32.scan(q)
+        sc32, _ = d32.last_scores(0)
+        assert (sc == sc32).all(), (qi, np.nonzero(sc != sc32)[0][:5])
+        es, ei = search.merge_topk([(sc, ids)], 10)
+        assert r["scores"].tolist() == es.tolist() and r["ids"].tolist() == ei.tolist(), qi
+        # the winners themselves against the oracle
+        top_sub = sample_db(chars, offsets, lengths, np.sort(ei))
+        assert sorted(O.scan(queries[qi], *top_sub, simd=True).tolist(), reverse=True) == es.tolist()
+        total_ovf += r["num_overflows"]
+        assert r["gcups"] > 0
+    assert total_ovf >= 0
+    d16.close()
+    d32.close()
+
+
+@pytest.mark.parametrize("kinds", [(2, 1, 2, 2), (1, 1, 2, 2)])
+def test_config5_streaming_int32_three_shards(kinds):
+    """Config 5's route: forced batch streaming (memory limit below the shard size), three shards in flight
+    (devices=[0,0,0]: one worker thread per shard), int32 kernels for every single-pass partition, batches that span
+    length partitions — vs the oracle on a ragged DB with all partition classes incl. > 8000."""
+    from cudasw4_amd import driver, synthdb
+    lengths = synthdb.sprot_like_lengths(24000, seed=11, max_len=12000)
+    chars, offsets, lengths = synthdb.random_db(lengths, seed=12, other_fraction=0.01)
+    _, letters = O.read_fasta(FASTA)
+    d = driver.Driver(devices=[0, 0, 0], num_top=25, kinds=kinds, max_gpu_mem=1, max_batch_bytes=400_000)
+    d.db_from_arrays(chars, offsets, lengths)
+    assert d.num_gpus() == 3 and not any(d.shard_info(g)["resident"] for g in range(3))
+    assert sum(d.shard_info(g)["subjects"] for g in range(3)) == len(lengths)
+    for qi in (0, 7, 13, 19):
+        r = d.scan(letters[qi])
+        expect = O.scan(O.encode(letters[qi]), chars, offsets, lengths, simd=True)
+        ids, sc = d.all_scores()
+        got = np.empty_like(sc)
+        got[ids] = sc
+        assert (got == expect).all(), (kinds, qi, np.nonzero(got != expect)[0][:5])
+        es, ei = O.topk(expect, 25)
+        assert r["scores"].tolist() == es.tolist() and r["ids"].tolist() == ei.tolist()
+        iv = d.batch_intervals()
+        assert len(iv) >= 3 * 5  # every shard needed several batches
+        if kinds[0] == 2:
+            assert r["num_overflows"] <= int((expect >= 25000 - 12500).sum())  # only partition 34 is packed
+    # the shards run concurrently: every GPU's span overlaps every other's (they start together, none waits for
+    # another to finish) and the scan's wall time is far below the sum of the spans
+    spans = d.gpu_spans()
+    assert len(spans) == 3
+    latest_begin, earliest_end = max(b for b, e in spans), min(e for b, e in spans)
+    assert latest_begin < earliest_end, spans
+    d.close()
+
+
+def test_streaming_pinned_fallback_matches(monkeypatch):
+    """The pinned-staging fallback of the streamed path (no hipHostRegister of the DB mapping) gives the same result."""
+    from cudasw4_amd import driver, synthdb
+    lengths = synthdb.sprot_like_lengths(6000, seed=3, max_len=9000)
+    chars, offsets, lengths = synthdb.random_db(lengths, seed=4)
+    _, letters = O.read_fasta(FASTA)
+    expect = O.scan(O.encode(letters[5]), chars, offsets, lengths, simd=True)
+    for env in ("0", "1"):
+        monkeypatch.setenv("CUDASW4_AMD_NO_HOSTREGISTER", env)
+        d = driver.Driver(devices=[0], num_top=5, kinds=(0, 0, 3, 3), max_gpu_mem=1, max_batch_bytes=200_000)
+        d.db_from_arrays(chars, offsets, lengths)
+        r = d.scan(letters[5])
+        ids, sc = d.all_scores()
+        assert (sc[np.argsort(ids)] == expect).all(), env
+        es, ei = O.topk(expect, 5)
+        assert r["scores"].tolist() == es.tolist() and r["ids"].tolist() == ei.tolist()
+        d.close()
+
+
+def run_bench(extra, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_two_ranks_on_one_gpu_strong_and_weak():
+    """`bench.py --gpus 2` spawns its two ranks itself; with the test hooks both use GPU 0 and gloo.  Strong scaling
+    (default): ONE DB is sharded, the merged top-10 equals the 1-rank run and every score is verified; weak: one DB
+    per rank, value counts both."""
+    common = ["--steps", "1", "--warmup", "0", "--db-size", "200000", "--no-cpu-baseline"]
+    one = run_bench(["--gpus", "1"] + common)
+    assert one["n_gpus"] == 1 and one["verified"] is True and one["scaling"] == "weak"
+    assert one["roofline"]["launches"] >= 1 and one["roofline"]["avg_launch_ms"] > 0
+    hooks = {"BENCH_FORCE_DEVICE": "0", "BENCH_DIST_BACKEND": "gloo"}
+    two = run_bench(["--gpus", "2"] + common, hooks)
+    assert two["n_gpus"] == 2 and two["verified"] is True and two["scaling"] == "strong"
+    assert two["config"]["db_subjects"] == 200000
+    assert two["config"]["top_merged_example"] == one["config"]["top_merged_example"]
+    weak = run_bench(["--gpus", "2", "--scaling", "weak"] + common, hooks)
+    assert weak["n_gpus"] == 2 and weak["verified"] is True and weak["scaling"] == "weak"
+    assert weak["config"]["db_subjects"] == 400000
+
+
+def test_bench_sprot_like_workload_small():
+    """`bench.py --workload sprot-like` (config 3's line for the driver's clock) on a reduced DB: CPU leg present,
+    every sampled score verified against the oracle, roofline from live HIP events."""
+    out = run_bench(["--workload", "sprot-like", "--db-size", "60000", "--steps", "1", "--warmup", "0",
+                     "--cpu-sample-subjects", "400"])
+    assert out["verified"] is True and out["dtype"] == "i16x2" and out["cpu_baseline"]["value"] > 0
+    assert out["roofline"]["achieved"] > 0 and out["value"] > 0
