@@ -61,7 +61,7 @@ QueryPlan plan_query(int kind, int32_t qlen, int lanes) {
     QueryPlan pl;
     pl.lanes = lanes;
     if (!kl || qlen <= 0) return pl;
-    const int maxrows = swk::max_rows(kl->packed, lanes);
+    const int maxrows = swk::max_rows(kind, lanes);
     const int64_t stripe_max = (int64_t)lanes * maxrows;
     const int ns_min = (int)((qlen + stripe_max - 1) / stripe_max);
     double best = 1e300;
@@ -167,8 +167,8 @@ int32_t border_capacity(int32_t max_len, int lanes) {
     return (int32_t)((steps + 15) / 16 * 16 + 16);  // + one prefetched quad past the end, rounded to 64 bytes
 }
 size_t border_bytes_per_wg(int32_t lcap, int lanes) {
-    const size_t junk = lanes == 16 ? swk::border_junk_words<16>() : swk::border_junk_words<64>();
-    return (size_t)(swk::kThreads / lanes) * 2 * ((size_t)lcap + junk) * sizeof(uint32_t);
+    const size_t region = lanes == 16 ? swk::border_region_words<16>(lcap) : swk::border_region_words<64>(lcap);
+    return (size_t)(swk::kThreads / lanes) * region * sizeof(uint32_t);
 }
 
 int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
@@ -263,9 +263,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // because another launch still holds the CUs simply take fewer batches
     p.work_counter = ctx->d_work + (ctx->work_next++ % kWorkSlots);
     SW_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream));
-    // short subjects: the F half of the stripe border stays in LDS (packed kinds, 16-lane groups)
-    const bool ldsf = multi && lanes == 16 && kl->packed && p.lcap <= swk::kLdsFCols;
-    SW_HIP(kl->scan(pl.rows, lanes, multi, ldsf, offs, grid, stream, p));
+    SW_HIP(kl->scan(pl.rows, lanes, multi, offs, grid, stream, p));
     return SW_OK;
 }
 

@@ -311,7 +311,7 @@ struct ScanParams {
     int32_t* ovf_pos;
     int32_t* ovf_count;
     int32_t ovf_check;
-    u32* scratch;              // stripe-border spill: per (workgroup, group): [64 junk][H lcap][64 junk][F lcap]
+    u32* scratch;              // stripe-border spill: per (workgroup, group) border_region_words(lcap) words
     int32_t lcap;
     const u32* zeros;          // >= 64 bytes of the kind's zero pattern (border of the first stripe)
     u32* work_counter;         // zeroed before the launch: next batch to hand out
@@ -687,8 +687,15 @@ __device__ __forceinline__ u32 group_max(u32 v) {
 // subjects per batch; LANES = 64: 4 groups), longest subjects first.  MULTI == the query needs more than
 // one stripe.
 // ------------------------------------------------------------------------------------------------
+// Stripe-border scratch of one group: [kJunk junk words][H/F interleaved: column j at words 2j (H) and 2j+1 (F)].
+// The last lane stores the four columns of a quad as ONE aligned 32-byte run (a full sector: no partial-line
+// write-backs); its quad q covers columns 4q-(LANES-1).., so the array starts 2*(LANES-1) words == 6 (mod 8) past a
+// 32-byte boundary.  The junk area holds the last lane's columns < 0 (2*(LANES-1) words right below the array) and
+// one 8-word slot per other lane (their stores are never read).
 template <int LANES>
-constexpr int border_junk_words() { return LANES == 16 ? 128 : 320; }  // >= 4*(LANES-1) + LANES, multiple of 64
+constexpr int border_junk_words() { return LANES == 16 ? 166 : 646; }  // >= 10*(LANES-1), == 6 (mod 8)
+template <int LANES>
+constexpr int border_region_words(int lcap) { return (border_junk_words<LANES>() + 2 * lcap + 15) / 16 * 16; }  // per group, 64-byte granular
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument).
 // Packed kinds: 1 (unconstrained) is best — forcing 3-4 waves spills the multi-stripe kernels (-3..4 %).
@@ -697,36 +704,36 @@ constexpr int border_junk_words() { return LANES == 16 ? 128 : 320; }  // >= 4*(
 #ifndef SWK_MIN_WAVES_SCALAR
 #define SWK_MIN_WAVES_SCALAR 0
 #endif
+#ifndef SWK_I32_WAVES3_MAX_R
+#define SWK_I32_WAVES3_MAX_R 32
+#endif
+#ifndef SWK_I32_WAVES3_MAX_R_MULTI
+#define SWK_I32_WAVES3_MAX_R_MULTI 32
+#endif
 template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
     // packed kinds: 2 waves/SIMD (256 VGPRs) for the tall kernels; up to SWK_WAVES3_MAX_R rows a third wave is asked for
     // (168 VGPRs): two waves cover each other's wait states only ~92 % of the time, three reach the issue peak
     if (Arith<KIND>::kPacked) return (LANES == 16 && !MULTI && R <= SWK_WAVES4_MAX_R) ? 4 : (LANES == 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
+    // int32 above 32 rows per lane: two waves per SIMD (the registers of the taller stripes; its add/max3 mix cannot
+    // co-issue anyway).  Up to 32 rows the third wave is worth more than the spills it causes in the multi-stripe kernels
+    // from R = 24 up (two-stripe queries of 850 / 1000 residues: 6.36 / 6.42 with three waves, 6.12 / 6.22 TCUPS with two)
+    if (KIND == I32 && LANES == 16 && R > (MULTI ? SWK_I32_WAVES3_MAX_R_MULTI : SWK_I32_WAVES3_MAX_R)) return 2;
     // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
     return (R <= 16 && !MULTI && LANES == 16) ? 4 : 3;
 }
 
-// F half of the stripe border kept in LDS (LDSF kernels: 16-lane groups, subjects up to ~540 residues): the
-// spill traffic that leaves the CU halves and the H half (2.8 MB per XCD) fits the 4 MB L2.
-constexpr int kLdsFCols = 576;   // columns per group (>= border_capacity of the longest subject served)
-constexpr int kLdsFJunk = 96;    // junk words in front of each group's columns (non-last lanes, columns < 0);
-                                 // stride 672 = 21 * 32 words keeps the bank pattern identical for every group
-constexpr int kLdsFStride = kLdsFCols + kLdsFJunk;
-
-template <int KIND, int R, int LANES, bool MULTI, bool LDSF = false, bool OFFS = false>
+template <int KIND, int R, int LANES, bool MULTI, bool OFFS = false>
 __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())) sw_scan_kernel(const ScanParams p) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
-    static_assert(!LDSF || (MULTI && LANES == 16), "the LDS border exists for multi-stripe 16-lane kernels only");
     constexpr int kGroups = kThreads / LANES;
     constexpr int kJunk = border_junk_words<LANES>();
-    constexpr int kJunkF = LDSF ? kLdsFJunk : kJunk;
     constexpr int SHL1 = Shift<LANES>::kShl1;
     constexpr int kQuadsPerLetterBlock = LANES;  // a lane holds 4 letters: LANES quads per reload
     constexpr int P = OFFS ? frame_classes(A::kPacked, R, LANES, MULTI) : 1;  // row classes of the column-offset frame
     __shared__ __attribute__((aligned(16))) unsigned char lds[16 + G::kTileBytes];
-    __shared__ __attribute__((aligned(16))) u32 ldsF[LDSF ? kGroups * kLdsFStride + 16 : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & (LANES - 1);  // position in the alignment group
@@ -741,18 +748,10 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         __syncthreads();
     }
 
-    // Stripe-border spill of this group: H[lcap] and F[lcap], each preceded by kJunk junk words.  The loop
-    // is kept branch-free: EVERY lane loads and stores each step, but only lane 0's load address and the
-    // last lane's store address walk the real arrays; the other lanes hit the junk words (the last lane's
-    // stores for columns t-(LANES-1) < 0 land there too).
-    u32* const borderH = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroups + group) * 2 * ((size_t)p.lcap + kJunk) + kJunk : nullptr;
-    u32* borderF = MULTI ? borderH + p.lcap + kJunk : nullptr;
-    const u32* zerosF = p.zeros;
-    if constexpr (LDSF) {
-        borderF = &ldsF[group * kLdsFStride + kLdsFJunk];
-        zerosF = &ldsF[kGroups * kLdsFStride];
-        if (tid < 16) ldsF[kGroups * kLdsFStride + tid] = A::kZero;  // published by the stripe loop's barriers
-    }
+    // Stripe-border spill of this group (layout: border_junk_words).  The loop is kept branch-free: EVERY lane loads
+    // and stores each quad, but only lane 0's load address and the last lane's store address walk the real array;
+    // the other lanes read the zeros array and write their junk slot.
+    u32* const borderHF = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroups + group) * (size_t)border_region_words<LANES>(p.lcap) + kJunk : nullptr;
 
     // OFFS: a lane starts every stripe "at column -lane": zero level a*(LANES - lane), +a per step
     const u32 apos = OFFS ? A::pos_word(p.gex_mag) : 0u;
@@ -842,22 +841,17 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             u32 nextB = A::kPacked ? fetch(s1, len1pad, 0) : 0u;
             u32 lettersA = 0, lettersB = 0;
 
-            // stripe border (MULTI only): lane 0 reads the previous stripe's bottom row four columns per
-            // quad, one quad ahead (2 x 16-byte loads); the last lane stores its own bottom row every step.
-            uint4 curH = make_uint4(A::kZero, A::kZero, A::kZero, A::kZero), curF = curH, nextH = curH, nextF = curH;
-            const int walkIn = (lane == 0 && !first) ? 4 : 0;  // words per quad the load address advances
-            const int walkOut = (lane == LANES - 1) ? 4 : 0;
-            const u32* inH = (lane == 0 && !first) ? borderH : p.zeros;
-            const u32* inF = (lane == 0 && !first) ? borderF : zerosF;
-            u32* outH = (lane == LANES - 1) ? borderH - (LANES - 1) : borderH - kJunk + 4 * lane;
-            // junk slots: 4 words per lane; in LDS they are skewed so that the 32 lanes of a half wave hit 32
-            // different banks (4*lane repeats every 8 lanes; the two groups of a half wave share a bank pattern)
-            const int junkSlot = LDSF ? 4 * lane + (lane >> 3) + 2 * (group & 1) : 4 * lane;
-            u32* outF = (lane == LANES - 1) ? borderF - (LANES - 1) : borderF - kJunkF + junkSlot;
+            // stripe border (MULTI only): lane 0 reads the previous stripe's bottom row four columns per quad, one quad
+            // ahead (2 x 16-byte loads of interleaved H/F); the last lane stores its own bottom row once per quad.
+            uint4 curH = make_uint4(A::kZero, A::kZero, A::kZero, A::kZero), curF = curH, bordA = curH, bordB = curH;
+            const int walkIn = (lane == 0 && !first) ? 8 : 0;  // words per quad the load address advances
+            const int walkOut = (lane == LANES - 1) ? 8 : 0;
+            const u32* inHF = (lane == 0 && !first) ? borderHF : p.zeros;
+            u32* outHF = (lane == LANES - 1) ? borderHF - 2 * (LANES - 1) : borderHF - kJunk + 8 * lane;
             if constexpr (MULTI) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                nextH = *reinterpret_cast<const uint4*>(inH);
-                nextF = *reinterpret_cast<const uint4*>(inF);
+                bordA = *reinterpret_cast<const uint4*>(inHF);
+                bordB = *reinterpret_cast<const uint4*>(inHF + 4);
             }
 
             auto quad = [&](int q, auto lower_tag) {
@@ -867,11 +861,13 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     nextA = fetch(s0, len0pad, q / kQuadsPerLetterBlock + 1);
                     if constexpr (A::kPacked) nextB = fetch(s1, len1pad, q / kQuadsPerLetterBlock + 1);
                 }
+                u32 bh0 = 0, bf0 = 0, bh1 = 0, bf1 = 0, bh2 = 0, bf2 = 0;
                 if constexpr (MULTI) {
-                    curH = nextH; curF = nextF;
-                    inH += walkIn; inF += walkIn;  // prefetch the next quad (the array has slack past the last one)
-                    nextH = *reinterpret_cast<const uint4*>(inH);
-                    nextF = *reinterpret_cast<const uint4*>(inF);
+                    curH = make_uint4(bordA.x, bordA.z, bordB.x, bordB.z);
+                    curF = make_uint4(bordA.y, bordA.w, bordB.y, bordB.w);
+                    inHF += walkIn;  // prefetch the next quad (the array has slack past the last one)
+                    bordA = *reinterpret_cast<const uint4*>(inHF);
+                    bordB = *reinterpret_cast<const uint4*>(inHF + 4);
                 }
                 // OFFS on long subjects: the frame of column j is a*(j mod K + LANES), i.e. a lane lowers everything it
                 // holds by a*K right before it enters a column that is a multiple of K (lane l at step m*K + l).  The
@@ -891,16 +887,16 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 };
                 if constexpr (LOWER) lower_frame(lower_lane + 0);
                 dp_step<KIND, R, LANES, 0, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first, p.wrap_class, p.wrap_last);
-                if constexpr (MULTI) { outH[0] = st.Hlast; outF[0] = st.Fout; }
+                if constexpr (MULTI) { bh0 = st.Hlast; bf0 = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 1);
                 dp_step<KIND, R, LANES, 1, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first, p.wrap_class, p.wrap_last);
-                if constexpr (MULTI) { outH[1] = st.Hlast; outF[1] = st.Fout; }
+                if constexpr (MULTI) { bh1 = st.Hlast; bf1 = st.Fout; *reinterpret_cast<uint4*>(outHF) = make_uint4(bh0, bf0, bh1, bf1); }
                 if constexpr (LOWER) lower_frame(lower_lane + 2);
                 dp_step<KIND, R, LANES, 2, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first, p.wrap_class, p.wrap_last);
-                if constexpr (MULTI) { outH[2] = st.Hlast; outF[2] = st.Fout; }
+                if constexpr (MULTI) { bh2 = st.Hlast; bf2 = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 3);
                 dp_step<KIND, R, LANES, 3, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first, p.wrap_class, p.wrap_last);
-                if constexpr (MULTI) { outH[3] = st.Hlast; outF[3] = st.Fout; outH += walkOut; outF += walkOut; }
+                if constexpr (MULTI) { *reinterpret_cast<uint4*>(outHF + 4) = make_uint4(bh2, bf2, st.Hlast, st.Fout); outHF += walkOut; }
                 lettersA = dpp<SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
                 if constexpr (OFFS && A::kWindow) {  // the windows move on by four columns
@@ -928,10 +924,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             }
             if constexpr (MULTI) {
                 // the last lane reached column 4*nquads-LANES; the next stripe reads up to 4*nquads-1: zero the rest
-                if (lane < LANES - 1) {
-                    borderH[4 * nquads - (LANES - 1) + lane] = A::kZero;
-                    borderF[4 * nquads - (LANES - 1) + lane] = A::kZero;
-                }
+                if (lane < LANES - 1)
+                    *reinterpret_cast<uint2*>(borderHF + 2 * (4 * nquads - (LANES - 1) + lane)) = make_uint2(A::kZero, A::kZero);
             }
             if constexpr (OFFS) {
                 if constexpr (A::kWindow) {

@@ -18,19 +18,24 @@ constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 768 query rows,
 #ifndef SWK_MAX_ROWS_SCALAR
 #define SWK_MAX_ROWS_SCALAR 32
 #endif
-constexpr int kMaxRowsScalar = SWK_MAX_ROWS_SCALAR;  // stripe = 512 query rows (32-bit profile entries, 43 KB tile)
+constexpr int kMaxRowsScalar = SWK_MAX_ROWS_SCALAR;  // fp32: stripe = 512 query rows (32-bit profile entries, 43 KB tile); its add/max3 co-issue wants three waves per SIMD
+#ifndef SWK_MAX_ROWS_I32
+#define SWK_MAX_ROWS_I32 48
+#endif
+constexpr int kMaxRowsI32 = SWK_MAX_ROWS_I32;  // int32 cannot co-issue, so like the packed kinds it trades the third wave for taller stripes (fewer stripes, less per-step overhead)
 // long-subject shape (64-lane groups)
 constexpr int kMaxRowsPackedLong = 16;  // stripe = 1024 query rows, 43 KB tile
 constexpr int kMaxRowsScalarLong = 8;   // stripe = 512 query rows, 43 KB tile
 
-constexpr int max_rows(bool packed, int lanes) {
-    return lanes == 16 ? (packed ? kMaxRowsPacked : kMaxRowsScalar) : (packed ? kMaxRowsPackedLong : kMaxRowsScalarLong);
+constexpr int max_rows(int kind, int lanes) {
+    const bool packed = kind == F16X2 || kind == I16X2;
+    return lanes == 16 ? (packed ? kMaxRowsPacked : kind == I32 ? kMaxRowsI32 : kMaxRowsScalar) : (packed ? kMaxRowsPackedLong : kMaxRowsScalarLong);
 }
 
 struct KindLaunch {
     // return hipSuccess or the launch error; (R, lanes) must be a compiled combination, else hipErrorInvalidValue
     // offs: the column-offset form of the recurrence (sw_dp_kernel.hpp: dp_step<OFFS>); needs a profile built with shift = a
-    hipError_t (*scan)(int R, int lanes, bool multi, bool ldsf, bool offs, int grid, hipStream_t stream, const ScanParams& p);
+    hipError_t (*scan)(int R, int lanes, bool multi, bool offs, int grid, hipStream_t stream, const ScanParams& p);
     hipError_t (*profile)(int R, int lanes, const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t nstripes,
                           unsigned char* out, int32_t shift, hipStream_t stream);
     size_t (*tile_bytes)(int R, int lanes);
@@ -44,43 +49,35 @@ const KindLaunch& launch_f32();
 
 // ---- helpers used by the kind TUs ----
 template <int KIND, int R, int LANES, bool OFFS>
-hipError_t launch_scan_ro(bool multi, bool ldsf, int grid, hipStream_t stream, const ScanParams& p) {
+hipError_t launch_scan_ro(bool multi, int grid, hipStream_t stream, const ScanParams& p) {
     // a query that needs more than one stripe always gets R > max/2 from the planner
-    constexpr int kMaxR = max_rows(Arith<KIND>::kPacked, LANES);
+    constexpr int kMaxR = max_rows(KIND, LANES);
     if constexpr (R > kMaxR) {
         return hipErrorInvalidValue;
     } else {
         if (multi) {
             if constexpr (2 * R > kMaxR) {
-                // the LDS border needs room next to the profile tile for two workgroups per CU
-                if constexpr (Arith<KIND>::kPacked && LANES == 16 &&
-                              Geometry<KIND, R, LANES>::kTileBytes + 16 * kLdsFStride * 4 + 256 <= 80 * 1024) {
-                    if (ldsf) {
-                        hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, true, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
-                        return hipGetLastError();
-                    }
-                }
-                hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, false, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
+                hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
             } else {
                 return hipErrorInvalidValue;
             }
         } else {
-            hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, false, false, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
+            hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, false, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
         }
         return hipGetLastError();
     }
 }
 
 template <int KIND, int R, int LANES>
-hipError_t launch_scan_r(bool multi, bool ldsf, bool offs, int grid, hipStream_t stream, const ScanParams& p) {
-    return offs ? launch_scan_ro<KIND, R, LANES, true>(multi, ldsf, grid, stream, p)
-                : launch_scan_ro<KIND, R, LANES, false>(multi, ldsf, grid, stream, p);
+hipError_t launch_scan_r(bool multi, bool offs, int grid, hipStream_t stream, const ScanParams& p) {
+    return offs ? launch_scan_ro<KIND, R, LANES, true>(multi, grid, stream, p)
+                : launch_scan_ro<KIND, R, LANES, false>(multi, grid, stream, p);
 }
 
 template <int KIND, int R, int LANES>
 hipError_t launch_profile_r(const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t nstripes,
                             unsigned char* out, int32_t shift, hipStream_t stream) {
-    if constexpr (R > max_rows(Arith<KIND>::kPacked, LANES)) {
+    if constexpr (R > max_rows(KIND, LANES)) {
         return hipErrorInvalidValue;
     } else {
         const size_t total = (size_t)nstripes * kLetters * (Geometry<KIND, R, LANES>::kRowBytes / 4);
@@ -93,17 +90,18 @@ hipError_t launch_profile_r(const int8_t* query, int32_t qlen, const int8_t* mat
 
 template <int KIND, int R, int LANES>
 constexpr size_t tile_bytes_r() {
-    if constexpr (R > max_rows(Arith<KIND>::kPacked, LANES)) return 0;
+    if constexpr (R > max_rows(KIND, LANES)) return 0;
     else return (size_t)Geometry<KIND, R, LANES>::kTileBytes;
 }
 
 #define SWK_FOR_EACH_R_PACKED(X) \
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48)
+#define SWK_FOR_EACH_R_I32(X) SWK_FOR_EACH_R_PACKED(X)
 #define SWK_FOR_EACH_R_SCALAR(X) \
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
 #define SWK_DEFINE_KIND(FN, KIND, FOR_EACH_R)                                                                      \
-    static hipError_t FN##_scan(int R, int lanes, bool multi, bool ldsf, bool offs, int grid, hipStream_t stream, \
+    static hipError_t FN##_scan(int R, int lanes, bool multi, bool offs, int grid, hipStream_t stream,            \
                                 const ScanParams& p) {                                                              \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN64_##KIND) } }                                 \

@@ -42,10 +42,11 @@ def test_version_and_plan_without_gpu(built):
             r, s = capi.plan_query(kind, q)
             assert 1 <= r <= 48 and 16 * r * s >= q > 16 * r * s - 16 * s   # padding below one row per lane and stripe
             assert (q + 767) // 768 <= s <= (q + 767) // 768 + 2
-    for kind in (capi.KIND_I32, capi.KIND_F32):
-        for q in (1, 256, 257, 5478):
+    for kind, rmax in ((capi.KIND_I32, 48), (capi.KIND_F32, 32)):
+        for q in (1, 256, 257, 567, 5478):
             r, s = capi.plan_query(kind, q)
-            assert 1 <= r <= 32 and 16 * r * s >= q > 16 * r * s - 16 * s
+            assert 1 <= r <= rmax and 16 * r * s >= q > 16 * r * s - 16 * s
+    assert capi.plan_query(capi.KIND_I32, 657)[1] == 1 and capi.plan_query(capi.KIND_F32, 657)[1] == 2
     with pytest.raises(capi.SwError):
         capi.plan_query(7, 100)
 

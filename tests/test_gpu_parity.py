@@ -358,7 +358,7 @@ def test_every_compiled_tile_shape():
         ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
         ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
-            rmax = {16: 48 if kind < 2 else 32, 64: 16 if kind < 2 else 8}[lanes]
+            rmax = {16: 48 if kind < 3 else 32, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
             qlens = set()
             for r in range(1, rmax + 1):
                 qlens.add(lanes * r - 1)                       # one stripe of R rows
