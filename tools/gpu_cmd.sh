@@ -1,3 +1,4 @@
 set -x
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/pytest_r2b.txt; cat gpurun_out/pytest_r2b.txt
-timeout 900 python tools/peak_sweep.py --lengths 512 --kernels half2,dpxs32 --json gpurun_out/peak_r2b.json 2>&1 | tail -5
+bash tools/collect_profiles.sh r02 1cd077a > gpurun_out/collect_r02.log 2>&1
+tail -3 gpurun_out/collect_r02.log
+cat gpurun_out/profiles_r02/kernel_counters.json
