@@ -123,7 +123,8 @@ void printHelp(char** argv) {
     std::cout << "      --top val : Output the val best scores. Default val = " << d.numTopOutputs << "\n";
     std::cout << "      --gop val : Gap open score. Overwrites our blosum-dependent default score.\n";
     std::cout << "      --gex val : Gap extend score. Overwrites our blosum-dependent default score.\n";
-    std::cout << "      --mat val: Set substitution matrix. Supported values: blosum45, blosum50, blosum62, blosum80. Default: blosum62\n\n";
+    std::cout << "      --mat val: Set substitution matrix. Supported values: blosum45, blosum50, blosum62, blosum80. Default: blosum62\n"
+                 "        (with suffix _25: the full 25-letter table for the query letters B, J, Z, X, *)\n\n";
     std::cout << "   Memory\n";
     std::cout << "      --maxGpuMem val : Try not to use more than val bytes of gpu memory per gpu. Uses all available gpu memory by default\n";
     std::cout << "      --maxTempBytes val : Size of temp storage in GPU memory. Can use suffix K,M,G. Default val = " << d.memory.maxTempBytes << "\n";

@@ -166,8 +166,17 @@ struct Database::Storage {
 Database::~Database() = default;
 
 void Database::finish() {
-    for (size_t i = 1; i < n_; i++)
-        if (lengths_[i] < lengths_[i - 1]) throw DbLoadError("DB is not sorted by sequence length");
+    // The scan kernels load 4-byte words at chars + offset + j for j < round4(length) and turn every letter byte into
+    // an LDS row offset, so a truncated, foreign or corrupt DB must be refused here, not discovered as out-of-bounds
+    // device reads or garbage scores: offsets non-decreasing with room for every padded sequence, lengths >= 0 and
+    // ascending, letter codes 0..20.
+    for (size_t i = 0; i < n_; i++) {
+        if (lengths_[i] < 0) throw DbLoadError("DB has a negative sequence length");
+        if (i > 0 && lengths_[i] < lengths_[i - 1]) throw DbLoadError("DB is not sorted by sequence length");
+        if (offsets_[i + 1] < offsets_[i]) throw DbLoadError("DB offsets are not monotonic");
+        const uint64_t padded = (uint64_t(lengths_[i]) + 3) / 4 * 4;
+        if (offsets_[i + 1] - offsets_[i] < padded) throw DbLoadError("DB offsets leave no room for a padded sequence");
+    }
     const auto& b = length_partition_bounds();
     begins_[0] = 0;
     const int32_t* first = lengths_;
@@ -180,6 +189,22 @@ void Database::finish() {
     }
     residues_ = 0;
     for (size_t i = 0; i < n_; i++) residues_ += uint64_t(lengths_[i]);
+}
+
+// every letter code of the DB is 0..20 (a parallel pass over the chars; for a memory-mapped file it reads the whole file,
+// which loadDB's prefetch does anyway)
+void Database::validate_codes() const {
+    const size_t total = num_chars();
+    const int8_t* c = chars_;
+    bool bad = false;
+#pragma omp parallel for schedule(static) reduction(|| : bad)
+    for (long blk = 0; blk < long((total + (1u << 20) - 1) >> 20); blk++) {
+        const size_t b = size_t(blk) << 20, e = std::min(total, b + (size_t(1) << 20));
+        unsigned char m = 0;
+        for (size_t i = b; i < e; i++) m |= (unsigned char)(c[i]) > 20 ? 1 : 0;
+        bad = bad || m;
+    }
+    if (bad) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
 }
 
 std::shared_ptr<Database> Database::open(const std::string& prefix, bool prefetch) {
@@ -207,6 +232,10 @@ std::shared_ptr<Database> Database::open(const std::string& prefix, bool prefetc
     db->header_offsets_ = static_cast<const uint64_t*>(s.header_offsets.ptr);
     if (db->n_ && db->offsets_[db->n_] > s.chars.bytes) throw DbLoadError("DB chars file is too short");
     db->finish();
+    // letter codes: checked when the file is read in full anyway (prefetch) or small; CUDASW4_AMD_VALIDATE_DB=1|0 forces it
+    const char* v = std::getenv("CUDASW4_AMD_VALIDATE_DB");
+    const bool check = v ? v[0] == '1' : (prefetch || db->num_chars() <= (size_t(4) << 30));
+    if (check) db->validate_codes();
     return db;
 }
 
@@ -228,7 +257,9 @@ std::shared_ptr<Database> Database::from_vectors(std::vector<int8_t> chars, std:
     db->lengths_ = s.vlengths.data();
     db->headers_ = s.vheaders.data();
     db->header_offsets_ = s.vheader_offsets.data();
+    if (db->n_ && (s.voffsets[db->n_] - s.voffsets[0]) > s.vchars.size()) throw DbLoadError("DB chars array is too short");
     db->finish();
+    db->validate_codes();
     return db;
 }
 

@@ -92,7 +92,8 @@ public:
 
 private:
     Database() = default;
-    void finish();  // validates ordering, computes partition tables
+    void finish();  // validates offsets / lengths / ordering, computes partition tables
+    void validate_codes() const;  // every letter code 0..20
     struct Storage;
     std::unique_ptr<Storage> storage_;
     const int8_t* chars_ = nullptr;

@@ -52,8 +52,10 @@ int swdrv_create(const int* devices, int ndev, int num_top, int matrix, int kind
             if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
             for (int i = 0; i < n; i++) ids.push_back(i);
         }
-        MatrixId mid;
-        if (!parse_matrix_name("blosum" + std::to_string(matrix), mid)) throw std::runtime_error("unknown matrix");
+        MatrixId mid;  // 45 | 50 | 62 | 80: the 21-letter tables; 4525 | 5025 | 6225 | 8025: the full 25-letter ones
+        const std::string mname = matrix > 100 ? "blosum" + std::to_string(matrix / 100) + "_25" : "blosum" + std::to_string(matrix);
+        if (matrix % 100 != 25 && matrix > 100) throw std::runtime_error("unknown matrix");
+        if (!parse_matrix_name(mname, mid)) throw std::runtime_error("unknown matrix");
         auto kt = [](int k) {
             if (k < 0 || k > 3) throw std::runtime_error("unknown kernel type");
             return KernelType(k);
@@ -261,8 +263,20 @@ int swdrv_matrix(int matrix, int8_t* out441) {
     MatrixId id;
     if (!parse_matrix_name("blosum" + std::to_string(matrix), id)) return -1;
     const SubstitutionMatrix& m = substitution_matrix(id);
-    std::memcpy(out441, m.m.data(), m.m.size());
+    std::memcpy(out441, m.m.data(), 441);
     return 0;
+}
+
+int swdrv_matrix25(int matrix, int8_t* out625) {
+    MatrixId id;
+    if (!parse_matrix_name("blosum" + std::to_string(matrix) + "_25", id)) return -1;
+    const SubstitutionMatrix& m = substitution_matrix(id);
+    std::memcpy(out625, m.m.data(), 625);
+    return 0;
+}
+
+void swdrv_encode25(const char* letters, int8_t* codes, size_t n) {
+    for (size_t i = 0; i < n; i++) codes[i] = encode_residue25(letters[i]);
 }
 
 int swdrv_reader_open(const char* path, swdrv_reader** out) {

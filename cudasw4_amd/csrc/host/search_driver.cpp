@@ -116,7 +116,8 @@ struct SearchDriver::Gpu {
     float* d_scores = nullptr;
     int32_t* d_ids = nullptr;
     int32_t* d_ovfPos = nullptr;
-    int32_t* d_ovfCount = nullptr;
+    int32_t* d_ovfCount = nullptr;   // kOvfLists counters: every packed run of a batch has its own overflow list
+    static constexpr int kOvfLists = 4;
     // Launches that run concurrently need their own stripe-border scratch: slot 0 = work stream,
     // slots 1.. = auxiliary streams (the reference round-robins 10 work streams, cudasw4.cuh:293,1745-1748)
     static constexpr int kAux = 2;
@@ -206,7 +207,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         g->device = dev;
         g->use();
         SWCHECK(sw_ctx_create(dev, &g->ctx));
-        SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), kAlphabet));
+        SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), matrix_.dim));
         HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&g->forkEvent, hipEventDisableTiming));
@@ -219,7 +220,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             HIPCHECK(hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&g->scanned[i], hipEventDisableTiming));
         }
-        HIPCHECK(hipMalloc(&g->d_ovfCount, sizeof(int32_t)));
+        HIPCHECK(hipMalloc(&g->d_ovfCount, Gpu::kOvfLists * sizeof(int32_t)));
         gpus_.push_back(std::move(g));
     }
     if (gpus_.size() > 1)
@@ -416,14 +417,20 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
                                        [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); });
     const uint64_t* offsets = g.d_offsets + lbegin;
     const int32_t* lengths = g.d_lengths + lbegin;
-    bool packedUsed = false;
-    HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, sizeof(int32_t), g.stream));
+    // Every packed run keeps its own overflow list (its slice of d_ovfPos) and counter, and is re-scored by a launch
+    // of its own: the group shape of a re-score follows the run's longest subject (16-lane groups for the bulk of the
+    // DB, the wave-wide shape only for the list of partition 34), not the longest subject of the whole batch.
+    HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, GpuT::kOvfLists * sizeof(int32_t), g.stream));
     size_t mainIdx = 0;
     for (size_t i = 1; i < runs.size(); i++)
         if (runs[i].end - runs[i].begin > runs[mainIdx].end - runs[mainIdx].begin) mainIdx = i;
     if (runs.size() > 1) HIPCHECK(hipEventRecord(g.forkEvent, g.stream));
-    auto launch = [&](const LaunchRun& r, hipStream_t stream, int slot) {
-        packedUsed |= is_packed(r.kind);
+    std::vector<int> ovfList(runs.size(), -1);
+    int numLists = 0;
+    for (size_t i = 0; i < runs.size(); i++)
+        if (is_packed(runs[i].kind)) ovfList[i] = std::min(numLists++, GpuT::kOvfLists - 1);
+    auto launch = [&](size_t ri, hipStream_t stream, int slot) {
+        const LaunchRun& r = runs[ri];
         const int32_t n = int32_t(r.end - r.begin);
         const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, r.maxlen);
         void* temp = ensure_temp(g.d_temp[slot], g.tempBytes[slot], need, mem.maxTempBytes);
@@ -434,9 +441,11 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
             t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end;
             HIPCHECK(hipEventRecord(t.ev0, stream));
         }
+        const bool packed = ovfList[ri] >= 0;
         SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, chars, offsets, lengths, int32_t(r.begin - lbegin), n,
-                                  r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), g.d_ovfPos,
-                                  g.d_ovfCount, is_packed(r.kind) ? 1 : 0, temp, g.tempBytes[slot], stream));
+                                  r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin),
+                                  packed ? g.d_ovfPos + (r.begin - lbegin) : nullptr, packed ? g.d_ovfCount + ovfList[ri] : nullptr,
+                                  packed ? 1 : 0, temp, g.tempBytes[slot], stream));
         if (record) {
             HIPCHECK(hipEventRecord(t.ev1, stream));
             g.timed.push_back(t);
@@ -449,22 +458,25 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         const int a = auxUsed++ % GpuT::kAux;
         if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], g.forkEvent, 0));
         auxBusy[a] = true;
-        launch(runs[i], g.aux[a], a + 1);
+        launch(i, g.aux[a], a + 1);
     }
-    if (!runs.empty()) launch(runs[mainIdx], g.stream, 0);
+    if (!runs.empty()) launch(mainIdx, g.stream, 0);
     for (int a = 0; a < GpuT::kAux; a++) {
         if (!auxBusy[a]) continue;
         HIPCHECK(hipEventRecord(g.joinEvent[a], g.aux[a]));
         HIPCHECK(hipStreamWaitEvent(g.stream, g.joinEvent[a], 0));
     }
-    if (packedUsed) {
-        const size_t n = lend - lbegin;
-        const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, int32_t(n), maxLen);
+    for (size_t i = 0; i < runs.size(); i++) {  // cudasw4.cuh:2134-2169
+        if (ovfList[i] < 0) continue;
+        const LaunchRun& r = runs[i];
+        const int32_t n = int32_t(r.end - r.begin);
+        const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, n, r.maxlen);
         void* temp = ensure_temp(g.d_temp[0], g.tempBytes[0], need, mem.maxTempBytes);
-        SWCHECK(sw_rescore_overflow(g.ctx, int(kt.overflowType), g.d_ovfPos, g.d_ovfCount, int32_t(n), chars, offsets,
-                                    lengths, maxLen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), temp,
-                                    g.tempBytes[0], g.stream));
+        SWCHECK(sw_rescore_overflow(g.ctx, int(kt.overflowType), g.d_ovfPos + (r.begin - lbegin), g.d_ovfCount + ovfList[i], n,
+                                    chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
+                                    int64_t(lbegin), temp, g.tempBytes[0], g.stream));
     }
+    (void)maxLen;
 }
 
 static void ensure_ovf_slots(int32_t*& h, size_t& cap, size_t need) {
@@ -476,10 +488,10 @@ static void ensure_ovf_slots(int32_t*& h, size_t& cap, size_t need) {
 }
 
 void SearchDriver::scanResident(Gpu& g) {
-    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, 1);
+    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, Gpu::kOvfLists);
     enqueue_batch(g, g.d_chars, 0, g.numLocal, g.maxLen, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
-    // per-query total (addKernel, cudasw4.cuh:46-49,2175): a single batch -> its count
-    HIPCHECK(hipMemcpyAsync(g.h_ovfBatch, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+    // per-query total (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
+    HIPCHECK(hipMemcpyAsync(g.h_ovfBatch, g.d_ovfCount, Gpu::kOvfLists * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
 }
 
 // DB shard larger than the memory limit: its chars stream through two device staging buffers (copy stream ->
@@ -507,7 +519,7 @@ void SearchDriver::scanStreamed(Gpu& g) {
         }
         g.pinnedCap = maxBytes + 64;
     }
-    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, nb);
+    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, nb * Gpu::kOvfLists);
     while (g.batchEv.size() < 2 * nb) {
         hipEvent_t e;
         HIPCHECK(hipEventCreate(&e));
@@ -552,7 +564,7 @@ void SearchDriver::scanStreamed(Gpu& g) {
         HIPCHECK(hipStreamWaitEvent(g.stream, g.copied[slot], 0));
         HIPCHECK(hipEventRecord(g.batchEv[2 * k], g.stream));
         enqueue_batch(g, dst, b.lbegin, b.lend, b.maxLen, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
-        HIPCHECK(hipMemcpyAsync(g.h_ovfBatch + k, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipMemcpyAsync(g.h_ovfBatch + k * Gpu::kOvfLists, g.d_ovfCount, Gpu::kOvfLists * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
         HIPCHECK(hipEventRecord(g.batchEv[2 * k + 1], g.stream));
         HIPCHECK(hipEventRecord(g.scanned[slot], g.stream));
         slotUsed[slot] = true;
@@ -598,7 +610,7 @@ void SearchDriver::scanOnGpu(Gpu& g, int32_t queryLength, int k) {
         g.lastTop = kk;
     }
     HIPCHECK(hipStreamSynchronize(g.stream));
-    for (size_t i = 0; i < nbatches; i++) g.lastOverflows += g.h_ovfBatch[i];
+    for (size_t i = 0; i < nbatches * Gpu::kOvfLists; i++) g.lastOverflows += g.h_ovfBatch[i];
     g.spanEnd = now_seconds() - scanT0_;
 }
 
@@ -607,7 +619,9 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
     if (queryLength <= 0) throw std::runtime_error("empty query");
     if (queryLength > INT32_MAX - 132) throw std::runtime_error("query too long");  // cudasw4.cuh:1281-1285
     encodedQuery_.resize(size_t(queryLength));
-    for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue(query[i]);
+    // 25-letter tables: the query keeps B, J, Z, X and '*' apart; the DB side stays the dbdata alphabet (include/cudasw4_amd.h)
+    if (matrix_.dim == 25) for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue25(query[i]);
+    else for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue(query[i]);
 
     const double t0 = now_seconds();
     scanT0_ = t0;

@@ -93,7 +93,8 @@ constexpr uint32_t kWorkSlots = 4096;
 struct sw_ctx {
     int device = 0;
     int num_cus = 0;
-    int8_t* d_matrix = nullptr;  // 21 x 21
+    int8_t* d_matrix = nullptr;  // (dim + 1) x 21: one row per query letter + the padding row, 21 subject letters
+    int dim = swk::kLetters;     // what sw_set_matrix was given: query codes are 0..dim-1
     uint32_t* d_zeros = nullptr; // per kind 64 bytes of its zero pattern (first-stripe border): [kind * 16 words]
     uint32_t* d_work = nullptr;  // kWorkSlots batch counters (dynamic batch distribution), one per launch in flight
     uint32_t work_next = 0;
@@ -152,7 +153,7 @@ int ensure_profile(sw_ctx* ctx, int kind, int lanes, bool offs, int shift, hipSt
         SW_HIP(hipMalloc(&pr.dev, cap));
         pr.capacity = cap;
     }
-    SW_HIP(kl->profile(pl.rows, lanes, ctx->d_query, ctx->qlen, ctx->d_matrix, pl.nstripes, pr.dev, shift, stream));
+    SW_HIP(kl->profile(pl.rows, lanes, ctx->d_query, ctx->qlen, ctx->d_matrix, ctx->dim, pl.nstripes, pr.dev, shift, stream));
     pr.shift = shift;
     if (!pr.ready) SW_HIP(hipEventCreateWithFlags(&pr.ready, hipEventDisableTiming));
     SW_HIP(hipEventRecord(pr.ready, stream));
@@ -296,7 +297,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
     if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = atoll(e);
-    hipError_t e = hipMalloc(&ctx->d_matrix, swk::kLetters * swk::kLetters);
+    hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
     if (e == hipSuccess) {
@@ -328,12 +329,25 @@ int sw_ctx_destroy(sw_ctx* ctx) {
 
 int sw_set_matrix(sw_ctx* ctx, const int8_t* matrix_host, int dim) {
     if (!ctx || !matrix_host) return fail(SW_ERR_INVALID, "null argument");
-    if (dim != swk::kLetters) return fail(SW_ERR_INVALID, "only 21 x 21 matrices (20 amino acids + other) are supported");
-    for (int i = 0; i < dim; i++)
-        if (matrix_host[swk::kPadLetter * dim + i] >= 0 || matrix_host[i * dim + swk::kPadLetter] >= 0)
-            return fail(SW_ERR_INVALID, "scores against the padding letter must be negative");
+    if (dim != 21 && dim != 25) return fail(SW_ERR_INVALID, "substitution matrices are 21 x 21 (20 amino acids + other) or 25 x 25 (types.hpp:205-396)");
+    // internal form: one row per query letter (dim of them) + the row of the query's padding, 21 columns = the dbdata
+    // alphabet of the subjects (codes 0..19, 20 = "other" and padding).  25-letter tables: subject code 20 is scored with
+    // the table's X column (index 23), the padding row is the X row; both must be negative so that padding neutralises itself.
+    constexpr int kX = 23;
+    int8_t m[26 * swk::kLetters];
+    auto subject_col = [&](int j) { return (dim == 25 && j == swk::kPadLetter) ? kX : j; };
+    for (int i = 0; i <= dim; i++) {
+        const int qi = i < dim ? i : (dim == 25 ? kX : swk::kPadLetter);
+        for (int j = 0; j < swk::kLetters; j++) m[i * swk::kLetters + j] = matrix_host[qi * dim + subject_col(j)];
+    }
+    for (int i = 0; i <= dim; i++)
+        if (m[i * swk::kLetters + swk::kPadLetter] >= 0) return fail(SW_ERR_INVALID, "scores against the padding letter must be negative");
+    for (int j = 0; j < swk::kLetters; j++)
+        if (m[dim * swk::kLetters + j] >= 0) return fail(SW_ERR_INVALID, "scores against the padding letter must be negative");
     SW_HIP(hipSetDevice(ctx->device));
-    SW_HIP(hipMemcpy(ctx->d_matrix, matrix_host, dim * dim, hipMemcpyHostToDevice));
+    SW_HIP(hipMemcpy(ctx->d_matrix, m, (size_t)(dim + 1) * swk::kLetters, hipMemcpyHostToDevice));
+    if (ctx->have_query && dim < ctx->dim) ctx->have_query = false;  // the installed query may hold codes of the larger alphabet
+    ctx->dim = dim;
     ctx->have_matrix = true;
     for (auto& row : ctx->profiles)
         for (auto& shape : row)
@@ -345,7 +359,7 @@ int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void
     if (!ctx || !query_codes_host) return fail(SW_ERR_INVALID, "null argument");
     if (qlen <= 0) return fail(SW_ERR_INVALID, "query length must be positive");
     for (int32_t i = 0; i < qlen; i++)
-        if (query_codes_host[i] < 0 || query_codes_host[i] >= swk::kLetters) return fail(SW_ERR_INVALID, "query code out of range");
+        if (query_codes_host[i] < 0 || query_codes_host[i] >= ctx->dim) return fail(SW_ERR_INVALID, "query code out of range for the installed matrix");
     SW_HIP(hipSetDevice(ctx->device));
     if ((size_t)qlen > ctx->query_capacity) {
         if (ctx->d_query) SW_HIP(hipFree(ctx->d_query));

@@ -993,7 +993,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 // ------------------------------------------------------------------------------------------------
 template <int KIND, int R, int LANES>
 __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_t qlen,
-                                        const int8_t* __restrict__ matrix21, int32_t nstripes,
+                                        const int8_t* __restrict__ matrix21, int32_t pad_row, int32_t nstripes,
                                         unsigned char* __restrict__ profile, int32_t shift) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
@@ -1012,7 +1012,8 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
             auto entry = [&](int row_in_lane) -> u32 {
                 if (row_in_lane >= R) return 0u;  // unused upper half of an odd R's last word
                 const int64_t row = (int64_t)stripe * G::kStripeRows + lane * R + row_in_lane;
-                const int qc = row < qlen ? (int)query[row] : kPadLetter;
+                // matrix21: (query letters + one padding row `pad_row`) x 21 subject letters
+                const int qc = row < qlen ? (int)query[row] : pad_row;
                 // OFFS kernels (shift = a): the diagonal step raises the frame by a per column and by a per row class;
                 // the row above lane-local row 0 is the previous lane's last row (dp_step<OFFS>)
                 const int P = frame_classes(A::kPacked, R, LANES, nstripes > 1);  // the scan kernel's (MULTI == more than one stripe)

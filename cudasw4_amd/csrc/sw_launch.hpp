@@ -36,8 +36,8 @@ struct KindLaunch {
     // return hipSuccess or the launch error; (R, lanes) must be a compiled combination, else hipErrorInvalidValue
     // offs: the column-offset form of the recurrence (sw_dp_kernel.hpp: dp_step<OFFS>); needs a profile built with shift = a
     hipError_t (*scan)(int R, int lanes, bool multi, bool offs, int grid, hipStream_t stream, const ScanParams& p);
-    hipError_t (*profile)(int R, int lanes, const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t nstripes,
-                          unsigned char* out, int32_t shift, hipStream_t stream);
+    hipError_t (*profile)(int R, int lanes, const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t pad_row,
+                          int32_t nstripes, unsigned char* out, int32_t shift, hipStream_t stream);
     size_t (*tile_bytes)(int R, int lanes);
     bool packed;
 };
@@ -75,7 +75,7 @@ hipError_t launch_scan_r(bool multi, bool offs, int grid, hipStream_t stream, co
 }
 
 template <int KIND, int R, int LANES>
-hipError_t launch_profile_r(const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t nstripes,
+hipError_t launch_profile_r(const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t pad_row, int32_t nstripes,
                             unsigned char* out, int32_t shift, hipStream_t stream) {
     if constexpr (R > max_rows(KIND, LANES)) {
         return hipErrorInvalidValue;
@@ -83,7 +83,7 @@ hipError_t launch_profile_r(const int8_t* query, int32_t qlen, const int8_t* mat
         const size_t total = (size_t)nstripes * kLetters * (Geometry<KIND, R, LANES>::kRowBytes / 4);
         const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);  // grid-stride loop covers the rest
         hipLaunchKernelGGL((sw_build_profile_kernel<KIND, R, LANES>), dim3(grid), dim3(256), 0, stream, query, qlen,
-                           matrix21, nstripes, out, shift);
+                           matrix21, pad_row, nstripes, out, shift);
         return hipGetLastError();
     }
 }
@@ -107,8 +107,8 @@ constexpr size_t tile_bytes_r() {
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN64_##KIND) } }                                 \
         return hipErrorInvalidValue;                                                                                \
     }                                                                                                               \
-    static hipError_t FN##_profile(int R, int lanes, const int8_t* q, int32_t qlen, const int8_t* m, int32_t ns,    \
-                                   unsigned char* out, int32_t shift, hipStream_t s) {                              \
+    static hipError_t FN##_profile(int R, int lanes, const int8_t* q, int32_t qlen, const int8_t* m, int32_t pr,    \
+                                   int32_t ns, unsigned char* out, int32_t shift, hipStream_t s) {                  \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_PROF16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_PROF64_##KIND) } }                                 \
         return hipErrorInvalidValue;                                                                                \

@@ -17,7 +17,8 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_reference_header", "swdrv_encode", "swdrv_pseudo_sequence", "swdrv_matrix", "swdrv_reader_open",
            "swdrv_reader_next", "swdrv_reader_close", "swdrv_db_from_arrays", "swdrv_set_shard",
            "swdrv_record_kernel_events", "swdrv_take_kernel_events", "swdrv_shard_info", "swdrv_last_scores",
-           "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges"]
+           "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges", "swdrv_matrix25",
+           "swdrv_encode25"]
 
 
 class DriverError(RuntimeError):
@@ -66,6 +67,8 @@ def _load():
     L.swdrv_gpu_spans.argtypes = [vp, vp, ctypes.c_int]
     L.swdrv_plan_runs.argtypes = [vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
     L.swdrv_shard_ranges.argtypes = [vp, vp, sz, ctypes.c_int, vp]
+    L.swdrv_matrix25.argtypes = [ctypes.c_int, vp]
+    L.swdrv_encode25.argtypes = [ctypes.c_char_p, vp, sz]
     return L
 
 
@@ -94,6 +97,23 @@ def matrix(which=62) -> np.ndarray:
     out = np.empty(441, dtype=np.int8)
     if lib.swdrv_matrix(which, out.ctypes.data) != 0:
         raise ValueError("unknown matrix %r" % which)
+    return out
+
+
+def matrix25(which=62) -> np.ndarray:
+    """The full 25 x 25 table, letter order ARNDCQEGHILKMFPSTWYVBJZX*."""
+    out = np.empty(625, dtype=np.int8)
+    if lib.swdrv_matrix25(which, out.ctypes.data) != 0:
+        raise ValueError("unknown matrix %r" % which)
+    return out
+
+
+def encode25(letters) -> np.ndarray:
+    """Query letters -> codes 0..24 for the 25-letter tables (anything else -> X)."""
+    if isinstance(letters, str):
+        letters = letters.encode()
+    out = np.empty(len(letters), dtype=np.int8)
+    lib.swdrv_encode25(letters, out.ctypes.data, len(letters))
     return out
 
 

@@ -187,7 +187,7 @@ class Searcher:
         self.scores = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
         self.ids = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         self.ovf_pos = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-        self.ovf_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.ovf_count = torch.zeros(NUM_PARTITIONS + 4, dtype=torch.int32, device=self.device)  # one counter per packed run
         self._plan = self._launch_plan()
 
     def _launch_plan(self):
@@ -237,7 +237,7 @@ class Searcher:
         self.ctx.set_query(q, sp)
         self.ovf_count.zero_()
         self.scores.fill_(-1.0)  # cudasw4.cuh:405-409
-        packed_used = False
+        packed_runs = []  # (plan index, overflow list slot): every packed run has its own list and re-score launch
         # The reference round-robins partition launches over 10 work streams (cudasw4.cuh:293,1745-1748) so
         # that small partitions overlap.  Here: the run with the most subjects stays on the caller's stream,
         # the (few, long-subject) others go to side streams and are launched FIRST so that they hold their
@@ -263,15 +263,17 @@ class Searcher:
             tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(kind, run["part_id"], n, run["maxlen"]),
                                              slot + 1 if on_side else 0)
             ovf_check = 1 if kind in capi.MAX_ACC else 0
-            packed_used |= bool(ovf_check)
+            lst = len(packed_runs)
+            if ovf_check:
+                packed_runs.append((i, lst))
             if self.record_kernel_events:
                 k0 = torch.cuda.Event(enable_timing=True)
                 k0.record(st)
             self.ctx.scan_partition(kind, run["part_id"], db.chars.data_ptr(), db.offsets.data_ptr(),
                                     db.lengths.data_ptr(), run["begin"], n, run["maxlen"], self.gop, self.gex,
                                     self.scores.data_ptr(), self.ids.data_ptr(), db.id_offset,
-                                    self.ovf_pos.data_ptr(), self.ovf_count.data_ptr(), ovf_check, tptr, tbytes,
-                                    st.cuda_stream)
+                                    self.ovf_pos.data_ptr() + 4 * run["begin"], self.ovf_count.data_ptr() + 4 * lst,
+                                    ovf_check, tptr, tbytes, st.cuda_stream)
             if self.record_kernel_events:
                 k1 = torch.cuda.Event(enable_timing=True)
                 k1.record(st)
@@ -284,12 +286,14 @@ class Searcher:
                 joins.append(j)
         for j in joins:
             stream.wait_event(j)
-        if packed_used:  # cudasw4.cuh:2117-2172
+        for i, lst in packed_runs:  # cudasw4.cuh:2117-2172; the group shape follows the run's longest subject
+            run = plan[i]
             okind = self.kernel_types.overflow
-            tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(okind, -1, db.num_sequences, db.max_length))
-            self.ctx.rescore_overflow(okind, self.ovf_pos.data_ptr(), self.ovf_count.data_ptr(), db.num_sequences,
+            n = run["end"] - run["begin"]
+            tptr, tbytes = self._ensure_temp(self.ctx.scan_temp_bytes(okind, -1, n, run["maxlen"]))
+            self.ctx.rescore_overflow(okind, self.ovf_pos.data_ptr() + 4 * run["begin"], self.ovf_count.data_ptr() + 4 * lst, n,
                                       db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(),
-                                      db.max_length, self.gop, self.gex, self.scores.data_ptr(), self.ids.data_ptr(),
+                                      run["maxlen"], self.gop, self.gex, self.scores.data_ptr(), self.ids.data_ptr(),
                                       db.id_offset, tptr, tbytes, sp)
         k = min(self.num_top, db.num_sequences)
         top_scores = top_ids = None
@@ -304,7 +308,8 @@ class Searcher:
             top_scores, top_ids = out_s, out_i
         cells = float(len(q)) * float(db.total_residues)
         res = ScanResult(scores=np.zeros(0, np.int32), reference_ids=np.zeros(0, np.int64), num_overflows=-1)
-        res.stats = {"cells": cells, "launches": len(self._plan), "_top": (top_scores, top_ids)}
+        # the counters are reused by the next scan: keep this scan's values (a stream-ordered copy)
+        res.stats = {"cells": cells, "launches": len(self._plan), "_top": (top_scores, top_ids), "_ovf": self.ovf_count.clone()}
         if not sync:
             return res
         if timed:
@@ -317,13 +322,13 @@ class Searcher:
         return self.finish(res)
 
     def finish(self, res):
-        """Copy the top-K of an enqueued scan to the host (D2H of cudasw4.cuh:1465-1487).  Only valid
-        before the next scan reuses the overflow counter."""
+        """Copy the top-K and the overflow count of an enqueued scan to the host (D2H of cudasw4.cuh:1465-1487)."""
         top_scores, top_ids = res.stats.pop("_top", (None, None))
         if top_scores is not None:
             res.scores = top_scores.cpu().numpy().astype(np.int32)
             res.reference_ids = top_ids.cpu().numpy().astype(np.int64)
-        res.num_overflows = int(self.ovf_count.item())
+        ovf = res.stats.pop("_ovf", None)
+        res.num_overflows = int(ovf.sum().item()) if ovf is not None else -1
         return res
 
     def all_scores(self):

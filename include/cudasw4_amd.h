@@ -66,9 +66,16 @@ int sw_device_count(void);
 int sw_ctx_create(int device, sw_ctx** out);
 int sw_ctx_destroy(sw_ctx* ctx);
 
-/* setProgramWideBlosum (blosum.hpp:26, blosum.cu:21-119): install a dim x dim substitution matrix
- * (HOST pointer, row-major int8; dim 21 = 20 amino acids + "other").  The last row/column must be
- * negative: padding is scored with it (half2_kernels.cuh:251-257, cudasw4.cuh:1298). */
+/* setProgramWideBlosum (blosum.hpp:26, blosum.cu:21-119): install a dim x dim substitution matrix (HOST pointer,
+ * row-major int8, rows = query letters, columns = subject letters).
+ *   dim 21: 20 amino acids + "other" (types.hpp:29-270).  The last row/column must be negative: padding is scored
+ *           with it (half2_kernels.cuh:251-257, cudasw4.cuh:1298).
+ *   dim 25: the full tables, letter order ARNDCQEGHILKMFPSTWYVBJZX* (types.hpp:205-396; the reference's
+ *           CAN_USE_FULL_BLOSUM build, options.cpp:135-143).  QUERY codes are then 0..24.  SUBJECT codes stay the
+ *           dbdata alphabet 0..20 — makedb encodes every DB with ConvertAA_20 (makedb.cpp:171,361), so B, J, Z, X and
+ *           '*' of a subject are all code 20 — and code 20 is scored with the table's X column (every entry of which
+ *           is negative, so it still neutralises padding; the column is checked).  The reference's own full build
+ *           would index the table with the raw code 20, i.e. score unknown subject letters and all padding as 'B'. */
 int sw_set_matrix(sw_ctx* ctx, const int8_t* matrix_host, int dim);
 
 /* CudaSW4::setQuery (cudasw4.cuh:1280-1310): install the encoded query (HOST pointer, codes
@@ -94,7 +101,11 @@ size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t
  *   lengths         DEVICE int32 true lengths
  *   first_pos, n    subjects first_pos .. first_pos+n-1 (batch-local positions, the reference's
  *                   counting PositionsIterator, kernels.cuh:28)
- *   max_subject_len upper bound of lengths[first_pos .. first_pos+n)
+ *   max_subject_len upper bound of lengths[first_pos .. first_pos+n).  CONTRACT: it sizes the stripe-border scratch of
+ *                   multi-stripe queries (sw_scan_temp_bytes) and the kernels never walk past that scratch, so an
+ *                   under-reported bound is memory-safe but SILENTLY truncates longer subjects at the bound (their
+ *                   scores are then those of the truncated subject).  Pass the true maximum (the reference passes the
+ *                   partition's boundary, cudasw4.cuh:1767-1912); over-reporting only costs scratch.
  *   gop, gex        gap open / extend scores, both <= 0 (reference: -11 / -1)
  *   scores, ids     DEVICE, indexed by position: scores[pos] = score, ids[pos] = id_offset + pos
  *   ovf_pos/count   DEVICE; when ovf_check != 0 a subject whose packed score reaches the kind's

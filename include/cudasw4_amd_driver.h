@@ -27,7 +27,8 @@ typedef struct swdrv swdrv;
 const char* swdrv_last_error(void);
 
 /* devices/ndev: HIP device ids; ndev = 0 -> all visible devices.
- * matrix: 45 | 50 | 62 | 80.  kinds: SW_KIND_* for single / many_small / many_large / overflow.
+ * matrix: 45 | 50 | 62 | 80 (the 21-letter tables) or 4525 | 5025 | 6225 | 8025 (the full 25-letter tables: the query
+ * is then encoded with 25 letters, the DB stays the 21-code dbdata alphabet, see include/cudasw4_amd.h).  kinds: SW_KIND_* for single / many_small / many_large / overflow.
  * max_gpu_mem = 0 -> unlimited. */
 int swdrv_create(const int* devices, int ndev, int num_top, int matrix,
                  int kind_single, int kind_many_small, int kind_many_large, int kind_overflow,
@@ -88,6 +89,9 @@ void swdrv_encode(const char* letters, int8_t* codes, size_t n);
 void swdrv_pseudo_sequence(int32_t length, int seed, int8_t* codes);
 /* 21 x 21 substitution matrix (types.hpp:29-270); matrix = 45 | 50 | 62 | 80; returns 0 or -1 */
 int swdrv_matrix(int matrix, int8_t* out441);
+/* 25 x 25 table (types.hpp:205-396), letter order ARNDCQEGHILKMFPSTWYVBJZX*, and its query encoder (anything else -> X) */
+int swdrv_matrix25(int matrix, int8_t* out625);
+void swdrv_encode25(const char* letters, int8_t* codes, size_t n);
 /* FASTA / FASTQ (.gz) reader (kseqpp/kseqpp.hpp:54-118): open -> next* -> close.  next returns 1 while there is a
  * record; the header / sequence pointers stay valid until the following call. */
 typedef struct swdrv_reader swdrv_reader;

@@ -6,6 +6,7 @@
 // pinned against them and golden fixtures can be generated (tests/golden/make_golden.py).
 //
 //   types.hpp:29-156 (+ BLOSUM80_20)   -> ref_blosum21()
+//   types.hpp:205-396                  -> ref_blosum25()
 //   convert.cuh:6-34                   -> ref_encode()
 //   length_partitions.hpp:75-113       -> ref_partition_boundaries()
 //   dbdata.hpp:222-272 (PseudoDBdata)  -> ref_pseudodb()
@@ -37,6 +38,21 @@ int ref_blosum21(int which, int8_t* out) {
         case 50: return put(cudasw4::BLOSUM50_20::get1D());
         case 62: return put(cudasw4::BLOSUM62_20::get1D());
         case 80: return put(cudasw4::BLOSUM80_20::get1D());
+    }
+    return -1;
+}
+
+// which: 45, 50, 62, 80.  out: 25*25 int8 (types.hpp:205-396, letter order ARNDCQEGHILKMFPSTWYVBJZX*). returns dim (25) or -1.
+int ref_blosum25(int which, int8_t* out) {
+    auto put = [&](auto flat) {
+        for (size_t i = 0; i < flat.size(); i++) out[i] = flat[i];
+        return int(25);
+    };
+    switch (which) {
+        case 45: return put(cudasw4::BLOSUM45::get1D());
+        case 50: return put(cudasw4::BLOSUM50::get1D());
+        case 62: return put(cudasw4::BLOSUM62::get1D());
+        case 80: return put(cudasw4::BLOSUM80::get1D());
     }
     return -1;
 }

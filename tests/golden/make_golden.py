@@ -9,7 +9,7 @@ Needs oracle/_ref/ (built by `make -C oracle ref` from /root/reference, see orac
 Outputs (data only — inputs and expected outputs):
   allqueries.fasta                 the reference's query set (data file, runpeakbenchmark.sh:26)
   allqueries_db/aq*                dbdata files written by the reference makedb for that FASTA
-  ref_tables.json                  BLOSUM 21x21 tables, partition bounds, encoder map, pseudo-DB residues
+  ref_tables.json                  BLOSUM 21x21 and 25x25 tables, partition bounds, encoder map, pseudo-DB residues
   ref_scores.json                  scores computed by the reference DP:
                                      pseudo[L][q]      20 queries x pseudo subject of length L (seed 42)
                                      allvsall[i][j]    20 x 20
@@ -67,11 +67,17 @@ def main():
         buf = (ctypes.c_int8 * 441)()
         assert shim.ref_blosum21(which, buf) == 21
         tables[str(which)] = [int(x) for x in buf]
+    tables25 = {}
+    for which in (45, 50, 62, 80):  # types.hpp:205-396, letter order ARNDCQEGHILKMFPSTWYVBJZX*
+        buf = (ctypes.c_int8 * 625)()
+        assert shim.ref_blosum25(which, buf) == 25
+        tables25[str(which)] = [int(x) for x in buf]
     bounds = (ctypes.c_int32 * 64)()
     nb = shim.ref_partition_boundaries(bounds, 64)
     encmap = list(ref_encode(bytes(range(256))))
     out_tables = {
         "blosum21": tables,
+        "blosum25": tables25,
         "partition_boundaries": [int(bounds[i]) for i in range(nb)],
         "encode_map_256": encmap,
         "pseudodb_seed42_first2048": list(pseudo_codes(2048, 42)),

@@ -96,3 +96,20 @@ def test_sort_db_and_merge_topk():
     assert all(int(o) % 4 == 0 for o in so)
     s, i = search.merge_topk([([9, 5, 5], [4, 1, 7]), ([9, 6], [2, 11])], 4)
     assert s.tolist() == [9, 9, 6, 5] and i.tolist() == [2, 4, 11, 1]
+
+
+def test_full_25_letter_tables_and_query_encoder():
+    """types.hpp:205-396: the host library's 25 x 25 tables equal the reference's; every entry of the X column is
+    negative (subject code 20 and all padding are scored with it); the 25-letter query encoder keeps B, J, Z, X, *."""
+    import numpy as np
+    from cudasw4_amd import driver
+    g = O.golden("ref_tables.json")
+    for which in (45, 50, 62, 80):
+        m = driver.matrix25(which).reshape(25, 25)
+        assert m.reshape(-1).tolist() == g["blosum25"][str(which)]
+        assert (m[:, 23] < 0).all() and (m[23, :] < 0).all()
+        assert (m[:20, :20] == driver.matrix(which).reshape(21, 21)[:20, :20]).all()
+        assert m[24, 24] == 1  # '*' vs '*' scores +1: why these tables need a padding row of their own
+    assert driver.encode25("ARNDCQEGHILKMFPSTWYVBJZX*").tolist() == list(range(25))
+    assert driver.encode25("abU-").tolist() == [23, 23, 23, 23]
+    assert driver.encode("BJZX*").tolist() == [20] * 5

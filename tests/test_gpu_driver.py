@@ -150,3 +150,32 @@ def test_align_interactive_mode(tmp_path):
     assert len(out) == 2 + 20 * 2
     es19, ei19 = expected_top(g["allvsall"][19], 2)
     assert out[-2].startswith("Result 0. Score: %d." % es19[0]) and out[-2].endswith("referenceId %d" % ei19[0])
+
+
+def test_driver_and_align_with_full_25_letter_matrix(tmp_path):
+    """`--mat blosum62_25` / matrix=6225: the query is encoded with 25 letters (B, J, Z, X, * distinct), the DB stays in
+    the dbdata alphabet; C++ driver and align CLI vs the oracle."""
+    from cudasw4_amd import driver
+    rng = np.random.default_rng(8)
+    chars = np.fromfile(GOLDEN_DB + "0chars", dtype=np.int8)
+    offsets = np.fromfile(GOLDEN_DB + "0offsets", dtype=np.uint64)
+    lengths = np.fromfile(GOLDEN_DB + "0lengths", dtype=np.int32)
+    _, seqs = O.read_fasta(FASTA)
+    q = bytearray(seqs[7])
+    for pos, letter in zip(rng.choice(len(q), 40, replace=False), b"BJZX*" * 8):
+        q[pos] = letter
+    q = bytes(q)
+    m = driver.matrix25(62).reshape(25, 25)[:, list(range(20)) + [23]]
+    expect = O.scan(driver.encode25(q), chars, offsets, lengths, m21=np.ascontiguousarray(m))
+    assert (expect != O.scan(O.encode(q), chars, offsets, lengths)).any()  # the full table does change scores
+    es, ei = O.topk(expect, 6)
+    d = driver.Driver(devices=[0], num_top=6, matrix=6225, kinds=(1, 1, 2, 2))
+    d.open_db(GOLDEN_DB)
+    r = d.scan(q)
+    assert r["scores"].tolist() == es.tolist() and r["ids"].tolist() == ei.tolist()
+    d.close()
+    fa = str(tmp_path / "q.fa")
+    open(fa, "wb").write(b">q\n" + q + b"\n")
+    p = subprocess.run([driver.ALIGN, "--query", fa, "--db", GOLDEN_DB, "--top", "2", "--mat", "blosum62_25"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "blosum: blosum62_25" in p.stdout and "Result 0. Score: %d." % es[0] in p.stdout and "Result 1. Score: %d." % es[1] in p.stdout

@@ -471,3 +471,51 @@ def test_randomized_stress_many_scans():
             check_overflow_count(res.num_overflows, expect[packed], lengths[packed], 2048)
         if name == "dpxs16+dpxs32":
             check_overflow_count(res.num_overflows, expect[packed], lengths[packed], 25000)
+
+
+def full_matrix_as_oracle_rows(m25):
+    """The 25 x 25 table as the oracle takes it: one row per QUERY letter (25), 21 columns = the dbdata alphabet of the
+    subjects, where code 20 ("other") is scored with the table's X column (include/cudasw4_amd.h, sw_set_matrix)."""
+    m = np.asarray(m25, dtype=np.int8).reshape(25, 25)
+    cols = list(range(20)) + [23]
+    return np.ascontiguousarray(m[:, cols])
+
+
+@pytest.mark.parametrize("which", [62, 45])
+def test_full_25_letter_matrix_all_kinds(which):
+    """SURVEY §8 f4 / the reference's CAN_USE_FULL_BLOSUM build (options.cpp:135-143, types.hpp:205-396): a 25 x 25
+    table through sw_set_matrix; queries with all 25 letters (B, J, Z, X, * score differently), subjects in the dbdata
+    alphabet incl. code 20; single- and multi-stripe queries, both group shapes, all four kinds, vs the scalar oracle."""
+    torch, capi, search = gpu_modules()
+    from cudasw4_amd import driver
+    rng = np.random.default_rng(1234 + which)
+    m25 = driver.matrix25(which)
+    mo = full_matrix_as_oracle_rows(m25)
+    lens = np.sort(np.concatenate([rng.integers(1, 600, 300), rng.integers(1281, 3000, 12), [8200]]))
+    seqs = [rng.integers(0, 21, int(l)).astype(np.int8) for l in lens]
+    db = O.make_db(seqs)
+    gop, gex = (-11, -1) if which == 62 else (-13, -2)
+    for qlen in (37, 300, 769, 1700):
+        q = rng.integers(0, 25, qlen).astype(np.int8)
+        q[::7] = 24  # plenty of '*' (the +1 diagonal entry) and of the ambiguity letters
+        q[3::11] = 20
+        expect = O.scan(q, *db, m21=mo, gop=gop, gex=gex)
+        for cfg, kt in kinds_configs(search, capi).items():
+            got, _, _ = scan_all_scores(search, capi, db, q, kernel_types=kt, matrix=m25, gop=gop, gex=gex)
+            np.testing.assert_array_equal(got, expect, err_msg="%s qlen %d" % (cfg, qlen))
+    # a query of the 21-letter alphabet scores the same under both tables whenever the subject has no code 20
+    clean = [s for s in seqs[:200] if (s < 20).all() and len(s) > 0][:50]
+    dbc = O.make_db(clean)
+    q = rng.integers(0, 20, 400).astype(np.int8)
+    a, _, _ = scan_all_scores(search, capi, dbc, q, matrix=m25, gop=gop, gex=gex)
+    b, _, _ = scan_all_scores(search, capi, dbc, q, matrix=driver.matrix(which), gop=gop, gex=gex)
+    np.testing.assert_array_equal(a, b)
+    # codes outside the installed alphabet are refused
+    ctx = capi.Context(0)
+    ctx.set_matrix(driver.matrix(which))
+    with pytest.raises(capi.SwError):
+        ctx.set_query(np.array([0, 22, 3], dtype=np.int8))
+    ctx.set_matrix(m25)
+    ctx.set_query(np.array([0, 22, 3], dtype=np.int8))
+    with pytest.raises(capi.SwError):
+        ctx.set_query(np.array([0, 25], dtype=np.int8))

@@ -202,9 +202,79 @@ def test_host_input_helpers_match_reference(golden_dir):
         driver.matrix(63)
 
 
-def test_cpp_reader_and_sharding_match_python_mirror(tmp_path, golden_dir):
-    """The C++ DB reader / partition counts / shard_database against the reference's metadata file and the
-    Python mirror used by bench.py (search.shard_ranges)."""
+def restated_shard_ranges(offsets, lengths, world):
+    """partitionDBAmongstGpus (cudasw4.cuh:928-1004, dbdata.cpp:265-292) restated independently of the product:
+    per length partition <= world contiguous ranges of ~chars/world, each ending at the first subject boundary
+    past its quota, leftovers to the last non-empty range."""
+    offsets = np.asarray(offsets, dtype=np.uint64).astype(np.int64)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    ends = np.searchsorted(lengths, O.partition_boundaries(), side="right")
+    begins = np.concatenate([[0], ends[:-1]])
+    out = [[(int(b), int(b)) for b in begins] for _ in range(world)]
+    for p in range(36):
+        pb, pe = int(begins[p]), int(ends[p])
+        if pe <= pb:
+            continue
+        quota = int(offsets[pe] - offsets[pb]) // world
+        cur = pb
+        for r in range(world):
+            if cur >= pe:
+                break
+            if r == world - 1:
+                end = pe
+            else:
+                end = int(np.searchsorted(offsets[cur:pe + 1], int(offsets[cur]) + quota, side="right")) + cur
+                end = min(max(end, cur + 1), pe)
+            out[r][p] = (cur, end)
+            cur = end
+        if cur < pe:
+            for r in range(world - 1, -1, -1):
+                if out[r][p][1] > out[r][p][0]:
+                    out[r][p] = (out[r][p][0], pe)
+                    break
+    return out
+
+
+def test_corrupt_databases_are_refused(tmp_path):
+    """Database::open validates what the kernels rely on (ADVICE r1): monotonic offsets with room for every padded
+    sequence, non-negative ascending lengths, letter codes 0..20, file sizes."""
+    dbinspect = os.path.join(LIBDIR, "dbinspect")
+    rng = np.random.default_rng(31)
+    fasta = str(tmp_path / "in.fa")
+    _random_fasta(fasta, rng, 300)
+    good = str(tmp_path / "good")
+    subprocess.check_call([MAKEDB, fasta, good], stdout=subprocess.DEVNULL)
+    assert subprocess.run([dbinspect, good], capture_output=True).returncode == 0
+
+    def variant(name, mutate):
+        prefix = str(tmp_path / name)
+        for suffix in ("metadata", "0chars", "0offsets", "0lengths", "0headers", "0headeroffsets", "0metadata"):
+            open(prefix + suffix, "wb").write(open(good + suffix, "rb").read())
+        mutate(prefix)
+        p = subprocess.run([dbinspect, prefix], capture_output=True, text=True)
+        assert p.returncode == 1, name
+        return p.stderr
+
+    def patch(suffix, dtype, fn):
+        def m(prefix):
+            a = np.fromfile(prefix + suffix, dtype=dtype)
+            fn(a)
+            a.tofile(prefix + suffix)
+        return m
+
+    assert "codes outside" in variant("badcode", patch("0chars", np.int8, lambda a: a.__setitem__(100, 77)))
+    assert "codes outside" in variant("negcode", patch("0chars", np.int8, lambda a: a.__setitem__(5, -3)))
+    assert "not monotonic" in variant("offdown", patch("0offsets", np.uint64, lambda a: a.__setitem__(10, a[9] - 4)))
+    assert "no room" in variant("offtight", patch("0offsets", np.uint64, lambda a: a.__setitem__(slice(200, None), a[200:] - 8)))
+    assert "negative" in variant("neglen", patch("0lengths", np.int32, lambda a: a.__setitem__(0, -1)))
+    assert "not sorted" in variant("unsorted", patch("0lengths", np.int32, lambda a: a.__setitem__(50, 1)))
+    assert "too short" in variant("truncated", lambda prefix: open(prefix + "0chars", "r+b").truncate(1000))
+    assert "do not match" in variant("shortoffsets", lambda prefix: open(prefix + "0offsets", "r+b").truncate(8 * 100))
+
+
+def test_cpp_reader_and_sharding_match_restatement(tmp_path, golden_dir):
+    """The C++ DB reader / partition counts / shard_database (the ONE shard cutter: search.shard_ranges calls it too)
+    against the reference's metadata file and an independent restatement of the reference's algorithm."""
     import json
     from cudasw4_amd import search
     dbinspect = os.path.join(LIBDIR, "dbinspect")
@@ -221,8 +291,9 @@ def test_cpp_reader_and_sharding_match_python_mirror(tmp_path, golden_dir):
         info = json.loads(subprocess.check_output([dbinspect, prefix, str(shards)]))
         assert info["num_sequences"] == len(lengths) and info["residues"] == int(lengths.sum())
         assert info["partition_counts"] == counts_file.tolist()
-        expect = search.shard_ranges(offsets, lengths, shards)
+        expect = restated_shard_ranges(offsets, lengths, shards)
         assert info["shards"] == [[list(r) for r in shard] for shard in expect]
+        assert search.shard_ranges(offsets, lengths, shards) == expect
     info = json.loads(subprocess.check_output([dbinspect, os.path.join(golden_dir, "allqueries_db", "aq"), "2"]))
     assert info["num_sequences"] == 20 and info["first_header"].startswith("gi|")
     bad = subprocess.run([dbinspect, str(tmp_path / "nope")], capture_output=True, text=True)

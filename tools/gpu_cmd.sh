@@ -1,4 +1,2 @@
 set -x
-bash tools/collect_profiles.sh r02 1cd077a > gpurun_out/collect_r02.log 2>&1
-tail -3 gpurun_out/collect_r02.log
-cat gpurun_out/profiles_r02/kernel_counters.json
+timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > gpurun_out/pytest_r2d.txt; cat gpurun_out/pytest_r2d.txt
