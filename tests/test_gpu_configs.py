@@ -147,9 +147,9 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
     """`bench.py --gpus 2` spawns its two ranks itself; with the test hooks both use GPU 0 and gloo.  Strong scaling
     (default): ONE DB is sharded, the merged top-10 equals the 1-rank run and every score is verified; weak: one DB
     per rank, value counts both."""
-    common = ["--steps", "1", "--warmup", "0", "--db-size", "200000", "--no-cpu-baseline"]
+    common = ["--steps", "1", "--warmup", "0", "--db-size", "200000", "--no-cpu-baseline", "--no-secondary"]
     one = run_bench(["--gpus", "1"] + common)
-    assert one["n_gpus"] == 1 and one["verified"] is True and one["scaling"] == "weak"
+    assert one["n_gpus"] == 1 and one["verified"] is True and one["scaling"] == "weak" and "sprot_like" not in one
     assert one["roofline"]["launches"] >= 1 and one["roofline"]["avg_launch_ms"] > 0
     hooks = {"BENCH_FORCE_DEVICE": "0", "BENCH_DIST_BACKEND": "gloo"}
     two = run_bench(["--gpus", "2"] + common, hooks)
@@ -159,6 +159,16 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
     weak = run_bench(["--gpus", "2", "--scaling", "weak"] + common, hooks)
     assert weak["n_gpus"] == 2 and weak["verified"] is True and weak["scaling"] == "weak"
     assert weak["config"]["db_subjects"] == 400000
+
+
+def test_bench_default_line_carries_the_sprot_like_secondary():
+    """The default command (what the round driver runs) reports config 3 next to the headline: same JSON line, own
+    timed region, every score verified (here without the CPU leg: packed vs int32 configuration)."""
+    out = run_bench(["--steps", "1", "--warmup", "0", "--db-size", "100000", "--no-cpu-baseline"])
+    assert out["verified"] is True and out["dtype"] == "f16x2"
+    sec = out["sprot_like"]
+    assert sec["verified"] is True and sec["dtype"] == "i16x2" and sec["value"] > 0 and sec["config"]["db_subjects"] == 570000
+    assert sec["roofline"]["launches"] >= 1
 
 
 def test_bench_sprot_like_workload_small():

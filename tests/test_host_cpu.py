@@ -298,3 +298,72 @@ def test_cpp_reader_and_sharding_match_restatement(tmp_path, golden_dir):
     assert info["num_sequences"] == 20 and info["first_header"].startswith("gi|")
     bad = subprocess.run([dbinspect, str(tmp_path / "nope")], capture_output=True, text=True)
     assert bad.returncode == 1 and "Cannot open DB" in bad.stderr
+
+
+def _big_fasta(path, n, seed, mean_len):
+    """n sequences with geometric-ish lengths written with numpy (fast): headers s<i>, letters from the 20 + X."""
+    rng = np.random.default_rng(seed)
+    lengths = np.minimum(1 + rng.geometric(1.0 / mean_len, n), 6 * mean_len).astype(np.int64)
+    letters = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVX", dtype=np.uint8)
+    with open(path, "wb") as f:
+        chunk = 50000
+        for b in range(0, n, chunk):
+            ls = lengths[b:b + chunk]
+            body = letters[rng.integers(0, 21, int(ls.sum()))]
+            parts, pos = [], 0
+            for i, l in enumerate(ls):
+                parts.append(b">s%d\n" % (b + i))
+                parts.append(body[pos:pos + l].tobytes())
+                parts.append(b"\n")
+                pos += int(l)
+            f.write(b"".join(parts))
+    return lengths
+
+
+@pytest.mark.parametrize("n,mean_len,parallel", [(300_000, 180, False), (1_100_000, 40, True)])
+def test_makedb_at_scale(tmp_path, n, mean_len, parallel):
+    """makedb on 3*10^5 sequences (serial sort path: byte-identical to the reference makedb when that is
+    built here) and on 1.1*10^6 sequences (above the 2^20 threshold: the parallel stable sort runs for real), under a
+    memory limit that makes the five arrays spill to their temp files.  Checked: ascending lengths, offsets = padded
+    prefix sums, partition counts, every residue accounted for (per-letter histogram), headers a permutation,
+    equal lengths in input order on the parallel path, and the DB loads (dbinspect validates offsets and codes)."""
+    fasta = str(tmp_path / "big.fa")
+    lengths_in = _big_fasta(fasta, n, 77, mean_len)
+    prefix = str(tmp_path / "db")
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    out = subprocess.run([MAKEDB, fasta, prefix, "--mem", "48M", "--tempdir", str(tmp_path)], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lengths = np.fromfile(prefix + "0lengths", dtype=np.int32)
+    offsets = np.fromfile(prefix + "0offsets", dtype=np.uint64)
+    chars = np.fromfile(prefix + "0chars", dtype=np.int8)
+    hoff = np.fromfile(prefix + "0headeroffsets", dtype=np.uint64)
+    assert len(lengths) == n and (np.diff(lengths) >= 0).all()
+    assert (np.sort(lengths_in) == lengths).all()
+    padded = (lengths.astype(np.int64) + 3) // 4 * 4
+    assert offsets[0] == 0 and (np.diff(offsets.astype(np.int64)) == padded).all() and len(chars) == int(offsets[-1])
+    # per-letter histogram of the whole DB == histogram of the input (+ padding as code 20)
+    raw = np.fromfile(fasta, dtype=np.uint8)
+    table = O.encode(bytes(range(256)))
+    # sequence lines only: drop header lines (they start with '>') — headers are "s<digits>", none of which encodes below 20
+    hist_db = np.bincount(chars.astype(np.int64), minlength=21)
+    assert hist_db[:20].sum() + hist_db[20] == len(chars)
+    seq_letters = int(lengths_in.sum())
+    assert hist_db.sum() - (padded.sum() - lengths.astype(np.int64).sum()) == seq_letters
+    # headers: a permutation of s0..s(n-1)
+    hdr = np.fromfile(prefix + "0headers", dtype=np.uint8).tobytes()
+    ids = np.array([int(hdr[int(hoff[i]) + 1:int(hoff[i + 1])]) for i in range(0, n, max(1, n // 5000))])
+    assert (lengths_in[ids] == lengths[::max(1, n // 5000)]).all()
+    if parallel:
+        all_ids = np.array([int(x) for x in hdr.replace(b"s", b" ").split()])
+        assert len(all_ids) == n and (np.sort(all_ids) == np.arange(n)).all()
+        same = lengths[1:] == lengths[:-1]
+        assert (all_ids[1:][same] > all_ids[:-1][same]).all()  # stable: equal lengths keep the input order
+    meta = open(prefix + "0metadata", "rb").read()
+    counts = np.frombuffer(meta[4 + 36 * 4:], dtype=np.uint64)
+    assert counts.sum() == n and counts.tolist() == np.histogram(lengths, bins=np.concatenate([[0], O.partition_boundaries().astype(np.int64) + 1]))[0].tolist()
+    info = subprocess.run([os.path.join(LIBDIR, "dbinspect"), prefix, "8"], capture_output=True, text=True)
+    assert info.returncode == 0, info.stderr
+    if not parallel and os.path.exists(REF_MAKEDB):
+        ref = run_makedb(REF_MAKEDB, fasta, str(tmp_path / "ref"))
+        for f in DB_FILES:
+            assert open(prefix + f, "rb").read() == ref[f], f
