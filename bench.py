@@ -376,7 +376,7 @@ def measure(env, args, workload, want_cpu):
             f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=comm_dev)
             dist.all_reduce(f, op=dist.ReduceOp.MIN)
             ok = bool(f.item())
-        verified = ok
+        verified = None if ok is None else bool(ok)
 
     if rank == 0:
         # dominant kernel: group the HIP-event timed launches by kernel instantiation (kind, rows per lane, stripes, shape)

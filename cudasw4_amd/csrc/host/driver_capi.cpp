@@ -141,7 +141,7 @@ int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64
 }
 
 int swdrv_record_kernel_events(swdrv* d, int on) {
-    return guarded([&] { d->driver->recordKernelEvents(on != 0); });
+    return guarded([&] { d->driver->recordKernelEvents(on); });
 }
 
 int swdrv_take_kernel_events(swdrv* d, double* out, int cap) {

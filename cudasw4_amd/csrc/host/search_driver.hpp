@@ -129,7 +129,9 @@ public:
     int numGpus() const { return int(gpus_.size()); }
 
     // ---- measurement / verification hooks (bench.py, tests) ----
-    void recordKernelEvents(bool on);                 // HIP events around every DP launch from now on
+    // HIP events around the DP launches from now on: 0 off, 1 every launch, 2 only the launches on the work stream
+    // (the bulk run of every batch; the few-subject launches on the auxiliary streams stay unobserved)
+    void recordKernelEvents(int mode);
     std::vector<KernelEvent> takeKernelEvents();      // elapsed times of the launches recorded so far (synchronises)
     size_t numLocal(int gpu) const;                   // subjects of this GPU's shard
     uint64_t localResidues(int gpu) const;            // true residues of this GPU's shard
@@ -164,7 +166,7 @@ private:
     int gop_, gex_;
     int shardRank_ = 0, shardWorld_ = 1;
     int64_t idBase_ = 0;
-    bool recordEvents_ = false;
+    int recordEvents_ = 0;
     bool dbRegistered_ = false;  // hipHostRegister of the DB's chars mapping succeeded (streamed shards copy from it directly)
     std::vector<int8_t> encodedQuery_;
     double scanT0_ = 0;
