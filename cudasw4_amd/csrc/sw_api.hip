@@ -47,7 +47,7 @@ bool kind_packed(int kind) { return kind == SW_KIND_F16X2 || kind == SW_KIND_I16
 struct QueryPlan {
     int rows = 0;      // R: query rows per lane
     int nstripes = 0;  // stripes of lanes*R rows
-    int lanes = 16;    // lanes per alignment group: 16 (DPP row) or 64 (whole wave, long subjects)
+    int lanes = 16;    // lanes per alignment group: 16 (DPP row), 64 (whole wave, long subjects) or 8 (half row, short queries)
 };
 
 // Pick (R, nstripes) with R a compiled value.  Replaces the reference's subject-length ->
@@ -89,6 +89,15 @@ struct Profile {
 }  // namespace
 
 constexpr uint32_t kWorkSlots = 4096;
+// Longest query that runs on 8-lane groups (measured on the peak DB, tools/short_query_sweep.py: at L = 512 the packed
+// kinds gain +14 % at 144 residues, +8 % at 280 and lose 1 % from 320 on, where the 8-lane kernels need the registers of
+// two waves per SIMD; the 32-bit kinds gain up to 222 residues; shorter subjects move both limits up)
+#ifndef SW_LANES8_MAX_QUERY_PACKED
+#define SW_LANES8_MAX_QUERY_PACKED 288
+#endif
+#ifndef SW_LANES8_MAX_QUERY_SCALAR
+#define SW_LANES8_MAX_QUERY_SCALAR 240
+#endif
 
 struct sw_ctx {
     int device = 0;
@@ -104,9 +113,10 @@ struct sw_ctx {
     size_t query_capacity = 0;
     int32_t qlen = 0;
     bool have_query = false;
-    Profile profiles[4][2][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups][plain | column-offset recurrence]
+    Profile profiles[4][3][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups, 2 = 8-lane groups][plain | column-offset recurrence]
     bool use_offs = true;        // CUDASW4_AMD_NO_OFFS=1: always the plain recurrence (A/B measurements)
     int64_t long16_min = -1;     // CUDASW4_AMD_LONG16_MIN: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
+    int32_t lanes8_max_q = -1;   // CUDASW4_AMD_LANES8_MAX_Q: queries up to this length use 8-lane groups (0: never; -1: the built-in limits)
 };
 
 namespace {
@@ -123,8 +133,16 @@ int max_grid(const sw_ctx* ctx) { return std::max(1, ctx->num_cus) * ctx->grid_m
 // overflowed subjects can have any length: long ones would dominate a 16-lane launch
 int rescore_lanes(int32_t max_subject_len) { return max_subject_len > 1280 ? 64 : 16; }
 
-int lanes_for_partition(const sw_ctx* ctx, int part_id, int32_t n) {
-    if (part_id < SW_NUM_LENGTH_PARTITIONS - 2) return 16;
+int shape_index(int lanes) { return lanes == 64 ? 1 : lanes == 8 ? 2 : 0; }
+
+// Short queries run on 8-lane groups (half DPP rows): twice the rows per lane for the same query, so the per-step
+// overhead is spread over twice the cells, and 7 instead of 15 fill steps per subject (sw_dp_kernel.hpp: Shift).
+int lanes_for_partition(const sw_ctx* ctx, int kind, int part_id, int32_t n) {
+    if (part_id < SW_NUM_LENGTH_PARTITIONS - 2) {
+        const bool fits8 = ctx->qlen <= 8 * swk::max_rows(kind, 8);  // single-stripe kernels only
+        const int32_t limit = ctx->lanes8_max_q >= 0 ? ctx->lanes8_max_q : kind_packed(kind) ? SW_LANES8_MAX_QUERY_PACKED : SW_LANES8_MAX_QUERY_SCALAR;
+        return (ctx->have_query && fits8 && ctx->qlen <= limit) ? 8 : 16;
+    }
     const int64_t fills_gpu_twice = (int64_t)2 * std::max(1, ctx->num_cus) * 4 * 32;
     if (part_id == SW_NUM_LENGTH_PARTITIONS - 2) return n >= (ctx->long16_min >= 0 ? ctx->long16_min : 512) ? 16 : 64;
     return n >= fills_gpu_twice ? 16 : 64;
@@ -132,7 +150,7 @@ int lanes_for_partition(const sw_ctx* ctx, int part_id, int32_t n) {
 
 
 int ensure_profile(sw_ctx* ctx, int kind, int lanes, bool offs, int shift, hipStream_t stream) {
-    Profile& pr = ctx->profiles[kind][lanes == 64][offs];
+    Profile& pr = ctx->profiles[kind][shape_index(lanes)][offs];
     if (pr.valid && pr.shift != shift) pr.valid = false;  // other gap-extension score than last time
     if (pr.valid) {
         // built on another stream earlier in this query: order this stream after the build
@@ -203,7 +221,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     const bool offs = ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
     int rc = ensure_profile(ctx, kind, lanes, offs, offs ? a : 0, stream);
     if (rc != SW_OK) return rc;
-    const Profile& prof = ctx->profiles[kind][lanes == 64][offs];
+    const Profile& prof = ctx->profiles[kind][shape_index(lanes)][offs];
     const QueryPlan pl = prof.plan;
     const bool multi = pl.nstripes > 1;
 
@@ -297,6 +315,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
     if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = atoll(e);
+    if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_Q")) ctx->lanes8_max_q = atoi(e);
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
@@ -391,7 +410,7 @@ int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstri
 
 size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0 || n <= 0) return 0;
-    const int lanes = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, part_id, n);
+    const int lanes = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, kind, part_id, n);
     const QueryPlan pl = plan_query(kind, ctx->qlen, lanes);
     if (pl.nstripes <= 1) return 0;
     const int subj_per_batch = (swk::kThreads / lanes) * (kind_packed(kind) ? 2 : 1);
@@ -406,7 +425,7 @@ int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, c
                       int ovf_check, void* temp, size_t temp_bytes, void* stream) {
     if (part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS) return fail(SW_ERR_INVALID, "partition id out of range");
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
-    return scan_common(ctx, kind, lanes_for_partition(ctx, part_id, n), chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
+    return scan_common(ctx, kind, lanes_for_partition(ctx, kind, part_id, n), chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
                        scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
                        static_cast<hipStream_t>(stream));
 }

@@ -60,19 +60,38 @@ constexpr int DPP_ROW_ROR1 = 0x121;
 constexpr int DPP_WAVE_SHL1 = 0x130;  // the same across all 64 lanes of the wave
 constexpr int DPP_WAVE_SHR1 = 0x138;
 
-// The group shape: LANES = 16 (one DPP row per alignment group, 4 groups per wave: the bulk of a DB) or
+// The group shape: LANES = 16 (one DPP row per alignment group, 4 groups per wave: the bulk of a DB),
 // LANES = 64 (the whole wave is one anti-diagonal pipeline: long subjects, 4x the lanes per alignment so
-// that the few giant sequences of a real DB do not become the tail of the scan).
+// that the few giant sequences of a real DB do not become the tail of the scan), or
+// LANES = 8 (half a DPP row, 8 groups per wave: SHORT QUERIES.  A query of Q rows gives every lane Q/8 instead of Q/16
+// rows, so the per-step work that does not scale with the rows (lane exchange, letter handling, window upkeep: ~10
+// instructions) is spread over twice the cells, and the pipeline fill per subject is 7 instead of 15 steps.  The
+// row_shr:1 exchange crosses from lane 7 into lane 8, the head of the second group of the row, which costs one select
+// per exchanged value (prev_lane).  Single-stripe queries only.)
 template <int LANES>
 struct Shift {
-    static_assert(LANES == 16 || LANES == 64, "group = DPP row or whole wave");
-    static constexpr int kShr1 = LANES == 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
-    static constexpr int kShl1 = LANES == 16 ? DPP_ROW_SHL1 : DPP_WAVE_SHL1;
+    static_assert(LANES == 8 || LANES == 16 || LANES == 64, "group = half a DPP row, a DPP row or the whole wave");
+    static constexpr int kShr1 = LANES <= 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
+    static constexpr int kShl1 = LANES <= 16 ? DPP_ROW_SHL1 : DPP_WAVE_SHL1;
 };
 
 template <int CTRL, bool ZERO_FILL>
 __device__ __forceinline__ u32 dpp(u32 old, u32 src) {
     return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, 0xf, ZERO_FILL);
+}
+
+// The value of the previous lane of the group; the group's head lane takes `headval` (ZERO_FILL: headval must be 0 and
+// the head is filled by bound_ctrl).  8-lane groups: lane 8 of a DPP row is a head too but has a source lane, so it
+// is selected explicitly (`head` is loop-invariant: one v_cndmask with an SGPR mask).
+template <int LANES, bool ZERO_FILL>
+__device__ __forceinline__ u32 prev_lane(u32 headval, u32 src, bool head) {
+    if constexpr (LANES == 8) {
+        const u32 v = dpp<DPP_ROW_SHR1, false>(headval, src);
+        return head ? headval : v;
+    } else {
+        (void)head;
+        return dpp<Shift<LANES>::kShr1, ZERO_FILL>(headval, src);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -281,15 +300,17 @@ struct Geometry {
     // packed kinds, 16-lane groups: WIDE words (score of the row, 1) — the pair (score A, score B) of a cell pair and its
     // addition to the diagonal are ONE packed multiply-add (Arith::add_pair).  Wave-wide groups keep two query rows per
     // word (an odd R leaves the upper half of the last word unused) and pair the scores with v_perm_b32.
-    static constexpr bool kWide = kPacked && LANES == 16;
+    static constexpr bool kWide = kPacked && LANES <= 16;
     static constexpr int NW = (kPacked && !kWide) ? (R + 1) / 2 : R;
     static constexpr int NCH = (NW + 3) / 4;
-    static constexpr int kChunkRowBytes = LANES * 16;            // chunk k of lane l at k*kChunkRowBytes + l*16
+    // chunk k of lane l at k*kChunkRowBytes + l*16; 8-lane groups keep the 16 slots of a DPP row (slots 8..15 unused:
+    // the second group of a row reads the first one's slots, in a later LDS cycle) so that the letter arithmetic is the same
+    static constexpr int kChunkRowBytes = (LANES <= 16 ? 16 : LANES) * 16;
     static constexpr int kRowBytes = NCH * kChunkRowBytes;
     static constexpr int kTileBytes = kLetters * kRowBytes;
     static constexpr int kStripeRows = LANES * R;
     // a letter travels as (letter * kLetterUnits) in one byte; its row offset is that byte << kLetterShift
-    static constexpr int kLetterShift = LANES == 16 ? 8 : 10;
+    static constexpr int kLetterShift = LANES <= 16 ? 8 : 10;
     static constexpr int kLetterUnits = kRowBytes >> kLetterShift;
     static_assert(kPadLetter * kLetterUnits < 256, "letter offset must fit a byte");
 };
@@ -468,10 +489,9 @@ struct StripeState {
 template <int KIND, int R, int LANES, int BYTE, bool MULTI, bool OFFS = false, int P = 1>
 __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsigned char* tile,
                                         u32 lettersA, u32 lettersB, u32 gop, u32 gex, u32 inH, u32 inF,
-                                        u32 apos = 0, bool first = false, u32 wrapP = 0, u32 wrapLast = 0) {
+                                        u32 apos = 0, bool first = false, u32 wrapP = 0, u32 wrapLast = 0, bool head = false) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
-    constexpr int SHR1 = Shift<LANES>::kShr1;
     constexpr u32 kSel = 0x0c0c000cu | ((u32)BYTE << 8);  // letter byte BYTE -> bits 15:8
     constexpr int kPostShift = G::kLetterShift - 8;        // row offset = byte << kLetterShift
 
@@ -483,19 +503,19 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
     // subject letter(s): shift along the group, lane 0 takes the next letter of its subject
     u32 wa[G::NW];
     u32 wb[G::NW];
-    if constexpr (A::kPacked && LANES == 16) {
+    if constexpr (A::kPacked && LANES <= 16) {
         // both LDS addresses (< 64 KB) travel in one register: one permute, one DPP move and one add for the pair
         constexpr u32 kSel2 = ((u32)(4 + BYTE) << 24) | 0x000c000cu | ((u32)BYTE << 8);  // B's byte -> 31:24, A's -> 15:8
         const u32 inj = __builtin_amdgcn_perm(lettersB, lettersA, kSel2);
-        st.yA = dpp<SHR1, false>(inj, st.yA) + 0x00100010u;
+        st.yA = prev_lane<LANES, false>(inj, st.yA, head) + 0x00100010u;
         if constexpr (!OFFS) lds_read_words2<G::NW, G::kChunkRowBytes>(wa, wb, tile + (st.yA & 0xffffu), tile + (st.yA >> 16));
     } else {
         const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel) << kPostShift;
-        st.yA = dpp<SHR1, false>(injA, st.yA) + 16u;
+        st.yA = prev_lane<LANES, false>(injA, st.yA, head) + 16u;
         if constexpr (A::kPacked || !OFFS || !kProgScalar) lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + st.yA);
         if constexpr (A::kPacked) {
             const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel) << kPostShift;
-            st.yB = dpp<SHR1, false>(injB, st.yB) + 16u;
+            st.yB = prev_lane<LANES, false>(injB, st.yB, head) + 16u;
             lds_read_words<G::NW, G::kChunkRowBytes>(wb, tile + st.yB);
         }
     }
@@ -512,15 +532,15 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         const u32 bH = st.Zc[Q + kLastClass];  // the local-alignment boundary H = 0 as row 0's diagonal expects it
         u32 upH, F;
         if constexpr (MULTI) {
-            upH = dpp<SHR1, false>(first ? bH : inH, st.Hlast);
+            upH = prev_lane<LANES, false>(first ? bH : inH, st.Hlast, head);
             // no select for F: in the first stripe lane 0 reads the zeros array (the kind's unraised zero pattern),
             // which lies below every zero level — "no vertical gap" as well as any other value down there
-            F = dpp<SHR1, false>(inF, st.Fout);
+            F = prev_lane<LANES, false>(inF, st.Fout, head);
         } else {
-            upH = dpp<SHR1, false>(bH, st.Hlast);
+            upH = prev_lane<LANES, false>(bH, st.Hlast, head);
             // any F below the column's zero level is "no vertical gap": bound_ctrl zero fill (pattern 0 is below every
             // zero level of every kind, and the fp16 comparator of the int16 kind orders +0.0 below all its patterns)
-            F = dpp<SHR1, true>(0u, st.Fout);
+            F = prev_lane<LANES, true>(0u, st.Fout, head);
         }
         u32 diag = st.upH_prev;
         st.upH_prev = upH;
@@ -619,14 +639,14 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
     // row above the lane's first row: from the neighbouring lane, or from the stripe border
     u32 upH, F;
     if constexpr (MULTI) {
-        upH = dpp<SHR1, false>(inH, st.Hlast);  // lane 0 keeps `old` == the border value
-        F = dpp<SHR1, false>(inF, st.Fout);
+        upH = prev_lane<LANES, false>(inH, st.Hlast, head);  // lane 0 keeps `old` == the border value
+        F = prev_lane<LANES, false>(inF, st.Fout, head);
     } else if constexpr (A::kZero == 0u) {
-        upH = dpp<SHR1, true>(0u, st.Hlast);  // bound_ctrl zero fill == the local-alignment boundary
-        F = dpp<SHR1, true>(0u, st.Fout);
+        upH = prev_lane<LANES, true>(0u, st.Hlast, head);  // bound_ctrl zero fill == the local-alignment boundary
+        F = prev_lane<LANES, true>(0u, st.Fout, head);
     } else {
-        upH = dpp<SHR1, false>(A::kZero, st.Hlast);
-        F = dpp<SHR1, false>(A::kZero, st.Fout);
+        upH = prev_lane<LANES, false>(A::kZero, st.Hlast, head);
+        F = prev_lane<LANES, false>(A::kZero, st.Fout, head);
     }
     u32 diag = st.upH_prev;
     st.upH_prev = upH;
@@ -668,9 +688,19 @@ __device__ __forceinline__ void load_tile(unsigned char* lds, const unsigned cha
     for (int i = threadIdx.x; i < TILE_BYTES / 16; i += kThreads) dst[i] = src[i];
 }
 
+// maximum over the 8 lanes of a half row, left in lanes 0..3 (and 8..11): half-row mirror, then the two quad swaps
+template <class MAX>
+__device__ __forceinline__ u32 half_row_max(u32 v, MAX&& mx) {
+    v = mx(v, dpp<0x141, false>(v, v));  // row_half_mirror: lane i <-> 7 - i
+    v = mx(v, dpp<0xB1, false>(v, v));   // quad_perm [1,0,3,2]
+    v = mx(v, dpp<0x4E, false>(v, v));   // quad_perm [2,3,0,1]
+    return v;
+}
+
 template <int KIND, int LANES>
 __device__ __forceinline__ u32 group_max(u32 v) {
     using A = Arith<KIND>;
+    if constexpr (LANES == 8) return half_row_max(v, [](u32 a, u32 b) { return A::max2(a, b); });
     v = A::max2(v, dpp<0x128, false>(v, v));  // row_ror:8
     v = A::max2(v, dpp<0x124, false>(v, v));  // row_ror:4
     v = A::max2(v, dpp<0x122, false>(v, v));  // row_ror:2
@@ -714,14 +744,14 @@ template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
     // packed kinds: 2 waves/SIMD (256 VGPRs) for the tall kernels; up to SWK_WAVES3_MAX_R rows a third wave is asked for
     // (168 VGPRs): two waves cover each other's wait states only ~92 % of the time, three reach the issue peak
-    if (Arith<KIND>::kPacked) return (LANES == 16 && !MULTI && R <= SWK_WAVES4_MAX_R) ? 4 : (LANES == 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
+    if (Arith<KIND>::kPacked) return (LANES <= 16 && !MULTI && R <= SWK_WAVES4_MAX_R) ? 4 : (LANES <= 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
     // int32 above 32 rows per lane: two waves per SIMD (the registers of the taller stripes; its add/max3 mix cannot
     // co-issue anyway).  Up to 32 rows the third wave is worth more than the spills it causes in the multi-stripe kernels
     // from R = 24 up (two-stripe queries of 850 / 1000 residues: 6.36 / 6.42 with three waves, 6.12 / 6.22 TCUPS with two)
-    if (KIND == I32 && LANES == 16 && R > (MULTI ? SWK_I32_WAVES3_MAX_R_MULTI : SWK_I32_WAVES3_MAX_R)) return 2;
+    if (KIND == I32 && LANES <= 16 && R > (MULTI ? SWK_I32_WAVES3_MAX_R_MULTI : SWK_I32_WAVES3_MAX_R)) return 2;
     // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
-    return (R <= 16 && !MULTI && LANES == 16) ? 4 : 3;
+    return (R <= 16 && !MULTI && LANES <= 16) ? 4 : 3;
 }
 
 template <int KIND, int R, int LANES, bool MULTI, bool OFFS = false>
@@ -729,6 +759,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
     constexpr int kGroups = kThreads / LANES;
+    static_assert(!(MULTI && LANES == 8), "8-lane groups serve single-stripe queries only");
     constexpr int kJunk = border_junk_words<LANES>();
     constexpr int SHL1 = Shift<LANES>::kShl1;
     constexpr int kQuadsPerLetterBlock = LANES;  // a lane holds 4 letters: LANES quads per reload
@@ -738,6 +769,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     const int tid = threadIdx.x;
     const int lane = tid & (LANES - 1);  // position in the alignment group
     const int group = tid / LANES;
+    const bool head = lane == 0;
     const int n = p.count_ptr ? *p.count_ptr : p.n;
     constexpr int kSubjPerBatch = kGroups * A::kSubjects;
     const int nbatches = (n + kSubjPerBatch - 1) / kSubjPerBatch;
@@ -790,7 +822,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             s1 = p.chars + (p.offsets[pos1] - p.offsets[0]);
         }
         int lmax = len0 > len1 ? len0 : len1;
-        if constexpr (LANES == 16) {  // the 4 groups of a wave run in lock-step
+        if constexpr (LANES <= 16) {  // the 4 (8) groups of a wave run in lock-step
+            if constexpr (LANES == 8) lmax = max(lmax, __shfl_xor(lmax, 8));
             lmax = max(lmax, __shfl_xor(lmax, 16));
             lmax = max(lmax, __shfl_xor(lmax, 32));
         }
@@ -827,7 +860,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             }
             st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
             st.yB = st.yA;
-            if constexpr (A::kPacked && LANES == 16) st.yA |= st.yA << 16;  // (address for subject B, address for subject A)
+            if constexpr (A::kPacked && LANES <= 16) st.yA |= st.yA << 16;  // (address for subject B, address for subject A)
 
             // subject letters: lane l holds letters 4*LANES*blk + 4l .. +3 of each subject, premultiplied
             // by kLetterUnits so that a byte << kLetterShift is the byte offset of the letter's profile row
@@ -886,16 +919,16 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     for (int d = 0; d < P + 3; d++) st.maxv[d] = A::gap(st.maxv[d], gw);
                 };
                 if constexpr (LOWER) lower_frame(lower_lane + 0);
-                dp_step<KIND, R, LANES, 0, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first, p.wrap_class, p.wrap_last);
+                dp_step<KIND, R, LANES, 0, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first, p.wrap_class, p.wrap_last, head);
                 if constexpr (MULTI) { bh0 = st.Hlast; bf0 = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 1);
-                dp_step<KIND, R, LANES, 1, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first, p.wrap_class, p.wrap_last);
+                dp_step<KIND, R, LANES, 1, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first, p.wrap_class, p.wrap_last, head);
                 if constexpr (MULTI) { bh1 = st.Hlast; bf1 = st.Fout; *reinterpret_cast<uint4*>(outHF) = make_uint4(bh0, bf0, bh1, bf1); }
                 if constexpr (LOWER) lower_frame(lower_lane + 2);
-                dp_step<KIND, R, LANES, 2, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first, p.wrap_class, p.wrap_last);
+                dp_step<KIND, R, LANES, 2, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first, p.wrap_class, p.wrap_last, head);
                 if constexpr (MULTI) { bh2 = st.Hlast; bf2 = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 3);
-                dp_step<KIND, R, LANES, 3, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first, p.wrap_class, p.wrap_last);
+                dp_step<KIND, R, LANES, 3, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first, p.wrap_class, p.wrap_last, head);
                 if constexpr (MULTI) { *reinterpret_cast<uint4*>(outHF + 4) = make_uint4(bh2, bf2, st.Hlast, st.Fout); outHF += walkOut; }
                 lettersA = dpp<SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
@@ -949,10 +982,14 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         int sc0, sc1, guard = 0;
         if constexpr (OFFS) {
             // group maximum of true scores
-            maxv = A::true_max(maxv, dpp<0x128, false>(maxv, maxv));
-            maxv = A::true_max(maxv, dpp<0x124, false>(maxv, maxv));
-            maxv = A::true_max(maxv, dpp<0x122, false>(maxv, maxv));
-            maxv = A::true_max(maxv, dpp<0x121, false>(maxv, maxv));
+            if constexpr (LANES == 8) {
+                maxv = half_row_max(maxv, [](u32 a, u32 b) { return A::true_max(a, b); });
+            } else {
+                maxv = A::true_max(maxv, dpp<0x128, false>(maxv, maxv));
+                maxv = A::true_max(maxv, dpp<0x124, false>(maxv, maxv));
+                maxv = A::true_max(maxv, dpp<0x122, false>(maxv, maxv));
+                maxv = A::true_max(maxv, dpp<0x121, false>(maxv, maxv));
+            }
             if constexpr (LANES == 64) {
                 maxv = A::true_max(maxv, (u32)__shfl_xor((int)maxv, 16));
                 maxv = A::true_max(maxv, (u32)__shfl_xor((int)maxv, 32));
@@ -1005,7 +1042,7 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
         const int word = (int)(i % kWordsPerRow);
         const int letter = (int)((i / kWordsPerRow) % kLetters);
         const int stripe = (int)(i / ((size_t)kWordsPerRow * kLetters));
-        const int chunk = word / kWordsPerChunkRow, lane = (word % kWordsPerChunkRow) / 4, sub = word % 4;
+        const int chunk = word / kWordsPerChunkRow, lane = ((word % kWordsPerChunkRow) / 4) % LANES, sub = word % 4;
         const int w = chunk * 4 + sub;  // word index within the lane's NW words
         u32 v = 0;
         if (w < G::NW) {

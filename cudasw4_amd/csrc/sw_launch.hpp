@@ -29,7 +29,7 @@ constexpr int kMaxRowsScalarLong = 8;   // stripe = 512 query rows, 43 KB tile
 
 constexpr int max_rows(int kind, int lanes) {
     const bool packed = kind == F16X2 || kind == I16X2;
-    return lanes == 16 ? (packed ? kMaxRowsPacked : kind == I32 ? kMaxRowsI32 : kMaxRowsScalar) : (packed ? kMaxRowsPackedLong : kMaxRowsScalarLong);
+    return lanes <= 16 ? (packed ? kMaxRowsPacked : kind == I32 ? kMaxRowsI32 : kMaxRowsScalar) : (packed ? kMaxRowsPackedLong : kMaxRowsScalarLong);
 }
 
 struct KindLaunch {
@@ -56,7 +56,7 @@ hipError_t launch_scan_ro(bool multi, int grid, hipStream_t stream, const ScanPa
         return hipErrorInvalidValue;
     } else {
         if (multi) {
-            if constexpr (2 * R > kMaxR) {
+            if constexpr (2 * R > kMaxR && LANES != 8) {
                 hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
             } else {
                 return hipErrorInvalidValue;
@@ -105,17 +105,20 @@ constexpr size_t tile_bytes_r() {
                                 const ScanParams& p) {                                                              \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN64_##KIND) } }                                 \
+        else if (lanes == 8) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN8_##KIND) } }                                   \
         return hipErrorInvalidValue;                                                                                \
     }                                                                                                               \
     static hipError_t FN##_profile(int R, int lanes, const int8_t* q, int32_t qlen, const int8_t* m, int32_t pr,    \
                                    int32_t ns, unsigned char* out, int32_t shift, hipStream_t s) {                  \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_PROF16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_PROF64_##KIND) } }                                 \
+        else if (lanes == 8) { switch (R) { FOR_EACH_R(SWK_CASE_PROF8_##KIND) } }                                   \
         return hipErrorInvalidValue;                                                                                \
     }                                                                                                               \
     static size_t FN##_tile_bytes(int R, int lanes) {                                                               \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_TILE16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_TILE64_##KIND) } }                                 \
+        else if (lanes == 8) { switch (R) { FOR_EACH_R(SWK_CASE_TILE8_##KIND) } }                                   \
         return 0;                                                                                                   \
     }                                                                                                               \
     const KindLaunch& FN() {                                                                                        \

@@ -337,18 +337,20 @@ def test_very_long_query():
         np.testing.assert_array_equal(got, expect, err_msg=cfg)
 
 
-def test_every_compiled_tile_shape():
+def test_every_compiled_tile_shape(monkeypatch):
     """Every (kind, rows-per-lane R, group shape, single/multi stripe) instantiation that the planner can pick:
     query lengths that land on each R for one and for several stripes, 16-lane groups (short subjects,
-    partition 33) and 64-lane groups (long subjects, partition 34 with a small n)."""
+    partition 33), 64-lane groups (long subjects, partition 34 with a small n) and 8-lane groups (short queries;
+    forced on / off through the environment so that both shapes see every single-stripe R)."""
     torch, capi, search = gpu_modules()
     rng = np.random.default_rng(77)
     short = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1, 260, 37))]
     long_ = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1281, 1700, 9))]
-    ctx = capi.Context(0)
-    ctx.set_matrix(O.blosum21(62))
     seen = set()
-    for seqs, part_id, lanes in ((short, 33, 16), (long_, 34, 64)):
+    for seqs, part_id, lanes in ((short, 33, 16), (long_, 34, 64), (short, 33, 8)):
+        monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_Q", "1000000" if lanes == 8 else "0")
+        ctx = capi.Context(0)  # reads the environment
+        ctx.set_matrix(O.blosum21(62))
         chars, offsets, lengths = O.make_db(seqs)
         db = search.DeviceDB.from_arrays(chars, offsets, lengths, device=0)
         n = len(seqs)
@@ -358,22 +360,26 @@ def test_every_compiled_tile_shape():
         ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
         ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
-            rmax = {16: 48 if kind < 3 else 32, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
+            rmax = {8: 48 if kind < 3 else 32, 16: 48 if kind < 3 else 32, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
             qlens = set()
             for r in range(1, rmax + 1):
                 qlens.add(lanes * r - 1)                       # one stripe of R rows
                 if lanes == 16:
                     assert capi.plan_query(kind, lanes * r - 1) == (r, 1)
-                if 2 * r > rmax:
+                if 2 * r > rmax and lanes != 8:
                     qlens.add(2 * lanes * r - lanes - 3)       # two stripes of R rows
                     if lanes == 16:
                         assert capi.plan_query(kind, 2 * lanes * r - lanes - 3) == (r, 2)
-            qlens.add(3 * lanes * rmax - 5)                    # three full stripes
+            if lanes == 8:
+                qlens.add(8 * rmax)                            # the longest query the 8-lane shape takes
+            else:
+                qlens.add(3 * lanes * rmax - 5)                # three full stripes
             for qlen in sorted(qlens):
                 q = rng.integers(0, 20, qlen).astype(np.int8)
                 expect = O.scan(q, chars, offsets, lengths, simd=True)
                 ctx.set_query(q)
                 need = ctx.scan_temp_bytes(kind, part_id, n, maxlen)
+                assert lanes != 8 or need == 0
                 temp = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
                 scores.fill_(-1.0)
                 ovf_cnt.zero_()
@@ -385,7 +391,7 @@ def test_every_compiled_tile_shape():
                 np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect,
                                               err_msg="kind %d lanes %d qlen %d" % (kind, lanes, qlen))
                 seen.add((kind, lanes, qlen))
-    assert len(seen) > 250
+    assert len(seen) > 400
 
 
 @pytest.mark.parametrize("gop,gex", [(-12, -5), (-1000, -1000), (-3, -12)])
