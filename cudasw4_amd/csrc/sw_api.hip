@@ -324,7 +324,10 @@ int sw_ctx_create(int device, sw_ctx** out) {
         for (int i = 0; i < 16; i++) z[SW_KIND_I16X2 * 16 + i] = swk::Arith<swk::I16X2>::kZero;
         e = hipMemcpy(ctx->d_zeros, z, sizeof(z), hipMemcpyHostToDevice);
     }
-    if (e != hipSuccess) { delete ctx; return fail(SW_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    // load the four kinds' code objects now (an empty launch each) rather than inside the first query's scan
+    for (int kind = 0; kind < 4 && e == hipSuccess; kind++) e = kind_launch(kind)->warm(nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) { delete ctx; return fail(SW_ERR_HIP, std::string("context set-up: ") + hipGetErrorString(e)); }
     *out = ctx;
     return SW_OK;
 }

@@ -39,6 +39,9 @@ struct KindLaunch {
     hipError_t (*profile)(int R, int lanes, const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t pad_row,
                           int32_t nstripes, unsigned char* out, int32_t shift, hipStream_t stream);
     size_t (*tile_bytes)(int R, int lanes);
+    // an empty launch from the kind's translation unit: the runtime loads a TU's code object (a few MB of kernels) on
+    // the first launch of any of its kernels; sw_ctx_create pays that once instead of the first query (~25 ms per kind)
+    hipError_t (*warm)(hipStream_t stream);
     bool packed;
 };
 
@@ -121,8 +124,13 @@ constexpr size_t tile_bytes_r() {
         else if (lanes == 8) { switch (R) { FOR_EACH_R(SWK_CASE_TILE8_##KIND) } }                                   \
         return 0;                                                                                                   \
     }                                                                                                               \
+    static __global__ void FN##_warm_kernel() {}                                                                    \
+    static hipError_t FN##_warm(hipStream_t s) {                                                                    \
+        hipLaunchKernelGGL(FN##_warm_kernel, dim3(1), dim3(64), 0, s);                                              \
+        return hipGetLastError();                                                                                   \
+    }                                                                                                               \
     const KindLaunch& FN() {                                                                                        \
-        static const KindLaunch k{FN##_scan, FN##_profile, FN##_tile_bytes, Arith<KIND>::kPacked};                  \
+        static const KindLaunch k{FN##_scan, FN##_profile, FN##_tile_bytes, FN##_warm, Arith<KIND>::kPacked};       \
         return k;                                                                                                   \
     }
 

@@ -14,7 +14,7 @@ OUT=gpurun_out/profiles_$TAG
 RAW=gpurun_out/prof_raw_$TAG
 mkdir -p $OUT $RAW
 export TMPDIR=/tmp
-BENCH="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify $EXTRA"
+BENCH="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-secondary $EXTRA"
 timeout 900 rocprofv3 --kernel-trace --stats -d $RAW/stats -o bench -- python3 $BENCH > $OUT/${NAME}_under_rocprof_stats.log 2>&1
 python3 tools/rocprof_summary.py stats $RAW/stats/bench_results.db > $OUT/${TAG}_${NAME}_kernel_stats.txt 2>&1
 : > $OUT/${TAG}_${NAME}_pmc.txt

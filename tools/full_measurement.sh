@@ -1,16 +1,28 @@
 #!/bin/bash
-# Full measurement pass on the GPU box (via gpurun): GPU tests, bench line, peak sweep, Swiss-Prot-like DB, the align
-# command line resident and streamed, rocprof stats + PMC.  Results under gpurun_out/final/ (copy what is to be kept into profiles/).
+# Full measurement pass on the GPU box (via gpurun): GPU tests, the bench line (peak + Swiss-Prot-like workload), other kernel
+# configurations, streamed runs, the 2-rank path on one GPU, peak and short-query sweeps, the align command line resident and
+# streamed.  Results under gpurun_out/final/ (copy what is to be kept into profiles/).  The rocprofv3 passes are separate:
+# tools/collect_profiles.sh r02 <commit> [--workload sprot-like].
 export TMPDIR=/tmp
 O=gpurun_out/final; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
-python bench.py > $O/bench_line.json 2> $O/bench_err.txt
+python bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench_err.txt
+for k in dpxs16 dpxs32 float; do python bench.py --kernel $k --no-secondary --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$k.json; done
+python bench.py --max-gpu-mem 1G --no-secondary --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_streamed.json
+python bench.py --workload sprot-like --max-gpu-mem 400M --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_sprot_streamed.json
+BENCH_FORCE_DEVICE=0 BENCH_DIST_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_2ranks_1gpu.json
 python tools/peak_sweep.py --json $O/peak_sweep.json > $O/peak_sweep.txt 2>&1
-python tools/synth_db_bench.py --config dpx > $O/synth_dpx.txt 2>&1
-python tools/synth_db_bench.py --config half2 > $O/synth_half2.txt 2>&1
+python tools/short_query_sweep.py > $O/short_query_sweep.txt 2>&1
 A=cudasw4_amd/lib/align
 $A --query tests/golden/allqueries.fasta --pseudodb 1000000 512 --top 0 --verbose --uploadFull --prefetchDBFile --mat blosum62 --singlePassType Half2 --manyPassType_small Half2 --manyPassType_large Float --overflowType Float > $O/align_peak.txt 2>&1
 $A --query tests/golden/allqueries.fasta --pseudodb 1000000 512 --top 0 --verbose --maxGpuMem 600M --maxBatchBytes 32M --mat blosum62 --singlePassType Half2 --manyPassType_small Half2 --manyPassType_large Float --overflowType Float > $O/align_stream.txt 2>&1
-bash tools/collect_profiles.sh r01 > $O/collect.txt 2>&1
-cp gpurun_out/profiles_r01/* $O/ 2>/dev/null
-tail -3 $O/pytest_gpu.txt; cat $O/bench_line.json; tail -2 $O/align_peak.txt $O/align_stream.txt
+tail -3 $O/pytest_gpu.txt; for f in $O/bench_*.json; do python3 - $f <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1], d["value"], d["n_gpus"], d["scaling"], d["verified"], d["config"]["resident"], d.get("sprot_like", {}).get("value"))
+except Exception as e:
+    print(sys.argv[1], "unreadable", e)
+PY
+done
+tail -n 2 $O/align_peak.txt; tail -n 2 $O/align_stream.txt
