@@ -190,7 +190,9 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # BENCH_FORCE_DIST=1 (test hook): go through the process-group code path (RCCL init, gather, reductions, barrier) even
+    # with a single rank, which is all a 1-GPU box can run with the real backend
+    distributed = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # test hooks (1-GPU boxes): BENCH_FORCE_DEVICE maps every rank onto one device, BENCH_DIST_BACKEND=gloo
@@ -202,6 +204,9 @@ def run_rank(args):
     comm_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:

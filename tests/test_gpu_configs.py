@@ -161,6 +161,21 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
     assert weak["config"]["db_subjects"] == 400000
 
 
+def test_bench_process_group_path_with_the_real_backend():
+    """The torch.distributed code path of bench.py with the backend the multi-GPU runs use (nccl == RCCL): process-group
+    init on the device, the per-step gather of CUDA tensors, the reductions and barriers — with the one rank a 1-GPU box
+    can give it (two RCCL ranks cannot share a GPU), under torch.distributed.run exactly as the round driver launches it."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--db-size", "100000", "--no-cpu-baseline", "--no-secondary"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["verified"] is True and out["value"] > 0
+    assert out["config"]["top_merged_example"]["ids"] == list(range(10))
+
+
 def test_bench_default_line_carries_the_sprot_like_secondary():
     """The default command (what the round driver runs) reports config 3 next to the headline: same JSON line, own
     timed region, every score verified (here without the CPU leg: packed vs int32 configuration)."""
