@@ -95,6 +95,9 @@ constexpr uint32_t kWorkSlots = 4096;
 #ifndef SW_LANES8_MAX_QUERY_PACKED
 #define SW_LANES8_MAX_QUERY_PACKED 288
 #endif
+#ifndef SW_LANES8_MAX_SUBJECT
+#define SW_LANES8_MAX_SUBJECT 192
+#endif
 #ifndef SW_LANES8_MAX_QUERY_SCALAR
 #define SW_LANES8_MAX_QUERY_SCALAR 240
 #endif
@@ -116,6 +119,7 @@ struct sw_ctx {
     Profile profiles[4][3][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups, 2 = 8-lane groups][plain | column-offset recurrence]
     bool use_offs = true;        // CUDASW4_AMD_NO_OFFS=1: always the plain recurrence (A/B measurements)
     int64_t long16_min = -1;     // CUDASW4_AMD_LONG16_MIN: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
+    int32_t lanes8_max_subject = -1;  // CUDASW4_AMD_LANES8_MAX_SUBJECT: multi-stripe queries use 8-lane groups when no subject of the launch is longer (-1: built-in)
     int32_t lanes8_max_q = -1;   // CUDASW4_AMD_LANES8_MAX_Q: queries up to this length use 8-lane groups (0: never; -1: the built-in limits)
 };
 
@@ -137,11 +141,18 @@ int shape_index(int lanes) { return lanes == 64 ? 1 : lanes == 8 ? 2 : 0; }
 
 // Short queries run on 8-lane groups (half DPP rows): twice the rows per lane for the same query, so the per-step
 // overhead is spread over twice the cells, and 7 instead of 15 fill steps per subject (sw_dp_kernel.hpp: Shift).
-int lanes_for_partition(const sw_ctx* ctx, int kind, int part_id, int32_t n) {
+int lanes_for_partition(const sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
     if (part_id < SW_NUM_LENGTH_PARTITIONS - 2) {
-        const bool fits8 = ctx->qlen <= 8 * swk::max_rows(kind, 8);  // single-stripe kernels only
+        if (!ctx->have_query) return 16;
+        const bool fits8 = ctx->qlen <= 8 * swk::max_rows(kind, 8);  // one stripe of 8-lane groups
         const int32_t limit = ctx->lanes8_max_q >= 0 ? ctx->lanes8_max_q : kind_packed(kind) ? SW_LANES8_MAX_QUERY_PACKED : SW_LANES8_MAX_QUERY_SCALAR;
-        return (ctx->have_query && fits8 && ctx->qlen <= limit) ? 8 : 16;
+        if (fits8 && ctx->qlen <= limit) return 8;
+        // longer queries on SHORT subjects: an 8-lane stripe has half the rows, so there are twice the stripes, but each
+        // fills its pipeline in 7 instead of 15 steps.  Measured on the peak DB (all 20 queries, half2): +2.5 % at L = 128
+        // (10.38 -> 10.63 TCUPS), -0.5 % at L = 256, -1.4 % at L = 512: short subjects only
+        const int32_t lmax = ctx->lanes8_max_subject >= 0 ? ctx->lanes8_max_subject : (kind_packed(kind) ? SW_LANES8_MAX_SUBJECT : 0);
+        if (!fits8 && max_subject_len <= lmax) return 8;
+        return 16;
     }
     const int64_t fills_gpu_twice = (int64_t)2 * std::max(1, ctx->num_cus) * 4 * 32;
     if (part_id == SW_NUM_LENGTH_PARTITIONS - 2) return n >= (ctx->long16_min >= 0 ? ctx->long16_min : 512) ? 16 : 64;
@@ -186,7 +197,7 @@ int32_t border_capacity(int32_t max_len, int lanes) {
     return (int32_t)((steps + 15) / 16 * 16 + 16);  // + one prefetched quad past the end, rounded to 64 bytes
 }
 size_t border_bytes_per_wg(int32_t lcap, int lanes) {
-    const size_t region = lanes == 16 ? swk::border_region_words<16>(lcap) : swk::border_region_words<64>(lcap);
+    const size_t region = lanes == 16 ? swk::border_region_words<16>(lcap) : lanes == 8 ? swk::border_region_words<8>(lcap) : swk::border_region_words<64>(lcap);
     return (size_t)(swk::kThreads / lanes) * region * sizeof(uint32_t);
 }
 
@@ -316,6 +327,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
     if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = atoll(e);
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_Q")) ctx->lanes8_max_q = atoi(e);
+    if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_SUBJECT")) ctx->lanes8_max_subject = atoi(e);
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
@@ -413,7 +425,7 @@ int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstri
 
 size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0 || n <= 0) return 0;
-    const int lanes = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, kind, part_id, n);
+    const int lanes = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, kind, part_id, n, max_subject_len);
     const QueryPlan pl = plan_query(kind, ctx->qlen, lanes);
     if (pl.nstripes <= 1) return 0;
     const int subj_per_batch = (swk::kThreads / lanes) * (kind_packed(kind) ? 2 : 1);
@@ -428,7 +440,7 @@ int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, c
                       int ovf_check, void* temp, size_t temp_bytes, void* stream) {
     if (part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS) return fail(SW_ERR_INVALID, "partition id out of range");
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
-    return scan_common(ctx, kind, lanes_for_partition(ctx, kind, part_id, n), chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
+    return scan_common(ctx, kind, lanes_for_partition(ctx, kind, part_id, n, max_subject_len), chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
                        scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
                        static_cast<hipStream_t>(stream));
 }

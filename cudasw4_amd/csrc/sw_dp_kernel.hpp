@@ -67,7 +67,8 @@ constexpr int DPP_WAVE_SHR1 = 0x138;
 // rows, so the per-step work that does not scale with the rows (lane exchange, letter handling, window upkeep: ~10
 // instructions) is spread over twice the cells, and the pipeline fill per subject is 7 instead of 15 steps.  The
 // row_shr:1 exchange crosses from lane 7 into lane 8, the head of the second group of the row, which costs one select
-// per exchanged value (prev_lane).  Single-stripe queries only.)
+// per exchanged value (prev_lane).  With several stripes the shape pays off for short subjects only: half the fill per
+// stripe, but twice the stripes.)
 template <int LANES>
 struct Shift {
     static_assert(LANES == 8 || LANES == 16 || LANES == 64, "group = half a DPP row, a DPP row or the whole wave");
@@ -723,7 +724,7 @@ __device__ __forceinline__ u32 group_max(u32 v) {
 // 32-byte boundary.  The junk area holds the last lane's columns < 0 (2*(LANES-1) words right below the array) and
 // one 8-word slot per other lane (their stores are never read).
 template <int LANES>
-constexpr int border_junk_words() { return LANES == 16 ? 166 : 646; }  // >= 10*(LANES-1), == 6 (mod 8)
+constexpr int border_junk_words() { return LANES == 8 ? 70 : LANES == 16 ? 166 : 646; }  // >= 10*(LANES-1), == 6 (mod 8)
 template <int LANES>
 constexpr int border_region_words(int lcap) { return (border_junk_words<LANES>() + 2 * lcap + 15) / 16 * 16; }  // per group, 64-byte granular
 
@@ -759,7 +760,6 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
     constexpr int kGroups = kThreads / LANES;
-    static_assert(!(MULTI && LANES == 8), "8-lane groups serve single-stripe queries only");
     constexpr int kJunk = border_junk_words<LANES>();
     constexpr int SHL1 = Shift<LANES>::kShl1;
     constexpr int kQuadsPerLetterBlock = LANES;  // a lane holds 4 letters: LANES quads per reload

@@ -59,7 +59,7 @@ hipError_t launch_scan_ro(bool multi, int grid, hipStream_t stream, const ScanPa
         return hipErrorInvalidValue;
     } else {
         if (multi) {
-            if constexpr (2 * R > kMaxR && LANES != 8) {
+            if constexpr (2 * R > kMaxR) {
                 hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
             } else {
                 return hipErrorInvalidValue;

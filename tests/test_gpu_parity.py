@@ -349,6 +349,7 @@ def test_every_compiled_tile_shape(monkeypatch):
     seen = set()
     for seqs, part_id, lanes in ((short, 33, 16), (long_, 34, 64), (short, 33, 8)):
         monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_Q", "1000000" if lanes == 8 else "0")
+        monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_SUBJECT", "1000000" if lanes == 8 else "0")
         ctx = capi.Context(0)  # reads the environment
         ctx.set_matrix(O.blosum21(62))
         chars, offsets, lengths = O.make_db(seqs)
@@ -366,20 +367,17 @@ def test_every_compiled_tile_shape(monkeypatch):
                 qlens.add(lanes * r - 1)                       # one stripe of R rows
                 if lanes == 16:
                     assert capi.plan_query(kind, lanes * r - 1) == (r, 1)
-                if 2 * r > rmax and lanes != 8:
+                if 2 * r > rmax:
                     qlens.add(2 * lanes * r - lanes - 3)       # two stripes of R rows
                     if lanes == 16:
                         assert capi.plan_query(kind, 2 * lanes * r - lanes - 3) == (r, 2)
-            if lanes == 8:
-                qlens.add(8 * rmax)                            # the longest query the 8-lane shape takes
-            else:
-                qlens.add(3 * lanes * rmax - 5)                # three full stripes
+            qlens.add(lanes * rmax)                            # the longest single-stripe query of the shape
+            qlens.add(3 * lanes * rmax - 5)                    # three full stripes
             for qlen in sorted(qlens):
                 q = rng.integers(0, 20, qlen).astype(np.int8)
                 expect = O.scan(q, chars, offsets, lengths, simd=True)
                 ctx.set_query(q)
                 need = ctx.scan_temp_bytes(kind, part_id, n, maxlen)
-                assert lanes != 8 or need == 0
                 temp = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
                 scores.fill_(-1.0)
                 ovf_cnt.zero_()
@@ -391,7 +389,7 @@ def test_every_compiled_tile_shape(monkeypatch):
                 np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect,
                                               err_msg="kind %d lanes %d qlen %d" % (kind, lanes, qlen))
                 seen.add((kind, lanes, qlen))
-    assert len(seen) > 400
+    assert len(seen) > 480
 
 
 @pytest.mark.parametrize("gop,gex", [(-12, -5), (-1000, -1000), (-3, -12)])
