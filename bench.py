@@ -415,9 +415,16 @@ def measure(env, args, workload, want_cpu):
             # the binding bound: VALU issue.  Peak: one wave64 instruction per 4 cycles per SIMD =
             # 64 lanes/clk/CU, 256 CUs at 2.4 GHz; fp32 kind: v_add_f32 co-issues with v_max3_f32 (99.5 lanes/clk/CU)
             packed = kind in (0, 1)
-            all_ms = sum(e["ms"] for e in events if e["kind"] == kind)
-            all_cells = sum(e["cells"] for e in events if e["kind"] == kind)
-            kern_gcups = all_cells / 1e9 / (all_ms * 1e-3)
+            # GCUPS of the DP launches alone.  The launches of one scan run concurrently (the few long subjects on the
+            # auxiliary streams next to the bulk launch), so a scan counts with its longest launch, not with their sum
+            scans, cur = [], None
+            for e in events:
+                if cur is None or cur["qlen"] != e["qlen"]:
+                    cur = {"qlen": e["qlen"], "ms": 0.0, "cells": 0.0}
+                    scans.append(cur)
+                cur["ms"] = max(cur["ms"], e["ms"])
+                cur["cells"] += e["cells"]
+            kern_gcups = sum(x["cells"] for x in scans) / 1e9 / (sum(x["ms"] for x in scans) * 1e-3)
             valu_peak = 256 * (99.5 if kind == 3 else 64) * 2.4e9
             ipu = (counters.get("valu_instr_per_unit") or {}).get("%s:%s" % (args.workload, DTYPE_BY_KIND[kind])) if counters else None
             valu = {"bound": "valu-issue", "peak": round(valu_peak / 1e12, 3), "unit": "T lane-instr/s",

@@ -1,2 +1,4 @@
-timeout 1800 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -8
-for v in 0 100000; do echo "LANES8_MAX_SUBJECT=$v"; CUDASW4_AMD_LANES8_MAX_SUBJECT=$v timeout 900 python tools/peak_sweep.py --kernels half2,dpxs16 --lengths 128,256,512 2>&1 | grep -v amdgpu.ids | cut -c1-400; done
+bash tools/collect_profiles.sh r02 ed0a3ce > gpurun_out/collect_r02.log 2>&1
+bash tools/collect_profiles.sh r02 ed0a3ce --workload sprot-like > gpurun_out/collect_r02s.log 2>&1
+head -8 profiles/kernel_counters.json
+bash tools/full_measurement.sh 2>&1 | tail -16
