@@ -832,6 +832,11 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         // the border arrays hold lcap columns (sized from the caller's max_subject_len): never walk past them,
         // even if a caller under-reports the bound (scores of such subjects are then wrong, memory is not)
         if constexpr (MULTI) nquads = min(nquads, (p.lcap - 4) >> 2);
+        // the same in every lane of the wave (lmax was reduced over its groups): saying so turns the quad loop, its
+        // letter-reload test and the frame-lowering segments into scalar control flow (the counter otherwise lives in a
+        // VGPR, with a compare, an exec update and a masked branch per quad).  Single-stripe kernels: +0.5 %; the
+        // multi-stripe kernels schedule worse with it (4 instructions fewer per quad, yet -1 %), so they keep the vector loop
+        if constexpr (!MULTI) nquads = __builtin_amdgcn_readfirstlane(nquads);
         const int len0pad = (len0 + 3) & ~3, len1pad = (len1 + 3) & ~3;
 
         u32 maxv = OFFS ? 0u : A::kZero;  // OFFS tracks true scores (unbiased), the plain form the kind's own zero
