@@ -95,7 +95,8 @@ size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t
  *   kind            SW_KIND_*
  *   part_id         reference length-partition index 0..35.  Any subject length works with any id; ids 34/35
  *                   (the long partitions) select the wave-wide group shape when n is small, so that a few
- *                   giant subjects do not become the tail of the scan
+ *                   giant subjects do not become the tail of the scan; for ids 0..33 the library chooses 8- or
+ *                   16-lane groups from the query length and max_subject_len
  *   chars           DEVICE int8 codes, each subject padded to a multiple of 4 (dbdata layout)
  *   offsets         DEVICE uint64[>= first_pos+n+1]; offsets[i]-offsets[0] = byte offset of subject i
  *   lengths         DEVICE int32 true lengths
