@@ -21,7 +21,8 @@ ERR_NAMES = {-1: "SW_ERR_INVALID", -2: "SW_ERR_HIP", -3: "SW_ERR_NO_QUERY", -4: 
 
 # every symbol include/cudasw4_amd.h declares
 EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "sw_ctx_destroy", "sw_set_matrix",
-           "sw_set_query", "sw_scan_temp_bytes", "sw_scan_partition", "sw_rescore_overflow", "sw_topk_temp_bytes",
+           "sw_set_query", "sw_scan_temp_bytes", "sw_scan_partition", "sw_rescore_overflow", "sw_rescore_overflow_stat",
+           "sw_topk_temp_bytes",
            "sw_topk", "sw_plan_query"]
 
 
@@ -50,6 +51,8 @@ def _load():
                                     ctypes.c_int, vp, vp, i64, vp, vp, ctypes.c_int, vp, sz, vp]
     L.sw_rescore_overflow.argtypes = [vp, ctypes.c_int, vp, vp, i32, vp, vp, vp, i32, ctypes.c_int, ctypes.c_int,
                                       vp, vp, i64, vp, sz, vp]
+    L.sw_rescore_overflow_stat.argtypes = [vp, ctypes.c_int, vp, vp, i32, vp, vp, vp, i32, ctypes.c_int, ctypes.c_int,
+                                           vp, vp, i64, vp, sz, i32, vp, vp]
     L.sw_topk_temp_bytes.restype = sz
     L.sw_topk_temp_bytes.argtypes = [i64, ctypes.c_int]
     L.sw_topk.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp, vp, sz, vp]
@@ -123,6 +126,12 @@ class Context:
                          scores, ids, id_offset=0, temp=0, temp_bytes=0, stream=0):
         check(lib.sw_rescore_overflow(self.handle, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths,
                                       max_subject_len, gop, gex, scores, ids, id_offset, temp, temp_bytes, stream))
+
+    def rescore_overflow_stat(self, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len, gop, gex,
+                              scores, ids, id_offset, temp, temp_bytes, packed_limit, true_count, stream=0):
+        check(lib.sw_rescore_overflow_stat(self.handle, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths,
+                                           max_subject_len, gop, gex, scores, ids, id_offset, temp, temp_bytes,
+                                           packed_limit, true_count, stream))
 
     def topk(self, scores, ids, n, k, out_scores, out_ids, temp, temp_bytes, stream=0):
         check(lib.sw_topk(self.handle, scores, ids, n, k, out_scores, out_ids, temp, temp_bytes, stream))

@@ -20,6 +20,7 @@ struct swdrv_reader {
 struct swdrv {
     std::unique_ptr<SearchDriver> driver;
     std::shared_ptr<Database> db;
+    int lastRescored = 0;
 };
 
 namespace {
@@ -135,6 +136,7 @@ int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64
         }
         if (nres) *nres = n;
         if (num_overflows) *num_overflows = r.stats.numOverflows;
+        d->lastRescored = r.stats.numRescored;
         if (seconds) *seconds = r.stats.seconds;
         if (gcups) *gcups = r.stats.gcups;
     });
@@ -236,6 +238,8 @@ int swdrv_shard_ranges(const int32_t* sorted_lengths, const uint64_t* offsets, s
             }
     });
 }
+
+int swdrv_last_rescored(swdrv* d) { return d ? d->lastRescored : 0; }
 
 int32_t swdrv_reference_length(swdrv* d, int64_t id) { return d->driver->getReferenceLength(id); }
 

@@ -133,7 +133,9 @@ struct SearchDriver::Gpu {
     float* h_topS = nullptr;
     int32_t* h_topI = nullptr;
     int lastTop = 0;
-    int lastOverflows = 0;
+    int lastOverflows = 0;      // subjects of the last query whose exact score reached the packed kind's limit (the reference's statistic)
+    int lastRescored = 0;       // subjects the packed launches flagged and the 32-bit kind re-scored (>= lastOverflows)
+    int32_t* h_trueOvf = nullptr;  // pinned
     int32_t qlen = 0;
     double spanBegin = 0, spanEnd = 0;  // host clock, seconds since the scan started
     std::vector<TimedLaunch> timed;     // launches recorded since the last takeKernelEvents
@@ -227,7 +229,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             HIPCHECK(hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&g->scanned[i], hipEventDisableTiming));
         }
-        HIPCHECK(hipMalloc(&g->d_ovfCount, Gpu::kOvfLists * sizeof(int32_t)));
+        HIPCHECK(hipMalloc(&g->d_ovfCount, (Gpu::kOvfLists + 1) * sizeof(int32_t)));
+        HIPCHECK(hipHostMalloc(&g->h_trueOvf, sizeof(int32_t)));
         gpus_.push_back(std::move(g));
     }
     if (gpus_.size() > 1)
@@ -251,7 +254,7 @@ SearchDriver::~SearchDriver() {
         if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
         for (auto* v : {&g.timed, &g.freeTimed})
             for (TimedLaunch& t : *v) { (void)hipEventDestroy(t.ev0); (void)hipEventDestroy(t.ev1); }
-        (void)hipHostFree(g.h_ovfBatch);
+        (void)hipHostFree(g.h_ovfBatch); (void)hipHostFree(g.h_trueOvf);
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos); (void)hipFree(g.d_ovfCount);
         for (int i = 0; i <= Gpu::kAux; i++) (void)hipFree(g.d_temp[i]);
         for (int i = 0; i < Gpu::kAux; i++) {
@@ -480,9 +483,11 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         const int32_t n = int32_t(r.end - r.begin);
         const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, n, r.maxlen);
         void* temp = ensure_temp(g.d_temp[0], g.tempBytes[0], need, mem.maxTempBytes);
-        SWCHECK(sw_rescore_overflow(g.ctx, int(kt.overflowType), g.d_ovfPos + (r.begin - lbegin), g.d_ovfCount + ovfList[i], n,
-                                    chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
-                                    int64_t(lbegin), temp, g.tempBytes[0], g.stream));
+        SWCHECK(sw_rescore_overflow_stat(g.ctx, int(kt.overflowType), g.d_ovfPos + (r.begin - lbegin), g.d_ovfCount + ovfList[i], n,
+                                         chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
+                                         int64_t(lbegin), temp, g.tempBytes[0],
+                                         r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16,
+                                         g.d_ovfCount + GpuT::kOvfLists, g.stream));
     }
     (void)maxLen;
 }
@@ -584,6 +589,7 @@ void SearchDriver::scanStreamed(Gpu& g) {
 void SearchDriver::scanOnGpu(Gpu& g, int32_t queryLength, int k) {
     g.lastTop = 0;
     g.lastOverflows = 0;
+    g.lastRescored = 0;
     g.spanBegin = g.spanEnd = now_seconds() - scanT0_;
     if (g.numLocal == 0) return;
     g.use();
@@ -591,6 +597,7 @@ void SearchDriver::scanOnGpu(Gpu& g, int32_t queryLength, int k) {
     if (g.wantResident && !g.resident) uploadShard(g);  // the first query pays the upload unless --uploadFull
     SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
     // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
+    HIPCHECK(hipMemsetAsync(g.d_ovfCount + Gpu::kOvfLists, 0, sizeof(int32_t), g.stream));
     size_t nbatches = 1;
     if (g.resident) scanResident(g);
     else { scanStreamed(g); nbatches = g.batches.size(); }
@@ -617,8 +624,10 @@ void SearchDriver::scanOnGpu(Gpu& g, int32_t queryLength, int k) {
         HIPCHECK(hipMemcpyAsync(g.h_topI, g.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
         g.lastTop = kk;
     }
+    HIPCHECK(hipMemcpyAsync(g.h_trueOvf, g.d_ovfCount + Gpu::kOvfLists, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
     HIPCHECK(hipStreamSynchronize(g.stream));
-    for (size_t i = 0; i < nbatches * Gpu::kOvfLists; i++) g.lastOverflows += g.h_ovfBatch[i];
+    for (size_t i = 0; i < nbatches * Gpu::kOvfLists; i++) g.lastRescored += g.h_ovfBatch[i];
+    g.lastOverflows = *g.h_trueOvf;
     g.spanEnd = now_seconds() - scanT0_;
 }
 
@@ -654,6 +663,7 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
     for (auto& gp : gpus_) {
         Gpu& g = *gp;
         result.stats.numOverflows += g.lastOverflows;
+        result.stats.numRescored += g.lastRescored;
         for (int i = 0; i < g.lastTop; i++) hits.push_back(Hit{int(g.h_topS[i]), idBase_ + g.toGlobal(g.h_topI[i])});
     }
     // host merge of the per-GPU lists (replaces cudasw4.cuh:1415-1463): score desc, id asc

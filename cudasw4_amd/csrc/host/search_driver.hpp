@@ -46,7 +46,8 @@ struct MemoryConfig {  // cudasw4.cuh:95-100, options.hpp:34-39
 };
 
 struct BenchmarkStats {  // cudasw4.cuh:75-80
-    int numOverflows = 0;
+    int numOverflows = 0;  // subjects whose exact score reached the packed kind's limit: what the reference counts and prints
+    int numRescored = 0;   // subjects the packed kernels flagged and the 32-bit kind re-scored (a few more, include/cudasw4_amd.h)
     double seconds = 0;
     double gcups = 0;
 };

@@ -205,7 +205,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
                 const int32_t* positions, const int32_t* count_ptr, int32_t first_pos, int32_t n,
                 int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
                 int32_t* ovf_pos, int32_t* ovf_count, int ovf_check, void* temp, size_t temp_bytes,
-                hipStream_t stream) {
+                hipStream_t stream, int32_t* stat_count = nullptr, int32_t stat_limit = 0) {
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
     const swk::KindLaunch* kl = kind_launch(kind);
     if (!kl) return fail(SW_ERR_INVALID, "unknown kind");
@@ -282,6 +282,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     p.scores = scores; p.ids = ids; p.id_offset = id_offset;
     p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;
     p.scratch = nullptr; p.lcap = 0; p.zeros = ctx->d_zeros + kind * 16;
+    p.stat_count = stat_count; p.stat_limit = stat_limit;
     if (multi) {
         p.lcap = border_capacity(max_subject_len, lanes);
         const size_t per_wg = border_bytes_per_wg(p.lcap, lanes);
@@ -449,6 +450,14 @@ int sw_rescore_overflow(sw_ctx* ctx, int kind, const int32_t* ovf_pos, const int
                         const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
                         int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp,
                         size_t temp_bytes, void* stream) {
+    return sw_rescore_overflow_stat(ctx, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len, gop, gex,
+                                    scores, ids, id_offset, temp, temp_bytes, 0, nullptr, stream);
+}
+
+int sw_rescore_overflow_stat(sw_ctx* ctx, int kind, const int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
+                             const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
+                             int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp,
+                             size_t temp_bytes, int32_t packed_limit, int32_t* true_overflow_count, void* stream) {
     if (kind != SW_KIND_I32 && kind != SW_KIND_F32) return fail(SW_ERR_INVALID, "overflow re-score needs a 32-bit kind");
     if (!ovf_pos || !ovf_count) return fail(SW_ERR_INVALID, "null overflow buffers");
     if (max_count <= 0) return SW_OK;
@@ -456,7 +465,8 @@ int sw_rescore_overflow(sw_ctx* ctx, int kind, const int32_t* ovf_pos, const int
     // no device-side launch — cf. float_kernels.cuh:1206-1258)
     const int lanes = rescore_lanes(max_subject_len);
     return scan_common(ctx, kind, lanes, chars, offsets, lengths, ovf_pos, ovf_count, 0, max_count, max_subject_len, gop, gex,
-                       scores, ids, id_offset, nullptr, nullptr, 0, temp, temp_bytes, static_cast<hipStream_t>(stream));
+                       scores, ids, id_offset, nullptr, nullptr, 0, temp, temp_bytes, static_cast<hipStream_t>(stream),
+                       true_overflow_count, packed_limit);
 }
 
 // ------------------------------------------------------------------ top-K

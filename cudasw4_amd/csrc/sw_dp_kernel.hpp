@@ -342,6 +342,8 @@ struct ScanParams {
     u32 renorm_word;           // encode_gap(-a*K)
     u32 wrap_class;            // OFFS: encode_gap(-a*P), P = frame_classes(...) of the launched kernel (dp_step: row classes)
     u32 wrap_last;             // OFFS: encode_gap(-a*((R-1) % P + 1))
+    int32_t* stat_count;       // optional (re-score launches): += subjects whose exact score is >= stat_limit, i.e. the
+    int32_t stat_limit;        // reference's notion of an overflow (half2_kernels.cuh:1087-1109), for the printed statistic
 };
 
 template <int NW, int CHUNK_ROW_BYTES>
@@ -1014,6 +1016,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     p.ovf_pos[atomicAdd(p.ovf_count, 1)] = pos0;
                 } else {
                     p.scores[pos0] = (float)sc0;
+                    if (p.stat_count && sc0 >= p.stat_limit) atomicAdd(p.stat_count, 1);
                 }
                 p.ids[pos0] = (int32_t)(p.id_offset + pos0);
             }

@@ -18,7 +18,7 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_reader_next", "swdrv_reader_close", "swdrv_db_from_arrays", "swdrv_set_shard",
            "swdrv_record_kernel_events", "swdrv_take_kernel_events", "swdrv_shard_info", "swdrv_last_scores",
            "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges", "swdrv_matrix25",
-           "swdrv_encode25"]
+           "swdrv_encode25", "swdrv_last_rescored"]
 
 
 class DriverError(RuntimeError):
@@ -68,6 +68,7 @@ def _load():
     L.swdrv_plan_runs.argtypes = [vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
     L.swdrv_shard_ranges.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.swdrv_matrix25.argtypes = [ctypes.c_int, vp]
+    L.swdrv_last_rescored.argtypes = [vp]
     L.swdrv_encode25.argtypes = [ctypes.c_char_p, vp, sz]
     return L
 
@@ -287,6 +288,7 @@ class Driver:
                               ctypes.byref(nres), ctypes.byref(novf), ctypes.byref(sec), ctypes.byref(gcups)))
         n = nres.value
         return {"scores": scores[:n].copy(), "ids": ids[:n].copy(), "num_overflows": novf.value,
+                "num_rescored": int(lib.swdrv_last_rescored(self.handle)),
                 "seconds": sec.value, "gcups": gcups.value}
 
     def reference_length(self, i):

@@ -137,6 +137,18 @@ int sw_rescore_overflow(sw_ctx* ctx, int kind /* SW_KIND_I32 | SW_KIND_F32 */,
                         float* scores, int32_t* ids, int64_t id_offset,
                         void* temp, size_t temp_bytes, void* stream);
 
+/* The same, and additionally *true_overflow_count += the number of re-scored subjects whose exact score is >=
+ * packed_limit (SW_MAX_ACC_F16 / SW_MAX_ACC_I16 of the kind that flagged them): the reference's "num overflows"
+ * statistic (main.cu:243-245) counts exactly those, whereas the overflow list may hold a few subjects more (see
+ * sw_scan_partition).  true_overflow_count: DEVICE int32, may be NULL. */
+int sw_rescore_overflow_stat(sw_ctx* ctx, int kind,
+                             const int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
+                             const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
+                             int32_t max_subject_len, int gop, int gex,
+                             float* scores, int32_t* ids, int64_t id_offset,
+                             void* temp, size_t temp_bytes,
+                             int32_t packed_limit, int32_t* true_overflow_count, void* stream);
+
 /* Per-GPU top-K (cudasw4.cuh:1357-1401): the k best (score desc, id asc on ties) of n results.
  * out_scores/out_ids: DEVICE, k entries, padded with (-1, -1) when n < k.
  * temp: DEVICE scratch of sw_topk_temp_bytes(n, k). */

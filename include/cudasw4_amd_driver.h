@@ -50,9 +50,12 @@ int64_t swdrv_num_sequences(swdrv* d);
 int swdrv_num_gpus(swdrv* d);
 int swdrv_set_num_top(swdrv* d, int num_top);
 
-/* query: residue letters (not encoded).  scores/ids: capacity `cap`; *nres = number of results written. */
+/* query: residue letters (not encoded).  scores/ids: capacity `cap`; *nres = number of results written.
+ * *num_overflows: subjects whose exact score reached the packed kind's limit (2048 / 25000) — the reference's "num
+ * overflows" (main.cu:243-245); swdrv_last_rescored: how many subjects the last scan re-scored in 32 bits (>= that). */
 int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64_t* ids, int cap,
                int* nres, int* num_overflows, double* seconds, double* gcups);
+int swdrv_last_rescored(swdrv* d);
 
 /* ---- measurement / verification hooks (bench.py, tests) ----
  * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 8 doubles per launch
