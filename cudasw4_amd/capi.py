@@ -36,6 +36,12 @@ def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libcudasw4_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C cudasw4_amd/csrc`): %s" % LIB_PATH)
+    # PyTorch wheels bundle their own HIP runtime.  If this library pulled in the system's libamdhip64 first, a later
+    # `import torch` would bring a second runtime into the process and find no GPU: load torch's first when it is there.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
     L.sw_version.restype = ctypes.c_char_p

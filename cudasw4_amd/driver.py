@@ -28,6 +28,12 @@ class DriverError(RuntimeError):
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libcudasw4_host.so is not built: run __graft_entry__.build()")
+    # PyTorch wheels bundle their own HIP runtime.  If this library pulled in the system's libamdhip64 first, a later
+    # `import torch` would bring a second runtime into the process and find no GPU: load torch's first when it is there.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32
     L.swdrv_last_error.restype = ctypes.c_char_p

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Randomised soak test on the GPU box: random queries / databases / gap scores / matrices / kernel configurations /
+host-driver modes, every score of every subject compared with the CPU oracle.  TEST TOOL (uses oracle/ as the checker).
+
+    python tools/fuzz_gpu.py --seconds 600 [--seed 1]
+
+Prints one line per case and stops at the first mismatch with everything needed to reproduce it."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+import oracle_lib as O
+from cudasw4_amd import capi, driver, search
+
+LETTERS21 = b"ARNDCQEGHILKMFPSTWYVX"
+LETTERS25 = b"ARNDCQEGHILKMFPSTWYVBJZX*"
+
+
+def random_lengths(rng, n):
+    mode = rng.integers(0, 5) if n >= 16 else 1
+    if mode == 0:
+        l = rng.integers(1, 60, n)
+    elif mode == 1:
+        l = rng.integers(1, 700, n)
+    elif mode == 2:
+        l = np.concatenate([rng.integers(1, 400, n - n // 8), rng.integers(1281, 5000, n // 8)])
+    elif mode == 3:
+        l = np.concatenate([rng.integers(100, 1280, n - 3), rng.integers(8001, 12000, 3)])
+    else:
+        l = np.full(n, int(rng.integers(1, 900)))
+    return np.sort(l).astype(np.int32)
+
+
+def mutate(rng, seq, rate):
+    s = seq.copy()
+    mask = rng.random(len(s)) < rate
+    s[mask] = rng.integers(0, 20, int(mask.sum()))
+    return s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--driver-bias", type=float, default=0.0, help="fraction of cases forced to the default scoring so that they can go through the C++ driver")
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    case = 0
+    K = search.KernelTypeConfig
+    kind_cfgs = [(0, 0, 3, 3), (1, 1, 2, 2), (2, 1, 2, 2), (3, 0, 3, 3), (0, 1, 2, 3), (1, 0, 3, 2)]
+    qlen_choices = [1, 2, 7, 8, 9, 15, 16, 17, 63, 127, 128, 129, 143, 240, 241, 288, 289, 383, 384, 385, 511, 767, 768, 769,
+                    1023, 1535, 1536, 1537, 2047, 3071, 3073]
+    while time.time() < t_end:
+        case += 1
+        seed = int(rng.integers(0, 2**31))
+        r = np.random.default_rng(seed)
+        n = int(r.choice([1, 2, 3, 31, 32, 33, 64, 65, 200, 700, 2000]))
+        lengths = random_lengths(r, n)
+        full25 = bool(r.integers(0, 6) == 0)
+        which = int(r.choice([45, 50, 62, 80]))
+        gop, gex = [(-11, -1), (-11, -1), (-13, -2), (-10, -1), (-5, -5), (-20, -3), (-1, -1), (-40, -12), (-3, -12), (-100, -30)][int(r.integers(0, 10))]
+        if r.random() < args.driver_bias:
+            full25, which, gop, gex = False, 62, -11, -1
+        qlen = int(r.choice(qlen_choices)) if r.integers(0, 2) else int(r.integers(1, 5600))
+        if qlen * int(lengths.astype(np.int64).sum()) > 3e10:
+            qlen = max(1, int(3e10 / max(1, int(lengths.astype(np.int64).sum()))))
+        q = r.integers(0, 25 if full25 else 21, qlen).astype(np.int8)
+        seqs = [r.integers(0, 21 if r.integers(0, 4) == 0 else 20, int(l)).astype(np.int8) for l in lengths]
+        # homologs of the query among the subjects: large scores, overflow lists, re-score
+        if r.integers(0, 2) and not full25:
+            for _ in range(int(r.integers(1, 6))):
+                i = int(r.integers(0, n))
+                a = int(r.integers(0, max(1, qlen - 1)))
+                piece = mutate(r, np.minimum(q[a:a + int(lengths[i])], 20), float(r.choice([0.0, 0.05, 0.3])))
+                seqs[i][:len(piece)] = piece
+        chars, offsets, lens = O.make_db(seqs)
+        if full25:
+            m = driver.matrix25(which)
+            mo = np.ascontiguousarray(m.reshape(25, 25)[:, list(range(20)) + [23]])
+        else:
+            m = driver.matrix(which)
+            mo = O.blosum21(which)
+        expect = O.scan(q, chars, offsets, lens, m21=mo, gop=gop, gex=gex)
+        kinds = kind_cfgs[int(r.integers(0, len(kind_cfgs)))]
+        host = "capi" if (full25 or which != 62 or (gop, gex) != (-11, -1) or r.integers(0, 2)) else "driver"
+        desc = "case %d seed %d host %s n %d lens %d..%d qlen %d kinds %s mat %d%s gap %d/%d" % (
+            case, seed, host, n, int(lengths[0]), int(lengths[-1]), qlen, kinds, which, "_25" if full25 else "", gop, gex)
+        if host == "capi":
+            kt = K(*kinds)
+            os.environ["CUDASW4_AMD_LANES8_MAX_Q"] = str(int(r.choice([-1, -1, 0, 100000])))
+            os.environ["CUDASW4_AMD_LANES8_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 0, 100000])))
+            s = search.Searcher(device=0, num_top=min(10, n), matrix=m, kernel_types=kt, gop=gop, gex=gex,
+                                merge_partitions=bool(r.integers(0, 2)))
+            s.set_database(search.DeviceDB.from_arrays(chars, offsets, lens, device=0))
+            res = s.scan(q)
+            got = s.all_scores()
+            top = (res.scores, res.reference_ids)
+            del s
+        else:
+            letters = bytes(LETTERS21[c] for c in q)
+            devs = [[0], [0, 0], [0, 0, 0]][int(r.integers(0, 3))]
+            kw = {}
+            if r.integers(0, 2):
+                kw = dict(max_gpu_mem=1, max_batch_bytes=int(r.choice([2000, 20000, 300000])))
+            d = driver.Driver(devices=devs, num_top=min(10, n), kinds=kinds, **kw)
+            d.db_from_arrays(chars, offsets, lens)
+            rr = d.scan(letters)
+            ids, sc = d.all_scores()
+            got = np.empty_like(sc)
+            got[ids] = sc
+            top = (rr["scores"], rr["ids"])
+            # the reference's overflow statistic: subjects of the packed partitions whose exact score reaches the limit
+            packed = np.array([(kinds[0] if l <= 1280 else kinds[1] if l <= 8000 else kinds[2]) for l in lens])
+            limit = np.where(packed == 0, 2048, np.where(packed == 1, 25000, 2**30))
+            want_ovf = int((expect >= limit).sum())
+            if rr["num_overflows"] != want_ovf or rr["num_rescored"] < want_ovf:
+                print("FAIL overflow statistic", rr["num_overflows"], rr["num_rescored"], want_ovf, desc)
+                sys.exit(1)
+            d.close()
+            desc += " devs %d %s" % (len(devs), "streamed" if kw else "resident")
+        es, ei = O.topk(expect, min(10, n))
+        ok = (got == expect).all() and list(top[0]) == es.tolist() and list(top[1]) == ei.tolist()
+        print(("ok   " if ok else "FAIL ") + desc, flush=True)
+        if not ok:
+            bad = np.nonzero(got != expect)[0]
+            print("mismatches at", bad[:10], "got", got[bad[:10]], "expect", expect[bad[:10]], "lengths", lens[bad[:10]])
+            print("top got", top, "expect", es, ei)
+            sys.exit(1)
+    print("fuzz: %d cases, no mismatch" % case)
+
+
+if __name__ == "__main__":
+    main()
