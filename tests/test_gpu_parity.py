@@ -348,6 +348,7 @@ def test_every_compiled_tile_shape(monkeypatch):
     long_ = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1281, 1700, 9))]
     seen = set()
     for seqs, part_id, lanes in ((short, 33, 16), (long_, 34, 64), (short, 33, 8)):
+        monkeypatch.setenv("CUDASW4_AMD_I32_NATIVE", "1")  # the int32 kernels themselves, not their fp32 stand-ins
         monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_Q", "1000000" if lanes == 8 else "0")
         monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_SUBJECT", "1000000" if lanes == 8 else "0")
         ctx = capi.Context(0)  # reads the environment
@@ -523,3 +524,24 @@ def test_full_25_letter_matrix_all_kinds(which):
     ctx.set_query(np.array([0, 22, 3], dtype=np.int8))
     with pytest.raises(capi.SwError):
         ctx.set_query(np.array([0, 25], dtype=np.int8))
+
+
+@pytest.mark.parametrize("native", ["0", "1"])
+def test_int32_kind_native_and_in_fp32_lanes(native, monkeypatch):
+    """The int32 kind is served by the fp32 kernels whenever min(query, subject) * max(matrix) + 2^22 < 2^24 proves the
+    fp32 arithmetic exact (sw_api.hip: effective_kind); CUDASW4_AMD_I32_NATIVE=1 keeps the int32 kernels.  Both must give
+    the oracle's scores: ragged DB with long subjects, homologs scoring far above the 16-bit ranges, all partitions int32."""
+    torch, capi, search = gpu_modules()
+    monkeypatch.setenv("CUDASW4_AMD_I32_NATIVE", native)
+    rng = np.random.default_rng(4242)
+    _, qs = O.load_queries()
+    lens = np.sort(np.concatenate([rng.integers(1, 1280, 300), rng.integers(1281, 6000, 20), [9000]]))
+    seqs = [rng.integers(0, 21, int(l)).astype(np.int8) for l in lens]
+    seqs[310][:len(qs[17])] = qs[17][:len(seqs[310])]   # a homolog of query 17 (4743 residues): score in the tens of thousands
+    db = O.make_db(seqs)
+    kt = search.KernelTypeConfig(capi.KIND_I32, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_I32)
+    for qi in (0, 6, 17):
+        expect = O.scan(qs[qi], *db, simd=True)
+        got, res, _ = scan_all_scores(search, capi, db, qs[qi], kernel_types=kt)
+        np.testing.assert_array_equal(got, expect, err_msg="native %s query %d" % (native, qi))
+    assert expect.max() > 10000

@@ -95,6 +95,7 @@ def main():
             case, seed, host, n, int(lengths[0]), int(lengths[-1]), qlen, kinds, which, "_25" if full25 else "", gop, gex)
         if host == "capi":
             kt = K(*kinds)
+            os.environ["CUDASW4_AMD_I32_NATIVE"] = str(int(r.integers(0, 2)))
             os.environ["CUDASW4_AMD_LANES8_MAX_Q"] = str(int(r.choice([-1, -1, 0, 100000])))
             os.environ["CUDASW4_AMD_LANES8_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 0, 100000])))
             s = search.Searcher(device=0, num_top=min(10, n), matrix=m, kernel_types=kt, gop=gop, gex=gex,
