@@ -62,18 +62,23 @@ QueryPlan plan_query(int kind, int32_t qlen, int lanes) {
     pl.lanes = lanes;
     if (!kl || qlen <= 0) return pl;
     const int maxrows = swk::max_rows(kind, lanes);
-    const int64_t stripe_max = (int64_t)lanes * maxrows;
-    const int ns_min = (int)((qlen + stripe_max - 1) / stripe_max);
+    // fp32 multi-stripe kernels above 32 rows per lane lose the third wave per SIMD (their single-stripe kernels keep it up to 36)
+    const int maxrows_multi = (kind == SW_KIND_F32 && lanes <= 16) ? std::min(maxrows, swk::kMaxRowsScalarMulti) : maxrows;
     double best = 1e300;
-    for (int ns = ns_min; ns <= ns_min + 2; ns++) {
+    auto consider = [&](int ns) {
         const int64_t per_lane = (qlen + (int64_t)lanes * ns - 1) / ((int64_t)lanes * ns);
         int r = (int)((per_lane + swk::kRowsGranule - 1) / swk::kRowsGranule * swk::kRowsGranule);
-        r = std::min(std::max(r, swk::kRowsGranule), maxrows);
-        if (ns > 1 && 2 * r <= maxrows) continue;  // multi-stripe kernels exist for R > max/2 only
+        r = std::max(r, swk::kRowsGranule);
+        if (r > (ns > 1 ? maxrows_multi : maxrows)) return;
+        if (ns > 1 && 2 * r <= maxrows) return;  // multi-stripe kernels exist for R > max/2 only
         // per-step overhead in row equivalents: ~10 VALU ops single-stripe, ~20 with the stripe border
         const double cost = ns * (r + (ns > 1 ? 2.5 : 1.2));
         if (cost < best - 1e-9) { best = cost; pl.rows = r; pl.nstripes = ns; }
-    }
+    };
+    if (qlen <= (int64_t)lanes * maxrows) consider(1);
+    const int64_t stripe_multi = (int64_t)lanes * maxrows_multi;
+    const int ns_m = std::max<int>(2, (int)((qlen + stripe_multi - 1) / stripe_multi));
+    for (int ns = ns_m; ns <= ns_m + 2; ns++) consider(ns);
     return pl;
 }
 

@@ -16,9 +16,10 @@ constexpr int kRowsGranule = 1;
 #endif
 constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 768 query rows, 63 KB tile of wide words (two workgroups per CU, LDS addresses stay below 64 KB); 256 VGPRs (2 waves/SIMD)
 #ifndef SWK_MAX_ROWS_SCALAR
-#define SWK_MAX_ROWS_SCALAR 32
+#define SWK_MAX_ROWS_SCALAR 36
 #endif
-constexpr int kMaxRowsScalar = SWK_MAX_ROWS_SCALAR;  // fp32: stripe = 512 query rows (32-bit profile entries, 43 KB tile); its add/max3 co-issue wants three waves per SIMD
+constexpr int kMaxRowsScalar = SWK_MAX_ROWS_SCALAR;  // fp32: its add/max3 co-issue wants three waves per SIMD: a single stripe up to 576 query rows (47 KB tile, three workgroups per CU; the 567-residue query 7.55 -> 8.71 TCUPS against two stripes of 18 rows), several stripes up to 32 rows per lane (kMaxRowsScalarMulti)
+constexpr int kMaxRowsScalarMulti = 32;
 #ifndef SWK_MAX_ROWS_I32
 #define SWK_MAX_ROWS_I32 48
 #endif

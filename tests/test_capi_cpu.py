@@ -42,7 +42,7 @@ def test_version_and_plan_without_gpu(built):
             r, s = capi.plan_query(kind, q)
             assert 1 <= r <= 48 and 16 * r * s >= q > 16 * r * s - 16 * s   # padding below one row per lane and stripe
             assert (q + 767) // 768 <= s <= (q + 767) // 768 + 2
-    for kind, rmax in ((capi.KIND_I32, 48), (capi.KIND_F32, 32)):
+    for kind, rmax in ((capi.KIND_I32, 48), (capi.KIND_F32, 36)):
         for q in (1, 256, 257, 567, 5478):
             r, s = capi.plan_query(kind, q)
             assert 1 <= r <= rmax and 16 * r * s >= q > 16 * r * s - 16 * s

@@ -362,18 +362,19 @@ def test_every_compiled_tile_shape(monkeypatch):
         ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
         ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
-            rmax = {8: 48 if kind < 3 else 32, 16: 48 if kind < 3 else 32, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
+            rmax = {8: 48 if kind < 3 else 36, 16: 48 if kind < 3 else 36, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
+            rmax_multi = 32 if (kind == 3 and lanes <= 16) else rmax  # fp32: several stripes only up to 32 rows per lane
             qlens = set()
             for r in range(1, rmax + 1):
                 qlens.add(lanes * r - 1)                       # one stripe of R rows
                 if lanes == 16:
                     assert capi.plan_query(kind, lanes * r - 1) == (r, 1)
-                if 2 * r > rmax:
+                if 2 * r > rmax and r <= rmax_multi:
                     qlens.add(2 * lanes * r - lanes - 3)       # two stripes of R rows
                     if lanes == 16:
                         assert capi.plan_query(kind, 2 * lanes * r - lanes - 3) == (r, 2)
             qlens.add(lanes * rmax)                            # the longest single-stripe query of the shape
-            qlens.add(3 * lanes * rmax - 5)                    # three full stripes
+            qlens.add(3 * lanes * rmax_multi - 5)              # three full stripes
             for qlen in sorted(qlens):
                 q = rng.integers(0, 20, qlen).astype(np.int8)
                 expect = O.scan(q, chars, offsets, lengths, simd=True)
