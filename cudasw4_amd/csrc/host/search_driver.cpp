@@ -421,7 +421,7 @@ void* ensure_temp(void*& ptr, size_t& have, size_t need, size_t cap) {
 // with the most subjects goes to the work stream; the others (few long subjects) are launched FIRST on auxiliary
 // streams so that they hold their handful of workgroups while the bulk run fills the rest of the GPU.
 template <class GpuT>
-static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t lend, int32_t maxLen, const Database& db,
+static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t lend, const Database& db,
                           const KernelTypeConfig& kt, const MemoryConfig& mem, int gop, int gex, int recordMode) {
     const auto runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, lend,
                                        [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); });
@@ -489,7 +489,6 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
                                          r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16,
                                          g.d_ovfCount + GpuT::kOvfLists, g.stream));
     }
-    (void)maxLen;
 }
 
 static void ensure_ovf_slots(int32_t*& h, size_t& cap, size_t need) {
@@ -502,7 +501,7 @@ static void ensure_ovf_slots(int32_t*& h, size_t& cap, size_t need) {
 
 void SearchDriver::scanResident(Gpu& g) {
     ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, Gpu::kOvfLists);
-    enqueue_batch(g, g.d_chars, 0, g.numLocal, g.maxLen, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
+    enqueue_batch(g, g.d_chars, 0, g.numLocal, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
     // per-query total (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
     HIPCHECK(hipMemcpyAsync(g.h_ovfBatch, g.d_ovfCount, Gpu::kOvfLists * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
 }
@@ -576,7 +575,7 @@ void SearchDriver::scanStreamed(Gpu& g) {
         HIPCHECK(hipEventRecord(g.copied[slot], g.copyStream));
         HIPCHECK(hipStreamWaitEvent(g.stream, g.copied[slot], 0));
         HIPCHECK(hipEventRecord(g.batchEv[2 * k], g.stream));
-        enqueue_batch(g, dst, b.lbegin, b.lend, b.maxLen, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
+        enqueue_batch(g, dst, b.lbegin, b.lend, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
         HIPCHECK(hipMemcpyAsync(g.h_ovfBatch + k * Gpu::kOvfLists, g.d_ovfCount, Gpu::kOvfLists * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
         HIPCHECK(hipEventRecord(g.batchEv[2 * k + 1], g.stream));
         HIPCHECK(hipEventRecord(g.scanned[slot], g.stream));
