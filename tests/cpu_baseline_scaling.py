@@ -2,7 +2,7 @@
 """Thread scaling of the CPU baseline (oracle's inter-sequence SIMD scan) on this host."""
 import os, sys, time
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # TEST INFRASTRUCTURE: times the oracle, nothing of the product
 import oracle_lib as O
 
 _, qs = O.load_queries()

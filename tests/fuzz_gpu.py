@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised soak test on the GPU box: random queries / databases / gap scores / matrices / kernel configurations /
-host-driver modes, every score of every subject compared with the CPU oracle.  TEST TOOL (uses oracle/ as the checker).
+host-driver modes, every score of every subject compared with the CPU oracle.  TEST INFRASTRUCTURE (the oracle is the
+checker); tests/test_gpu_fuzz.py runs a short pass of it inside the GPU suite.
 
-    python tools/fuzz_gpu.py --seconds 600 [--seed 1]
+    python tests/fuzz_gpu.py --seconds 600 [--seed 1] [--driver-bias 0.3]
 
 Prints one line per case and stops at the first mismatch with everything needed to reproduce it."""
 import argparse
@@ -45,12 +46,12 @@ def mutate(rng, seq, rate):
     return s
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--driver-bias", type=float, default=0.0, help="fraction of cases forced to the default scoring so that they can go through the C++ driver")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     case = 0
@@ -136,6 +137,7 @@ def main():
             print("top got", top, "expect", es, ei)
             sys.exit(1)
     print("fuzz: %d cases, no mismatch" % case)
+    return case
 
 
 if __name__ == "__main__":
