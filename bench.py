@@ -28,7 +28,8 @@ After the timed region every query is scanned once more and EVERY score is check
 golden scores in tests/golden/ref_scores.json; sprot-like: against the CPU oracle on the cpu_baseline sample, or
 packed-vs-int32 equality of all scores when there is no CPU leg) -> "verified".
 
-The default (peak) run also measures the sprot-like workload afterwards and reports it as `"sprot_like": {...}` in the
+With N > 1 ranks the default (strong-scaling) line also carries `"weak_scaling": {...}`: the same benchmark with one full
+DB per rank.  The default (peak) run also measures the sprot-like workload afterwards and reports it as `"sprot_like": {...}` in the
 same line (its own timed region, verification, roofline and CPU leg), so that BASELINE config 3 is under the same clock.
 
 Prints ONE JSON line on rank 0 (driver contract), including `roofline` and `cpu_baseline`.
@@ -231,6 +232,16 @@ def run_rank(args):
         if rank == 0:
             out["sprot_like"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "verified", "verified_how",
                                                       "config", "roofline", "valu_roofline", "cpu_baseline") if k in sec}
+    if distributed and world > 1 and args.scaling == "strong" and args.workload == "peak" and not args.no_secondary:
+        # next to the strong-scaling headline (ONE DB sharded over the ranks): the same benchmark with one full DB per
+        # rank, so that a multi-GPU run shows both what sharding a 532 MB DB eight ways costs and what the GPUs do when
+        # each keeps a full-size shard
+        import copy
+        a3 = copy.copy(args)
+        a3.scaling = "weak"
+        wk = measure(env, a3, "peak", want_cpu=False)
+        if rank == 0:
+            out["weak_scaling"] = {k: wk[k] for k in ("value", "unit", "ms_per_step", "scaling", "verified", "config") if k in wk}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

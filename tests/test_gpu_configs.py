@@ -155,10 +155,19 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
     two = run_bench(["--gpus", "2"] + common, hooks)
     assert two["n_gpus"] == 2 and two["verified"] is True and two["scaling"] == "strong"
     assert two["config"]["db_subjects"] == 200000
-    assert two["config"]["top_merged_example"] == one["config"]["top_merged_example"]
+    assert two["config"]["top_merged_example"] == one["config"]["top_merged_example"] and "weak_scaling" not in two
     weak = run_bench(["--gpus", "2", "--scaling", "weak"] + common, hooks)
     assert weak["n_gpus"] == 2 and weak["verified"] is True and weak["scaling"] == "weak"
     assert weak["config"]["db_subjects"] == 400000
+
+
+def test_bench_two_rank_default_line_carries_weak_scaling_and_sprot_like():
+    """The default multi-rank line: strong scaling headline + the weak-scaling run + the Swiss-Prot-like workload."""
+    hooks = {"BENCH_FORCE_DEVICE": "0", "BENCH_DIST_BACKEND": "gloo"}
+    out = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--db-size", "100000", "--no-cpu-baseline"], hooks)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["verified"] is True
+    assert out["weak_scaling"]["scaling"] == "weak" and out["weak_scaling"]["verified"] is True
+    assert out["weak_scaling"]["config"]["db_subjects"] == 200000 and out["sprot_like"]["verified"] is True
 
 
 def test_bench_process_group_path_with_the_real_backend():
