@@ -350,7 +350,13 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
     // otherwise they go through two pinned staging buffers per GPU.  CUDASW4_AMD_NO_HOSTREGISTER=1 forces the latter.
     if (anyStreamed && db_->num_chars() > 0) {
         const char* no = std::getenv("CUDASW4_AMD_NO_HOSTREGISTER");
-        if (!(no && no[0] == '1')) {
+        // registering pins the whole mapping (and faults a memory-mapped file in): fine for DBs of tens of GB, not for
+        // ones that rival the host's memory — above CUDASW4_AMD_HOSTREGISTER_MAX_GB (default 64) the pinned staging
+        // buffers are used instead
+        double maxGb = 64.0;
+        if (const char* e = std::getenv("CUDASW4_AMD_HOSTREGISTER_MAX_GB")) maxGb = std::atof(e);
+        const bool small = double(db_->num_chars()) <= maxGb * double(size_t(1) << 30);
+        if (!(no && no[0] == '1') && small) {
             const hipError_t e = hipHostRegister(const_cast<int8_t*>(db_->chars()), db_->num_chars(), hipHostRegisterPortable);
             dbRegistered_ = e == hipSuccess;
             if (!dbRegistered_) (void)hipGetLastError();
