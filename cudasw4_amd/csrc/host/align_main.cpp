@@ -112,7 +112,9 @@ int main(int argc, char** argv) {
         if (!options.usePseudoDB) {
             if (options.verbose) std::cout << "Reading Database: \n";
             Stopwatch t;
-            auto db = Database::open(options.dbPrefix, options.prefetchDBFile);
+            bool mapped = true;
+            auto db = Database::open_or_read(options.dbPrefix, options.prefetchDBFile, &mapped);
+            if (options.verbose && !mapped) std::cout << "Failed to map db files. Using fallback db.\n";  // main.cu:180-183
             if (options.verbose) t.print("Read DB");
             driver.setDatabase(db);
         } else {

@@ -13,6 +13,7 @@
 #include <parallel/algorithm>
 #include <cstdlib>
 #include <random>
+#include <type_traits>
 
 #include "sequence_codec.hpp"
 
@@ -147,7 +148,7 @@ struct Mapping {
             int flags = MAP_PRIVATE;
             if (populate) flags |= MAP_POPULATE;
             ptr = mmap(nullptr, bytes, PROT_READ, flags, fd, 0);
-            if (ptr == MAP_FAILED) { ptr = nullptr; ::close(fd); throw DbLoadError("Cannot mmap " + path); }
+            if (ptr == MAP_FAILED) { ptr = nullptr; ::close(fd); throw DbMapError("Cannot mmap " + path); }
         }
         ::close(fd);
     }
@@ -212,6 +213,9 @@ std::shared_ptr<Database> Database::open(const std::string& prefix, bool prefetc
         std::ifstream marker(prefix + "metadata", std::ios::binary);  // dbdata.cpp:199-204
         if (!marker) throw DbLoadError("Cannot open DB " + prefix + " (missing " + prefix + "metadata)");
     }
+    if (const char* e = std::getenv("CUDASW4_AMD_DB_NO_MMAP")) {
+        if (e[0] == '1') throw DbMapError("memory mapping disabled by CUDASW4_AMD_DB_NO_MMAP");
+    }
     std::shared_ptr<Database> db(new Database);
     db->storage_ = std::make_unique<Storage>();
     Storage& s = *db->storage_;
@@ -237,6 +241,49 @@ std::shared_ptr<Database> Database::open(const std::string& prefix, bool prefetc
     const bool check = v ? v[0] == '1' : (prefetch || db->num_chars() <= (size_t(4) << 30));
     if (check) db->validate_codes();
     return db;
+}
+
+// loadDBWithVectors (dbdata.cpp:118-190): the same files read into memory with plain file I/O — the fallback `align`
+// takes when the files cannot be memory-mapped (main.cu:180-191), and what CUDASW4_AMD_DB_NO_MMAP=1 forces (tests)
+std::shared_ptr<Database> Database::open_with_vectors(const std::string& prefix) {
+    {
+        std::ifstream marker(prefix + "metadata", std::ios::binary);
+        if (!marker) throw DbLoadError("Cannot open DB " + prefix + " (missing " + prefix + "metadata)");
+    }
+    auto slurp = [](const std::string& path, auto& vec) {
+        using T = typename std::remove_reference_t<decltype(vec)>::value_type;
+        std::ifstream in(path, std::ios::binary | std::ios::ate);
+        if (!in) throw DbLoadError("Cannot open " + path);
+        const std::streamsize bytes = in.tellg();
+        if (bytes % std::streamsize(sizeof(T))) throw DbLoadError("Corrupt DB file " + path);
+        vec.resize(size_t(bytes) / sizeof(T));
+        in.seekg(0);
+        if (bytes && !in.read(reinterpret_cast<char*>(vec.data()), bytes)) throw DbLoadError("Cannot read " + path);
+    };
+    const std::string chunk = prefix + "0";
+    std::vector<int8_t> chars;
+    std::vector<uint64_t> offsets, header_offsets;
+    std::vector<int32_t> lengths;
+    std::vector<char> headers;
+    slurp(chunk + "chars", chars);
+    slurp(chunk + "offsets", offsets);
+    slurp(chunk + "lengths", lengths);
+    slurp(chunk + "headers", headers);
+    slurp(chunk + "headeroffsets", header_offsets);
+    if (offsets.size() != lengths.size() + 1 || header_offsets.size() != lengths.size() + 1)
+        throw DbLoadError("DB offset files do not match the number of sequences");
+    return from_vectors(std::move(chars), std::move(offsets), std::move(lengths), std::move(headers), std::move(header_offsets));
+}
+
+std::shared_ptr<Database> Database::open_or_read(const std::string& prefix, bool prefetch, bool* mapped) {
+    try {
+        auto db = open(prefix, prefetch);
+        if (mapped) *mapped = true;
+        return db;
+    } catch (const DbMapError&) {
+        if (mapped) *mapped = false;
+        return open_with_vectors(prefix);
+    }
 }
 
 std::shared_ptr<Database> Database::from_vectors(std::vector<int8_t> chars, std::vector<uint64_t> offsets,

@@ -33,6 +33,11 @@ class DbLoadError : public std::runtime_error {
 public:
     using std::runtime_error::runtime_error;
 };
+// the files exist but cannot be memory-mapped: callers fall back to Database::open_with_vectors (main.cu:180-191)
+class DbMapError : public DbLoadError {
+public:
+    using DbLoadError::DbLoadError;
+};
 
 // Sequences collected by makedb before sorting (HybridBatch, makedb.cpp:80-133): raw letters, padded to 4
 // with ' '.  With a memory limit (--mem) the five arrays share the budget 50/7/7/29/7 % like the reference
@@ -66,6 +71,10 @@ class Database {
 public:
     // loadDB (dbdata.cpp:46-116,207-222); prefetch == MAP_POPULATE (mapped_file.hpp:76-78)
     static std::shared_ptr<Database> open(const std::string& prefix, bool prefetch);
+    // loadDBWithVectors (dbdata.cpp:118-190): the files read into memory, for when they cannot be mapped
+    static std::shared_ptr<Database> open_with_vectors(const std::string& prefix);
+    // open(), falling back to open_with_vectors() on a DbMapError like the reference's main (main.cu:172-191)
+    static std::shared_ptr<Database> open_or_read(const std::string& prefix, bool prefetch, bool* mapped = nullptr);
     // PseudoDBdata (dbdata.hpp:222-272): one std::mt19937(seed) sequence of `length` replicated `num` times
     static std::shared_ptr<Database> pseudo(size_t num, int32_t length, int seed = 42);
     // from arrays already in dbdata layout (used by tests / embedding)

@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     try {
-        auto db = swh::Database::open(argv[1], false);
+        auto db = swh::Database::open_or_read(argv[1], false);
         const int shards = argc > 2 ? std::atoi(argv[2]) : 1;
         std::cout << "{\"num_sequences\": " << db->num_sequences() << ", \"num_chars\": " << db->num_chars()
                   << ", \"residues\": " << db->total_residues() << ", \"partition_counts\": [";

@@ -85,7 +85,7 @@ int swdrv_destroy(swdrv* d) {
 
 int swdrv_open_db(swdrv* d, const char* prefix, int prefetch) {
     return guarded([&] {
-        d->db = Database::open(prefix, prefetch != 0);
+        d->db = Database::open_or_read(prefix, prefetch != 0);
         d->driver->setDatabase(d->db);
     });
 }

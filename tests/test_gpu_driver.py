@@ -184,3 +184,19 @@ def test_driver_and_align_with_full_25_letter_matrix(tmp_path):
     p = subprocess.run([driver.ALIGN, "--query", fa, "--db", GOLDEN_DB, "--top", "2", "--mat", "blosum62_25"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert "blosum: blosum62_25" in p.stdout and "Result 0. Score: %d." % es[0] in p.stdout and "Result 1. Score: %d." % es[1] in p.stdout
+
+
+def test_align_with_the_vector_loader_fallback():
+    """`align` when the DB files cannot be memory-mapped (forced here): loadDBWithVectors path (main.cu:180-191),
+    same hits; with --maxGpuMem 1 the shard streams from the in-memory copy."""
+    from cudasw4_amd import driver
+    g = O.golden("ref_scores.json")
+    env = dict(os.environ, CUDASW4_AMD_DB_NO_MMAP="1")
+    for extra in ([], ["--maxGpuMem", "1", "--maxBatchBytes", "5000"]):
+        p = subprocess.run([driver.ALIGN, "--query", FASTA, "--db", GOLDEN_DB, "--top", "1", "--verbose"] + extra,
+                           capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stderr
+        assert "Failed to map db files. Using fallback db." in p.stdout
+        for qi in (0, 9, 19):
+            es, ei = expected_top(g["allvsall"][qi], 1)
+            assert "Result 0. Score: %d." % es[0] in p.stdout

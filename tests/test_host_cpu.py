@@ -367,3 +367,17 @@ def test_makedb_at_scale(tmp_path, n, mean_len, parallel):
         ref = run_makedb(REF_MAKEDB, fasta, str(tmp_path / "ref"))
         for f in DB_FILES:
             assert open(prefix + f, "rb").read() == ref[f], f
+
+
+def test_vector_loader_fallback_when_the_files_cannot_be_mapped(tmp_path, golden_dir):
+    """main.cu:172-191 / dbdata.cpp:118-190: when the DB files cannot be memory-mapped the loader reads them into memory
+    (loadDBWithVectors); CUDASW4_AMD_DB_NO_MMAP=1 forces that path.  Same content, same validation."""
+    import json
+    dbinspect = os.path.join(LIBDIR, "dbinspect")
+    prefix = os.path.join(golden_dir, "allqueries_db", "aq")
+    a = json.loads(subprocess.check_output([dbinspect, prefix, "3"]))
+    b = json.loads(subprocess.check_output([dbinspect, prefix, "3"], env=dict(os.environ, CUDASW4_AMD_DB_NO_MMAP="1")))
+    assert a == b and a["num_sequences"] == 20
+    bad = subprocess.run([dbinspect, str(tmp_path / "nope")], capture_output=True, text=True,
+                         env=dict(os.environ, CUDASW4_AMD_DB_NO_MMAP="1"))
+    assert bad.returncode == 1 and "Cannot open DB" in bad.stderr

@@ -14,7 +14,8 @@ for num in (1_000_000, 125_000):
     db = search.DeviceDB.pseudo(num, L, driver.pseudo_sequence(L, 42), device=0)
     kt = search.KernelTypeConfig()
     ss = [search.Searcher(device=0, num_top=10, matrix=driver.matrix(62), kernel_types=kt) for _ in range(2)]
-    streams = [torch.cuda.Stream(device=0, priority=0), torch.cuda.Stream(device=0, priority=-1)]
+    prios = [int(x) for x in os.environ.get("PROBE_PRIOS", "0,-1").split(",")]
+    streams = [torch.cuda.Stream(device=0, priority=prios[0]), torch.cuda.Stream(device=0, priority=prios[1])]
     for s in ss:
         s.set_database(db)
         s.scan(queries[0]); s.scan(queries[19])
