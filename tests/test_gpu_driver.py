@@ -200,3 +200,25 @@ def test_align_with_the_vector_loader_fallback():
         for qi in (0, 9, 19):
             es, ei = expected_top(g["allvsall"][qi], 1)
             assert "Result 0. Score: %d." % es[0] in p.stdout
+
+
+def test_more_than_4_gib_of_subject_chars_resident_and_streamed():
+    """Offsets beyond 2^32: a pseudo DB of 8.5 million subjects x 512 residues (4.35 GB of chars) through the C++ driver,
+    resident and streamed in 1 GiB batches; every score equals the reference's golden score, ids are global."""
+    from cudasw4_amd import driver
+    g = O.golden("ref_scores.json")
+    _, seqs = O.read_fasta(FASTA)
+    n = 8_500_000
+    for kw in ({}, dict(max_gpu_mem=2 << 30, max_batch_bytes=1 << 30)):
+        d = driver.Driver(devices=[0], num_top=5, kinds=(0, 0, 3, 3), **kw)
+        d.pseudo_db(n, 512)
+        if not kw:
+            d.upload()
+        assert d.shard_info(0)["resident"] == (not kw) and d.shard_info(0)["chars"] == n * 512 > 2**32
+        for qi in (0, 3):
+            r = d.scan(seqs[qi])
+            assert r["scores"].tolist() == [g["pseudo"]["512"][qi]] * 5 and r["ids"].tolist() == [0, 1, 2, 3, 4]
+            sc, ids = d.last_scores(0)
+            assert len(sc) == n and int(sc.min()) == int(sc.max()) == g["pseudo"]["512"][qi]
+            assert int(ids[-1]) == n - 1 and int(ids[n // 2]) == n // 2
+        d.close()
