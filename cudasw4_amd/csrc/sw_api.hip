@@ -128,6 +128,7 @@ struct sw_ctx {
     bool i32_native = false;     // CUDASW4_AMD_I32_NATIVE=1: never compute the int32 kind in fp32 lanes (tests of the int32 kernels)
     int32_t lanes8_max_subject = -1;  // CUDASW4_AMD_LANES8_MAX_SUBJECT: multi-stripe queries use 8-lane groups when no subject of the launch is longer (-1: built-in)
     int32_t lanes8_max_q = -1;   // CUDASW4_AMD_LANES8_MAX_Q: queries up to this length use 8-lane groups (0: never; -1: the built-in limits)
+    bool check_bounds = false;   // CUDASW4_AMD_CHECK_BOUNDS=1 (debug): every scan first verifies the max_subject_len contract on the device (synchronises)
 };
 
 namespace {
@@ -221,6 +222,16 @@ size_t border_bytes_per_wg(int32_t lcap, int lanes) {
     return (size_t)(swk::kThreads / lanes) * region * sizeof(uint32_t);
 }
 
+// Debug check of the max_subject_len contract (include/cudasw4_amd.h): longest subject of the range / of the listed positions
+__global__ void max_length_kernel(const int32_t* lengths, const int32_t* positions, const int32_t* count_ptr, int32_t first_pos,
+                                  int32_t n, int32_t* out) {
+    const int32_t cnt = count_ptr ? min(*count_ptr, n) : n;
+    int32_t m = 0;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x)
+        m = max(m, lengths[positions ? positions[i] : first_pos + i]);
+    if (m > 0) atomicMax(out, m);
+}
+
 int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
                 const int32_t* positions, const int32_t* count_ptr, int32_t first_pos, int32_t n,
                 int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
@@ -238,6 +249,18 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     if (!chars || !offsets || !lengths || !scores || !ids) return fail(SW_ERR_INVALID, "null buffer");
     if (ovf_check && kind_packed(kind) && (!ovf_pos || !ovf_count)) return fail(SW_ERR_INVALID, "overflow check without overflow buffers");
     SW_HIP(hipSetDevice(ctx->device));
+    if (ctx->check_bounds) {
+        int32_t* slot = reinterpret_cast<int32_t*>(ctx->d_zeros + 64);
+        int32_t longest = 0;
+        SW_HIP(hipMemsetAsync(slot, 0, sizeof(int32_t), stream));
+        hipLaunchKernelGGL(max_length_kernel, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, stream, lengths, positions, count_ptr, first_pos, n, slot);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipMemcpyAsync(&longest, slot, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        if (longest > max_subject_len)
+            return fail(SW_ERR_INVALID, "max_subject_len " + std::to_string(max_subject_len) + " under-reports: a subject of the range has " +
+                                            std::to_string(longest) + " residues");
+    }
     // Column-offset recurrence (7.5 instead of 8.5 instructions per cell pair): values grow by a = -gex per column,
     // so it is used while a * columns leaves room below the kind's limit (fp16: 3/4 of the exact range — every
     // single-pass partition with the default gap scores; int16: half).  A subject whose bound score + a * columns
@@ -322,7 +345,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
 
 extern "C" {
 
-const char* sw_version(void) { return "cudasw4_amd 0.1 (gfx950)"; }
+const char* sw_version(void) { return "cudasw4_amd 0.2 (gfx950)"; }
 
 const char* sw_last_error(void) { return g_last_error.c_str(); }
 
@@ -350,8 +373,9 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_I32_NATIVE")) ctx->i32_native = e[0] == '1';
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_Q")) ctx->lanes8_max_q = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_SUBJECT")) ctx->lanes8_max_subject = atoi(e);
+    if (const char* e = getenv("CUDASW4_AMD_CHECK_BOUNDS")) ctx->check_bounds = e[0] == '1';
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
     if (e == hipSuccess) {
         uint32_t z[64] = {};

@@ -108,6 +108,9 @@ size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t
  *                   under-reported bound is memory-safe but SILENTLY truncates longer subjects at the bound (their
  *                   scores are then those of the truncated subject).  Pass the true maximum (the reference passes the
  *                   partition's boundary, cudasw4.cuh:1767-1912); over-reporting only costs scratch.
+ *                   Debugging a binding: with CUDASW4_AMD_CHECK_BOUNDS=1 in the environment of sw_ctx_create every scan
+ *                   and re-score first finds the longest subject of its range on the device (one small kernel and a
+ *                   stream synchronisation) and returns SW_ERR_INVALID when the bound under-reports it.
  *   gop, gex        gap open / extend scores, both <= 0 (reference: -11 / -1)
  *   scores, ids     DEVICE, indexed by position: scores[pos] = score, ids[pos] = id_offset + pos
  *   ovf_pos/count   DEVICE; when ovf_check != 0 a subject whose packed score reaches the kind's

@@ -241,6 +241,47 @@ def test_temp_sizing_and_too_small_temp():
         assert ids.cpu().numpy().tolist() == list(range(n))
 
 
+def test_debug_check_of_the_max_subject_len_contract(monkeypatch):
+    """include/cudasw4_amd.h: an under-reported max_subject_len silently truncates; with CUDASW4_AMD_CHECK_BOUNDS=1 the
+    library finds the longest subject of the range (and of an overflow list) on the device and refuses the call."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(3)
+    seqs = [rng.integers(0, 20, int(l)).astype(np.int8) for l in (30, 90, 200, 301)]
+    chars, offsets, lengths = O.make_db(seqs)
+    db = search.DeviceDB.from_arrays(chars, offsets, lengths, device=0)
+    q = rng.integers(0, 20, 900).astype(np.int8)
+    n = len(seqs)
+    scores = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+    ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+    temp = torch.empty(1 << 22, dtype=torch.uint8, device="cuda")
+    pos = torch.tensor([3, 0], dtype=torch.int32, device="cuda")
+    cnt = torch.tensor([2], dtype=torch.int32, device="cuda")
+    expect = O.scan(q, chars, offsets, lengths)
+    monkeypatch.setenv("CUDASW4_AMD_CHECK_BOUNDS", "1")
+    ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    ctx.set_query(q)
+
+    def scan(first, cnt_n, maxlen):
+        ctx.scan_partition(capi.KIND_F32, 5, db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(), first, cnt_n, maxlen,
+                           -11, -1, scores.data_ptr(), ids.data_ptr(), 0, 0, 0, 0, temp.data_ptr(), temp.numel(), 0)
+
+    def rescore(maxlen):
+        ctx.rescore_overflow(capi.KIND_F32, pos.data_ptr(), cnt.data_ptr(), 2, db.chars.data_ptr(), db.offsets.data_ptr(),
+                             db.lengths.data_ptr(), maxlen, -11, -1, scores.data_ptr(), ids.data_ptr(), 0, temp.data_ptr(), temp.numel(), 0)
+
+    for call in (lambda: scan(0, n, 300), lambda: scan(2, 2, 256), lambda: rescore(300)):
+        with pytest.raises(capi.SwError) as ei:
+            call()
+        assert ei.value.code == -1 and "under-reports" in str(ei.value) and "301" in str(ei.value)
+    scan(0, 2, 90)       # the bound of THIS range, not of the DB
+    scan(0, n, 301)
+    rescore(301)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect)
+    ctx.close()
+
+
 def test_group_shapes_agree_on_long_subjects():
     """Partitions 34/35 run with wave-wide (64-lane) groups when they hold few subjects and with 16-lane
     groups when they hold many: both shapes must give the oracle's scores."""
