@@ -1,4 +1,5 @@
 #include "db_format.hpp"
+#include "parallel_blocks.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -6,6 +7,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <fstream>
 #include <limits>
@@ -197,15 +199,15 @@ void Database::finish() {
 void Database::validate_codes() const {
     const size_t total = num_chars();
     const int8_t* c = chars_;
-    bool bad = false;
-#pragma omp parallel for schedule(static) reduction(|| : bad)
-    for (long blk = 0; blk < long((total + (1u << 20) - 1) >> 20); blk++) {
-        const size_t b = size_t(blk) << 20, e = std::min(total, b + (size_t(1) << 20));
+    std::atomic<bool> bad{false};
+    // threads that exit with the loop, not OpenMP workers that spin afterwards (parallel_blocks.hpp)
+    parallel_blocks((total + (size_t(1) << 22) - 1) >> 22, 16, [&](size_t blk) {
+        const size_t b = blk << 22, e = std::min(total, b + (size_t(1) << 22));
         unsigned char m = 0;
         for (size_t i = b; i < e; i++) m |= (unsigned char)(c[i]) > 20 ? 1 : 0;
-        bad = bad || m;
-    }
-    if (bad) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
+        if (m) bad.store(true, std::memory_order_relaxed);
+    });
+    if (bad.load()) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
 }
 
 std::shared_ptr<Database> Database::open(const std::string& prefix, bool prefetch) {

@@ -1,4 +1,5 @@
 #include "search_driver.hpp"
+#include "parallel_blocks.hpp"
 
 #include <hip/hip_runtime_api.h>
 
@@ -564,15 +565,14 @@ void SearchDriver::scanStreamed(Gpu& g) {
             if (dbRegistered_) {
                 HIPCHECK(hipMemcpyAsync(dst + pos, src, bytes, hipMemcpyHostToDevice, g.copyStream));
             } else {
-                // page cache / mmap -> pinned staging, in parallel chunks (one thread moves ~6 GB/s only)
+                // page cache / mmap -> pinned staging, in parallel chunks (one thread moves ~6 GB/s only); plain threads
+                // that end with the copy, not OpenMP workers that would spin next to the scan (parallel_blocks.hpp)
                 const size_t chunk = size_t(4) << 20;
-                const long nchunks = long((bytes + chunk - 1) / chunk);
                 int8_t* hdst = g.h_pinned[slot] + pos;
-#pragma omp parallel for schedule(static) num_threads(8)
-                for (long c = 0; c < nchunks; c++) {
-                    const size_t o = size_t(c) * chunk;
+                parallel_blocks((bytes + chunk - 1) / chunk, 8, [&](size_t c) {
+                    const size_t o = c * chunk;
                     std::memcpy(hdst + o, src + o, std::min(chunk, size_t(bytes) - o));
-                }
+                });
             }
             pos += bytes;
         }
