@@ -381,3 +381,14 @@ def test_vector_loader_fallback_when_the_files_cannot_be_mapped(tmp_path, golden
     bad = subprocess.run([dbinspect, str(tmp_path / "nope")], capture_output=True, text=True,
                          env=dict(os.environ, CUDASW4_AMD_DB_NO_MMAP="1"))
     assert bad.returncode == 1 and "Cannot open DB" in bad.stderr
+
+
+def test_parallel_blocks_helper(tmp_path):
+    """host/parallel_blocks.hpp (the fork-join helper that replaced OpenMP in the host library): every block exactly once
+    for any block / thread count, exceptions propagate to the caller."""
+    exe = str(tmp_path / "pb_test")
+    src = os.path.join(ROOT, "tests", "host", "parallel_blocks_test.cpp")
+    inc = os.path.join(ROOT, "cudasw4_amd", "csrc", "host")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I", inc, src, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
