@@ -35,7 +35,7 @@ def random_lengths(rng, n):
     elif mode == 3:
         l = np.concatenate([rng.integers(100, 1280, n - 3), rng.integers(8001, 12000, 3)])
     else:
-        l = np.full(n, int(rng.integers(1, 900)))
+        l = np.maximum(1, np.full(n, int(rng.integers(1, 900))) - rng.integers(0, 2) * rng.integers(0, 8, n))  # equal or nearly equal
     return np.sort(l).astype(np.int32)
 
 
