@@ -89,7 +89,10 @@ struct SearchDriver::Gpu {
     int index = 0;   // position in gpus_
     int device = 0;
     sw_ctx* ctx = nullptr;
-    hipStream_t stream = nullptr, copyStream = nullptr;
+    // stream: the work stream (resident scans, every other batch of a streamed scan, top-K, copy-back); stream2: the
+    // batches in between, so that the first workgroups of a batch fill the CUs the last round of the batch before
+    // leaves idle
+    hipStream_t stream = nullptr, stream2 = nullptr, copyStream = nullptr;
     std::array<ShardRange, kNumLengthPartitions> ranges{};
     std::array<size_t, kNumLengthPartitions + 1> localBegin{};
     size_t numLocal = 0;
@@ -103,29 +106,42 @@ struct SearchDriver::Gpu {
     int32_t* d_lengths = nullptr;
     int8_t* d_chars = nullptr;
     bool resident = false, wantResident = false;
-    // streaming: two device staging buffers fed from the (registered) DB mapping, or through pinned host buffers
+    // streaming: three device staging buffers fed from the (registered) DB mapping, or through pinned host buffers
     std::vector<Batch> batches;
-    int8_t* d_staging[2] = {nullptr, nullptr};
+    // Two batches compute at a time (one per work stream) while a third is being copied in: three buffers
+    static constexpr int kSlots = 3;
+    int8_t* d_staging[kSlots] = {nullptr, nullptr, nullptr};
     size_t stagingCap = 0;
-    int8_t* h_pinned[2] = {nullptr, nullptr};
+    int8_t* h_pinned[kSlots] = {nullptr, nullptr, nullptr};
     size_t pinnedCap = 0;
-    hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
+    hipEvent_t copied[kSlots] = {nullptr, nullptr, nullptr}, scanned[kSlots] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> batchEv;  // 2 per batch of the last streamed scan (intervals for tests / tuning)
     hipEvent_t scanStartEv = nullptr;
-    int32_t* h_ovfBatch = nullptr;    // pinned: overflow count of every batch of the current query
+    int32_t* h_ovfBatch = nullptr;    // pinned: copy of d_ovfCount after the scan
     size_t ovfBatchCap = 0;
     float* d_scores = nullptr;
     int32_t* d_ids = nullptr;
     int32_t* d_ovfPos = nullptr;
-    int32_t* d_ovfCount = nullptr;   // kOvfLists counters: every packed run of a batch has its own overflow list
+    // [0]: subjects whose exact score reached the packed limit (the reference's statistic); [1 + k * kOvfLists + i]:
+    // length of overflow list i of batch k — every packed run of a batch has its own list, and the lists of one scan
+    // never share a counter, because the long-subject runs of a batch keep running next to the following batches
+    int32_t* d_ovfCount = nullptr;
+    size_t ovfCountCap = 0;
     static constexpr int kOvfLists = 4;
     // Launches that run concurrently need their own stripe-border scratch: slot 0 = work stream,
     // slots 1.. = auxiliary streams (the reference round-robins 10 work streams, cudasw4.cuh:293,1745-1748)
     static constexpr int kAux = 2;
     hipStream_t aux[kAux] = {nullptr, nullptr};
-    hipEvent_t forkEvent = nullptr, joinEvent[kAux] = {nullptr, nullptr};
-    void* d_temp[kAux + 1] = {nullptr, nullptr, nullptr};
-    size_t tempBytes[kAux + 1] = {0, 0, 0};
+    hipEvent_t forkEvent[2] = {nullptr, nullptr}, joinEvent[kAux] = {nullptr, nullptr}, join2Event = nullptr;
+    // the auxiliary launches of a streamed batch read the batch's staging buffer: recorded after the last of them on each
+    // auxiliary stream, waited for before the buffer is overwritten
+    hipEvent_t auxDone[kSlots][kAux] = {};
+    bool auxPending[kSlots][kAux] = {};
+    bool auxUsed[kAux] = {false, false};  // this scan put work on the stream: joined before the top-K
+    bool stream2Used = false;
+    bool twoWorkStreams = true;   // CUDASW4_AMD_ONE_WORK_STREAM=1: every batch of a streamed scan on the work stream (A/B measurements)
+    void* d_temp[kAux + 2] = {nullptr, nullptr, nullptr, nullptr};  // work stream, auxiliary streams, stream2
+    size_t tempBytes[kAux + 2] = {0, 0, 0, 0};
     void* d_topkTemp = nullptr;
     size_t topkTempBytes = 0;
     float* d_topS = nullptr;
@@ -136,7 +152,6 @@ struct SearchDriver::Gpu {
     int lastTop = 0;
     int lastOverflows = 0;      // subjects of the last query whose exact score reached the packed kind's limit (the reference's statistic)
     int lastRescored = 0;       // subjects the packed launches flagged and the 32-bit kind re-scored (>= lastOverflows)
-    int32_t* h_trueOvf = nullptr;  // pinned
     int32_t qlen = 0;
     double spanBegin = 0, spanEnd = 0;  // host clock, seconds since the scan started
     std::vector<TimedLaunch> timed;     // launches recorded since the last takeKernelEvents
@@ -213,7 +228,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), matrix_.dim));
         HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
-        HIPCHECK(hipEventCreateWithFlags(&g->forkEvent, hipEventDisableTiming));
+        for (auto& e : g->forkEvent) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&g->join2Event, hipEventDisableTiming));
         HIPCHECK(hipEventCreate(&g->scanStartEv));
         // The auxiliary streams carry the few long subjects that must overlap the bulk launch.  The runtime multiplexes
         // streams of one priority onto GPU_MAX_HW_QUEUES (4) hardware queues, and two streams that share a queue
@@ -226,12 +242,14 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             HIPCHECK(hipStreamCreateWithPriority(&g->aux[i], hipStreamNonBlocking, prioHigh));
             HIPCHECK(hipEventCreateWithFlags(&g->joinEvent[i], hipEventDisableTiming));
         }
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < Gpu::kSlots; i++) {
             HIPCHECK(hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&g->scanned[i], hipEventDisableTiming));
+            for (int a = 0; a < Gpu::kAux; a++) HIPCHECK(hipEventCreateWithFlags(&g->auxDone[i][a], hipEventDisableTiming));
         }
-        HIPCHECK(hipMalloc(&g->d_ovfCount, (Gpu::kOvfLists + 1) * sizeof(int32_t)));
-        HIPCHECK(hipHostMalloc(&g->h_trueOvf, sizeof(int32_t)));
+        if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
+        g->ovfCountCap = 1 + Gpu::kOvfLists;
+        HIPCHECK(hipMalloc(&g->d_ovfCount, g->ovfCountCap * sizeof(int32_t)));
         gpus_.push_back(std::move(g));
     }
     if (gpus_.size() > 1)
@@ -245,28 +263,33 @@ SearchDriver::~SearchDriver() {
         (void)hipSetDevice(g.device);
         (void)hipDeviceSynchronize();
         (void)hipFree(g.d_offsets); (void)hipFree(g.d_lengths); (void)hipFree(g.d_chars);
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < Gpu::kSlots; i++) {
             (void)hipFree(g.d_staging[i]);
             (void)hipHostFree(g.h_pinned[i]);
             if (g.copied[i]) (void)hipEventDestroy(g.copied[i]);
             if (g.scanned[i]) (void)hipEventDestroy(g.scanned[i]);
+            for (int a = 0; a < Gpu::kAux; a++)
+                if (g.auxDone[i][a]) (void)hipEventDestroy(g.auxDone[i][a]);
         }
         for (hipEvent_t e : g.batchEv) (void)hipEventDestroy(e);
         if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
         for (auto* v : {&g.timed, &g.freeTimed})
             for (TimedLaunch& t : *v) { (void)hipEventDestroy(t.ev0); (void)hipEventDestroy(t.ev1); }
-        (void)hipHostFree(g.h_ovfBatch); (void)hipHostFree(g.h_trueOvf);
+        (void)hipHostFree(g.h_ovfBatch);
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos); (void)hipFree(g.d_ovfCount);
-        for (int i = 0; i <= Gpu::kAux; i++) (void)hipFree(g.d_temp[i]);
+        for (void* t : g.d_temp) (void)hipFree(t);
         for (int i = 0; i < Gpu::kAux; i++) {
             if (g.aux[i]) (void)hipStreamDestroy(g.aux[i]);
             if (g.joinEvent[i]) (void)hipEventDestroy(g.joinEvent[i]);
         }
-        if (g.forkEvent) (void)hipEventDestroy(g.forkEvent);
+        for (hipEvent_t e : g.forkEvent)
+            if (e) (void)hipEventDestroy(e);
+        if (g.join2Event) (void)hipEventDestroy(g.join2Event);
         (void)hipFree(g.d_topkTemp); (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
         (void)hipHostFree(g.h_topS); (void)hipHostFree(g.h_topI);
         if (g.stream) (void)hipStreamDestroy(g.stream);
         if (g.copyStream) (void)hipStreamDestroy(g.copyStream);
+        if (g.stream2) (void)hipStreamDestroy(g.stream2);
         if (g.ctx) sw_ctx_destroy(g.ctx);
     }
     if (db_ && dbRegistered_) (void)hipHostUnregister(const_cast<int8_t*>(db_->chars()));
@@ -424,35 +447,47 @@ void* ensure_temp(void*& ptr, size_t& have, size_t need, size_t cap) {
 
 }  // namespace
 
-// Enqueue the scan of the shard-local subjects [lbegin, lend) whose chars start at `chars` (device).  The run
-// with the most subjects goes to the work stream; the others (few long subjects) are launched FIRST on auxiliary
-// streams so that they hold their handful of workgroups while the bulk run fills the rest of the GPU.
+// Enqueue the scan of the shard-local subjects [lbegin, lend) whose chars start at `chars` (device) as batch `batch` of
+// the current query, staged in buffer `slot` (-1: resident chars).  The run with the most subjects goes to the work stream
+// together with its re-score; the others (few long subjects) are launched on the auxiliary streams, re-scored there, and
+// NOT joined at the end of the batch: a giant subject of a Swiss-Prot-like DB keeps one wave busy for as long as the whole
+// batch takes (61 ms for a 5478-residue query), and joining it per batch put that time in front of every following batch
+// (streamed Swiss-Prot-like DB: 133 instead of 107 ms for that query).  scanOnGpu joins the auxiliary streams before the
+// top-K; a staging buffer is overwritten only after the auxiliary launches that read it (auxDone).
 template <class GpuT>
 static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t lend, const Database& db,
-                          const KernelTypeConfig& kt, const MemoryConfig& mem, int gop, int gex, int recordMode) {
+                          const KernelTypeConfig& kt, const MemoryConfig& mem, int gop, int gex, int recordMode,
+                          size_t batch, int slot, bool second) {
+    // every other batch of a streamed scan runs on stream2 with a scratch of its own (see Gpu::stream2)
+    const hipStream_t work = second ? g.stream2 : g.stream;
+    const int workTemp = second ? GpuT::kAux + 1 : 0;
+    const hipEvent_t fork = g.forkEvent[second ? 1 : 0];
     const auto runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, lend,
                                        [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); });
     const uint64_t* offsets = g.d_offsets + lbegin;
     const int32_t* lengths = g.d_lengths + lbegin;
-    // Every packed run keeps its own overflow list (its slice of d_ovfPos) and counter, and is re-scored by a launch
-    // of its own: the group shape of a re-score follows the run's longest subject (16-lane groups for the bulk of the
-    // DB, the wave-wide shape only for the list of partition 34), not the longest subject of the whole batch.
-    HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, GpuT::kOvfLists * sizeof(int32_t), g.stream));
+    // Every packed run keeps its own overflow list (the slice of d_ovfPos at its first subject) and counter, and is
+    // re-scored by a launch of its own: the group shape of a re-score follows the run's longest subject (16-lane groups for
+    // the bulk of the DB, the wave-wide shape only for the list of partition 34), not the longest subject of the batch.
+    int32_t* const counters = g.d_ovfCount + 1 + batch * GpuT::kOvfLists;  // zeroed at the start of the scan
     size_t mainIdx = 0;
     for (size_t i = 1; i < runs.size(); i++)
         if (runs[i].end - runs[i].begin > runs[mainIdx].end - runs[mainIdx].begin) mainIdx = i;
-    if (runs.size() > 1) HIPCHECK(hipEventRecord(g.forkEvent, g.stream));
+    if (runs.size() > 1) HIPCHECK(hipEventRecord(fork, work));
     std::vector<int> ovfList(runs.size(), -1);
     int numLists = 0;
     for (size_t i = 0; i < runs.size(); i++)
         if (is_packed(runs[i].kind)) ovfList[i] = std::min(numLists++, GpuT::kOvfLists - 1);
-    auto launch = [&](size_t ri, hipStream_t stream, int slot) {
+    // with more packed runs than lists (never with the reference's partitions: at most three runs per batch) the last
+    // list is shared, which is only safe on one stream
+    const bool shareLast = numLists > GpuT::kOvfLists;
+    auto launch = [&](size_t ri, hipStream_t stream, int tslot) {
         const LaunchRun& r = runs[ri];
         const int32_t n = int32_t(r.end - r.begin);
         const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, r.maxlen);
-        void* temp = ensure_temp(g.d_temp[slot], g.tempBytes[slot], need, mem.maxTempBytes);
+        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, mem.maxTempBytes);
         TimedLaunch t;
-        const bool record = recordMode == 1 || (recordMode == 2 && slot == 0);
+        const bool record = recordMode == 1 || (recordMode == 2 && tslot == workTemp);
         if (record) {
             if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
             else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
@@ -462,39 +497,67 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         const bool packed = ovfList[ri] >= 0;
         SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, chars, offsets, lengths, int32_t(r.begin - lbegin), n,
                                   r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin),
-                                  packed ? g.d_ovfPos + (r.begin - lbegin) : nullptr, packed ? g.d_ovfCount + ovfList[ri] : nullptr,
-                                  packed ? 1 : 0, temp, g.tempBytes[slot], stream));
+                                  packed ? g.d_ovfPos + r.begin : nullptr, packed ? counters + ovfList[ri] : nullptr,
+                                  packed ? 1 : 0, temp, g.tempBytes[tslot], stream));
         if (record) {
             HIPCHECK(hipEventRecord(t.ev1, stream));
             g.timed.push_back(t);
         }
     };
-    int auxUsed = 0;
-    bool auxBusy[GpuT::kAux] = {};
-    for (size_t i = 0; i < runs.size(); i++) {
-        if (i == mainIdx) continue;
-        const int a = auxUsed++ % GpuT::kAux;
-        if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], g.forkEvent, 0));
-        auxBusy[a] = true;
-        launch(i, g.aux[a], a + 1);
-    }
-    if (!runs.empty()) launch(mainIdx, g.stream, 0);
-    for (int a = 0; a < GpuT::kAux; a++) {
-        if (!auxBusy[a]) continue;
-        HIPCHECK(hipEventRecord(g.joinEvent[a], g.aux[a]));
-        HIPCHECK(hipStreamWaitEvent(g.stream, g.joinEvent[a], 0));
-    }
-    for (size_t i = 0; i < runs.size(); i++) {  // cudasw4.cuh:2134-2169
-        if (ovfList[i] < 0) continue;
-        const LaunchRun& r = runs[i];
+    auto rescore = [&](size_t ri, hipStream_t stream, int tslot) {  // cudasw4.cuh:2134-2169
+        if (ovfList[ri] < 0) return;
+        const LaunchRun& r = runs[ri];
         const int32_t n = int32_t(r.end - r.begin);
         const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, n, r.maxlen);
-        void* temp = ensure_temp(g.d_temp[0], g.tempBytes[0], need, mem.maxTempBytes);
-        SWCHECK(sw_rescore_overflow_stat(g.ctx, int(kt.overflowType), g.d_ovfPos + (r.begin - lbegin), g.d_ovfCount + ovfList[i], n,
+        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, mem.maxTempBytes);
+        SWCHECK(sw_rescore_overflow_stat(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[ri], n,
                                          chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
-                                         int64_t(lbegin), temp, g.tempBytes[0],
+                                         int64_t(lbegin), temp, g.tempBytes[tslot],
                                          r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16,
-                                         g.d_ovfCount + GpuT::kOvfLists, g.stream));
+                                         g.d_ovfCount, stream));
+    };
+    int auxNext = 0;
+    bool auxBusy[GpuT::kAux] = {};
+    std::vector<int> streamOf(runs.size(), -1);  // auxiliary stream of a run, -1: work stream
+    for (size_t i = 0; i < runs.size(); i++) {
+        if (i == mainIdx || (shareLast && ovfList[i] == GpuT::kOvfLists - 1)) continue;
+        const int a = auxNext++ % GpuT::kAux;
+        if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], fork, 0));
+        auxBusy[a] = true;
+        streamOf[i] = a;
+        launch(i, g.aux[a], a + 1);
+    }
+    for (size_t i = 0; i < runs.size(); i++)
+        if (streamOf[i] < 0) launch(i, work, workTemp);
+    for (size_t i = 0; i < runs.size(); i++) {
+        if (streamOf[i] >= 0) rescore(i, g.aux[streamOf[i]], streamOf[i] + 1);
+        else rescore(i, work, workTemp);
+    }
+    for (int a = 0; a < GpuT::kAux; a++) {
+        if (!auxBusy[a]) continue;
+        g.auxUsed[a] = true;
+        if (slot >= 0) {
+            HIPCHECK(hipEventRecord(g.auxDone[slot][a], g.aux[a]));
+            g.auxPending[slot][a] = true;
+        }
+    }
+}
+
+// the work stream continues only after everything the auxiliary streams were given in this scan
+template <class GpuT>
+static void join_aux(GpuT& g) {
+    for (int a = 0; a < GpuT::kAux; a++) {
+        if (!g.auxUsed[a]) continue;
+        HIPCHECK(hipEventRecord(g.joinEvent[a], g.aux[a]));
+        HIPCHECK(hipStreamWaitEvent(g.stream, g.joinEvent[a], 0));
+        g.auxUsed[a] = false;
+    }
+    for (auto& slot : g.auxPending)
+        for (bool& pending : slot) pending = false;
+    if (g.stream2Used) {
+        HIPCHECK(hipEventRecord(g.join2Event, g.stream2));
+        HIPCHECK(hipStreamWaitEvent(g.stream, g.join2Event, 0));
+        g.stream2Used = false;
     }
 }
 
@@ -507,23 +570,21 @@ static void ensure_ovf_slots(int32_t*& h, size_t& cap, size_t need) {
 }
 
 void SearchDriver::scanResident(Gpu& g) {
-    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, Gpu::kOvfLists);
-    enqueue_batch(g, g.d_chars, 0, g.numLocal, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
-    // per-query total (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
-    HIPCHECK(hipMemcpyAsync(g.h_ovfBatch, g.d_ovfCount, Gpu::kOvfLists * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+    enqueue_batch(g, g.d_chars, 0, g.numLocal, *db_, kernels_, memory_, gop_, gex_, recordEvents_, 0, -1, false);
 }
 
-// DB shard larger than the memory limit: its chars stream through two device staging buffers (copy stream ->
-// work stream), cf. cudasw4.cuh:1560-1712; offsets and lengths are resident.  Batches run longest subjects first,
-// so the tail of the query consists of short subjects.  With the DB mapping registered the whole scan is enqueued
-// without blocking the host; the pinned fallback blocks only on its own two host buffers.
+// DB shard larger than the memory limit: its chars stream through three device staging buffers (copy stream -> the two
+// work streams in turn: two batches compute while the third is copied in), cf. cudasw4.cuh:1560-1712; offsets and
+// lengths are resident.  Batches run longest subjects first, so the tail of the query consists of short subjects.  With
+// the DB mapping registered the whole scan is enqueued without blocking the host; the pinned fallback blocks only on its
+// own host buffers.
 void SearchDriver::scanStreamed(Gpu& g) {
     const uint64_t* off = db_->offsets();
     const size_t nb = g.batches.size();
     uint64_t maxBytes = 0;
     for (const Batch& b : g.batches) maxBytes = std::max(maxBytes, b.bytes);
     if (maxBytes + 64 > g.stagingCap) {
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < Gpu::kSlots; i++) {
             (void)hipFree(g.d_staging[i]);
             g.d_staging[i] = nullptr;
             HIPCHECK(hipMalloc(&g.d_staging[i], maxBytes + 64));
@@ -531,28 +592,32 @@ void SearchDriver::scanStreamed(Gpu& g) {
         g.stagingCap = maxBytes + 64;
     }
     if (!dbRegistered_ && maxBytes + 64 > g.pinnedCap) {
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < Gpu::kSlots; i++) {
             (void)hipHostFree(g.h_pinned[i]);
             g.h_pinned[i] = nullptr;
             HIPCHECK(hipHostMalloc(&g.h_pinned[i], maxBytes + 64));
         }
         g.pinnedCap = maxBytes + 64;
     }
-    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, nb * Gpu::kOvfLists);
     while (g.batchEv.size() < 2 * nb) {
         hipEvent_t e;
         HIPCHECK(hipEventCreate(&e));
         g.batchEv.push_back(e);
     }
     HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
-    bool slotUsed[2] = {false, false};
-    int slot = 0;
+    bool slotUsed[Gpu::kSlots] = {};
     for (size_t k = 0; k < nb; k++) {
         const size_t bi = nb - 1 - k;
         const Batch& b = g.batches[bi];
+        const int slot = int(k % Gpu::kSlots);
         int8_t* dst = g.d_staging[slot];
         // the scan that last used this device buffer must have finished before the copy overwrites it
         if (slotUsed[slot]) HIPCHECK(hipStreamWaitEvent(g.copyStream, g.scanned[slot], 0));
+        for (int a = 0; a < Gpu::kAux; a++) {
+            if (!g.auxPending[slot][a]) continue;
+            HIPCHECK(hipStreamWaitEvent(g.copyStream, g.auxDone[slot][a], 0));
+            g.auxPending[slot][a] = false;
+        }
         if (!dbRegistered_ && slotUsed[slot]) HIPCHECK(hipEventSynchronize(g.copied[slot]));  // pinned buffer free again
         // the batch's pieces: one contiguous slice of the chars file per length partition it touches
         uint64_t pos = 0;
@@ -579,14 +644,24 @@ void SearchDriver::scanStreamed(Gpu& g) {
         if (!dbRegistered_) HIPCHECK(hipMemcpyAsync(dst, g.h_pinned[slot], b.bytes, hipMemcpyHostToDevice, g.copyStream));
         HIPCHECK(hipMemsetAsync(dst + b.bytes, kOtherCode, 64, g.copyStream));
         HIPCHECK(hipEventRecord(g.copied[slot], g.copyStream));
-        HIPCHECK(hipStreamWaitEvent(g.stream, g.copied[slot], 0));
-        HIPCHECK(hipEventRecord(g.batchEv[2 * k], g.stream));
-        enqueue_batch(g, dst, b.lbegin, b.lend, *db_, kernels_, memory_, gop_, gex_, recordEvents_);
-        HIPCHECK(hipMemcpyAsync(g.h_ovfBatch + k * Gpu::kOvfLists, g.d_ovfCount, Gpu::kOvfLists * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
-        HIPCHECK(hipEventRecord(g.batchEv[2 * k + 1], g.stream));
-        HIPCHECK(hipEventRecord(g.scanned[slot], g.stream));
+        // created with the first streamed scan that needs it: a driver whose shards are resident keeps the set of
+        // streams it was tuned with (one more stream of the work stream's priority changes which streams end up sharing a
+        // hardware queue: the giants' launch of a RESIDENT Swiss-Prot-like DB went back in front of the bulk launch, 138
+        // instead of 107 ms for the longest query, when stream2 was created in the constructor)
+        const bool second = (k & 1) && g.twoWorkStreams;
+        if (second && !g.stream2) HIPCHECK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+        const hipStream_t work = second ? g.stream2 : g.stream;
+        if (second && !g.stream2Used) {
+            // ordered after the query upload and the zeroed counters on the work stream
+            HIPCHECK(hipStreamWaitEvent(g.stream2, g.scanStartEv, 0));
+            g.stream2Used = true;
+        }
+        HIPCHECK(hipStreamWaitEvent(work, g.copied[slot], 0));
+        HIPCHECK(hipEventRecord(g.batchEv[2 * k], work));
+        enqueue_batch(g, dst, b.lbegin, b.lend, *db_, kernels_, memory_, gop_, gex_, recordEvents_, k, slot, second);
+        HIPCHECK(hipEventRecord(g.batchEv[2 * k + 1], work));
+        HIPCHECK(hipEventRecord(g.scanned[slot], work));
         slotUsed[slot] = true;
-        slot ^= 1;
     }
 }
 
@@ -602,10 +677,20 @@ void SearchDriver::scanOnGpu(Gpu& g, int32_t queryLength, int k) {
     if (g.wantResident && !g.resident) uploadShard(g);  // the first query pays the upload unless --uploadFull
     SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
     // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
-    HIPCHECK(hipMemsetAsync(g.d_ovfCount + Gpu::kOvfLists, 0, sizeof(int32_t), g.stream));
-    size_t nbatches = 1;
+    const size_t nbatches = g.resident ? 1 : g.batches.size();
+    const size_t ncounters = 1 + nbatches * Gpu::kOvfLists;
+    if (ncounters > g.ovfCountCap) {
+        (void)hipFree(g.d_ovfCount);
+        g.d_ovfCount = nullptr;
+        g.ovfCountCap = 0;
+        HIPCHECK(hipMalloc(&g.d_ovfCount, ncounters * sizeof(int32_t)));
+        g.ovfCountCap = ncounters;
+    }
+    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, ncounters);
+    HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, ncounters * sizeof(int32_t), g.stream));
     if (g.resident) scanResident(g);
-    else { scanStreamed(g); nbatches = g.batches.size(); }
+    else scanStreamed(g);
+    join_aux(g);
     const int kk = int(std::min<size_t>(size_t(std::max(k, 0)), g.numLocal));
     if (kk > 0) {
         if (kk > g.topCapacity) {
@@ -629,10 +714,11 @@ void SearchDriver::scanOnGpu(Gpu& g, int32_t queryLength, int k) {
         HIPCHECK(hipMemcpyAsync(g.h_topI, g.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
         g.lastTop = kk;
     }
-    HIPCHECK(hipMemcpyAsync(g.h_trueOvf, g.d_ovfCount + Gpu::kOvfLists, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+    // per-query totals (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
+    HIPCHECK(hipMemcpyAsync(g.h_ovfBatch, g.d_ovfCount, ncounters * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
     HIPCHECK(hipStreamSynchronize(g.stream));
-    for (size_t i = 0; i < nbatches * Gpu::kOvfLists; i++) g.lastRescored += g.h_ovfBatch[i];
-    g.lastOverflows = *g.h_trueOvf;
+    for (size_t i = 1; i < ncounters; i++) g.lastRescored += g.h_ovfBatch[i];
+    g.lastOverflows = g.h_ovfBatch[0];
     g.spanEnd = now_seconds() - scanT0_;
 }
 
