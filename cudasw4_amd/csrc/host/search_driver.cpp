@@ -139,6 +139,10 @@ struct SearchDriver::Gpu {
     bool auxPending[kSlots][kAux] = {};
     bool auxUsed[kAux] = {false, false};  // this scan put work on the stream: joined before the top-K
     bool stream2Used = false;
+    bool firstBatchStaged = false;  // staging buffer slotBase already holds the first batch of the next streamed scan
+    size_t slotBase = 0;            // staging buffer of the first batch of the next streamed scan
+    bool slotUsed[kSlots] = {};     // the buffer has been scanned from since the DB was set: scanned[] is valid
+    bool prefetchNext = true;       // CUDASW4_AMD_NO_NEXT_PREFETCH=1 turns that off (A/B measurements)
     bool twoWorkStreams = true;   // CUDASW4_AMD_ONE_WORK_STREAM=1: every batch of a streamed scan on the work stream (A/B measurements)
     void* d_temp[kAux + 2] = {nullptr, nullptr, nullptr, nullptr};  // work stream, auxiliary streams, stream2
     size_t tempBytes[kAux + 2] = {0, 0, 0, 0};
@@ -248,6 +252,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             for (int a = 0; a < Gpu::kAux; a++) HIPCHECK(hipEventCreateWithFlags(&g->auxDone[i][a], hipEventDisableTiming));
         }
         if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
+        if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
         g->ovfCountCap = 1 + Gpu::kOvfLists;
         HIPCHECK(hipMalloc(&g->d_ovfCount, g->ovfCountCap * sizeof(int32_t)));
         gpus_.push_back(std::move(g));
@@ -303,6 +308,15 @@ void SearchDriver::setShard(int rank, int world, int64_t idBase) {
 }
 
 void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
+    for (auto& gp : gpus_) {  // a prefetch of the old DB's first batch may still be in flight
+        gp->use();
+        (void)hipStreamSynchronize(gp->copyStream);
+        gp->firstBatchStaged = false;
+        (void)hipStreamSynchronize(gp->stream);
+        if (gp->stream2) (void)hipStreamSynchronize(gp->stream2);
+        for (bool& u : gp->slotUsed) u = false;
+        gp->slotBase = 0;
+    }
     if (db_ && dbRegistered_) { (void)hipHostUnregister(const_cast<int8_t*>(db_->chars())); dbRegistered_ = false; }
     db_ = std::move(db);
     if (db_->num_sequences() > size_t(INT32_MAX) - 1) throw std::runtime_error("Too many sequences in DB");
@@ -605,11 +619,15 @@ void SearchDriver::scanStreamed(Gpu& g) {
         g.batchEv.push_back(e);
     }
     HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
-    bool slotUsed[Gpu::kSlots] = {};
-    for (size_t k = 0; k < nb; k++) {
-        const size_t bi = nb - 1 - k;
-        const Batch& b = g.batches[bi];
-        const int slot = int(k % Gpu::kSlots);
+    // The buffers rotate across scans (slotBase): the first batch of the next scan then gets the buffer whose last user
+    // finishes earliest, two batches before the end of this scan.
+    bool* const slotUsed = g.slotUsed;
+    auto slot_of = [&](size_t k) { return int((g.slotBase + k) % Gpu::kSlots); };
+    // copy of batch k of the scan order (longest subjects first; k == nb: the first batch again, for the next scan) into
+    // its staging buffer, on the copy stream
+    auto copy_batch = [&](size_t k) {
+        const Batch& b = g.batches[nb - 1 - (k % nb)];
+        const int slot = slot_of(k);
         int8_t* dst = g.d_staging[slot];
         // the scan that last used this device buffer must have finished before the copy overwrites it
         if (slotUsed[slot]) HIPCHECK(hipStreamWaitEvent(g.copyStream, g.scanned[slot], 0));
@@ -644,6 +662,14 @@ void SearchDriver::scanStreamed(Gpu& g) {
         if (!dbRegistered_) HIPCHECK(hipMemcpyAsync(dst, g.h_pinned[slot], b.bytes, hipMemcpyHostToDevice, g.copyStream));
         HIPCHECK(hipMemsetAsync(dst + b.bytes, kOtherCode, 64, g.copyStream));
         HIPCHECK(hipEventRecord(g.copied[slot], g.copyStream));
+    };
+    for (size_t k = 0; k < nb; k++) {
+        const Batch& b = g.batches[nb - 1 - k];
+        const int slot = slot_of(k);
+        int8_t* dst = g.d_staging[slot];
+        // the first batch may already be there: the previous scan copied it in behind its own last batches (below)
+        if (k == 0 && g.firstBatchStaged) g.firstBatchStaged = false;
+        else copy_batch(k);
         // created with the first streamed scan that needs it: a driver whose shards are resident keeps the set of
         // streams it was tuned with (one more stream of the work stream's priority changes which streams end up sharing a
         // hardware queue: the giants' launch of a RESIDENT Swiss-Prot-like DB went back in front of the bulk launch, 138
@@ -663,6 +689,15 @@ void SearchDriver::scanStreamed(Gpu& g) {
         HIPCHECK(hipEventRecord(g.scanned[slot], work));
         slotUsed[slot] = true;
     }
+    // The DB does not depend on the query: the first batch of the NEXT scan goes into its buffer as soon as this scan's
+    // last user of that buffer is done, behind this scan's last copies — otherwise every query starts with a copy that
+    // nothing hides (2-4 ms per 128 MB batch; a 144-residue query scans such a batch in 1.7 ms).  Only with the DB mapping
+    // registered (pure DMA; the pinned fallback would block the host here); one batch copy is wasted after the last query.
+    if (dbRegistered_ && nb > 0 && g.prefetchNext) {
+        copy_batch(nb);
+        g.firstBatchStaged = true;
+    }
+    g.slotBase = (g.slotBase + nb) % Gpu::kSlots;
 }
 
 // Everything one GPU does for one query; runs on the GPU's worker thread when there are several GPUs.
