@@ -61,6 +61,39 @@ def test_driver_streamed_batches_and_two_shards_on_one_gpu():
         d.close()
 
 
+def test_streamed_driver_switches_databases_between_scans():
+    """A streamed scan leaves the first batch of the NEXT scan in a staging buffer (the buffers rotate across scans) and
+    keeps long-subject launches running next to the following batches.  One driver, batch counts of 1, 2, 3, 4 and 7
+    (every rotation phase of the three buffers), several scans each, then ANOTHER DB on the same driver: nothing staged
+    for the old DB may be used for the new one.  Every score against the oracle."""
+    from cudasw4_amd import driver
+    rng = np.random.default_rng(77)
+    letters = b"ARNDCQEGHILKMFPSTWYV"
+
+    def make(n, lo, hi, giants):
+        lens = np.sort(np.concatenate([rng.integers(lo, hi, n), np.array(giants, dtype=np.int64)])).astype(np.int64)
+        return O.make_db([rng.integers(0, 20, int(l)).astype(np.int8) for l in lens])
+
+    dbs = [make(300, 20, 400, [1500, 9000]), make(200, 100, 900, [2000]), make(500, 1, 60, [])]
+    queries = [rng.integers(0, 20, ql).astype(np.int8) for ql in (40, 300, 900)]
+    for batch_bytes in (1 << 30, 40000, 26000, 20000, 11000):
+        d = driver.Driver(devices=[0], num_top=5, kinds=(0, 0, 3, 3), max_gpu_mem=1, max_batch_bytes=batch_bytes)
+        for chars, offsets, lengths in dbs + dbs[:1]:
+            d.db_from_arrays(chars, offsets, lengths)
+            assert not d.shard_info(0)["resident"]
+            for q in queries:
+                expect = O.scan(q, chars, offsets, lengths, simd=True)
+                for _ in range(2):
+                    r = d.scan(bytes(letters[c] for c in q))
+                    ids, sc = d.all_scores()
+                    got = np.empty_like(sc)
+                    got[ids] = sc
+                    np.testing.assert_array_equal(got.astype(np.int32), expect, err_msg="batch bytes %d" % batch_bytes)
+                    es, ei = O.topk(expect, 5)
+                    assert r["scores"].tolist() == es.tolist() and r["ids"].tolist() == ei.tolist()
+        d.close()
+
+
 def test_driver_pseudo_db():
     from cudasw4_amd import driver
     g = O.golden("ref_scores.json")
