@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <deque>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -53,28 +54,46 @@ void reportScan(const ProgramOptions& o, const ScanResult& r) {
     else std::cout << "Done.\n";
 }
 
+// All queries of a file (main.cu:217-260).  The file is at hand as a whole, so the next query is submitted before the
+// current one is collected (SearchDriver::submit / collect): its upload, profile build and first launches queue up behind
+// the current query's top-K on the GPU instead of waiting for the host to come back.  Output order and format are the
+// reference's; a query's line is printed when its results are in.
 void processQueryFile(const std::string& file, const ProgramOptions& o, SearchDriver& driver, std::ostream& out, bool interactive) {
     SequenceReader reader(file);
+    struct Pending { int64_t num; std::string header, sequence; };
+    std::deque<Pending> pending;
     int64_t query_num = 0;
     if (!interactive) driver.totalTimerStart();
-    while (reader.next()) {
-        std::cout << "Processing query " << query_num << " ... ";
+    auto finish_oldest = [&]() {
+        const Pending q = std::move(pending.front());
+        pending.pop_front();
+        std::cout << "Processing query " << q.num << " ... ";
         std::cout.flush();
-        const std::string& header = reader.header();
-        const std::string& sequence = reader.sequence();
-        ScanResult r = driver.scan(sequence.data(), int32_t(sequence.size()));
+        ScanResult r = driver.collect();
         reportScan(o, r);
         if (o.numTopOutputs > 0 || interactive) {
             if (o.outputMode == ProgramOptions::OutputMode::Plain) {
-                (interactive ? std::cout : out) << "Query " << query_num << ", header" << header << ", length " << sequence.size()
+                (interactive ? std::cout : out) << "Query " << q.num << ", header" << q.header << ", length " << q.sequence.size()
                                                 << ", num overflows " << r.stats.numOverflows << "\n";
                 printScanResultPlain(out, r, driver);
             } else {
-                printScanResultTSV(out, r, driver, interactive ? -1 : query_num, int64_t(sequence.size()), interactive ? "-" : header);
+                printScanResultTSV(out, r, driver, interactive ? -1 : q.num, int64_t(q.sequence.size()), interactive ? "-" : q.header);
             }
             out.flush();
         }
-        query_num++;
+    };
+    try {
+        while (reader.next()) {
+            pending.push_back(Pending{query_num++, reader.header(), reader.sequence()});
+            driver.submit(pending.back().sequence.data(), int32_t(pending.back().sequence.size()));
+            if (driver.inFlight() >= SearchDriver::kMaxInFlight) finish_oldest();
+        }
+        while (driver.inFlight() > 0) finish_oldest();
+    } catch (...) {
+        while (driver.inFlight() > 0) {  // leave the driver usable (interactive mode goes on after an error)
+            try { (void)driver.collect(); } catch (...) {}
+        }
+        throw;
     }
     if (!interactive) {
         const BenchmarkStats total = driver.totalTimerStop();

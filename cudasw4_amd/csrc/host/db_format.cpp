@@ -196,7 +196,7 @@ void Database::finish() {
 
 // every letter code of the DB is 0..20 (a parallel pass over the chars; for a memory-mapped file it reads the whole file,
 // which loadDB's prefetch does anyway)
-void Database::validate_codes() const {
+void Database::validate_codes() {
     const size_t total = num_chars();
     const int8_t* c = chars_;
     std::atomic<bool> bad{false};
@@ -208,6 +208,7 @@ void Database::validate_codes() const {
         if (m) bad.store(true, std::memory_order_relaxed);
     });
     if (bad.load()) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
+    codes_validated_ = true;
 }
 
 std::shared_ptr<Database> Database::open(const std::string& prefix, bool prefetch) {
@@ -238,7 +239,9 @@ std::shared_ptr<Database> Database::open(const std::string& prefix, bool prefetc
     db->header_offsets_ = static_cast<const uint64_t*>(s.header_offsets.ptr);
     if (db->n_ && db->offsets_[db->n_] > s.chars.bytes) throw DbLoadError("DB chars file is too short");
     db->finish();
-    // letter codes: checked when the file is read in full anyway (prefetch) or small; CUDASW4_AMD_VALIDATE_DB=1|0 forces it
+    // letter codes: checked here when the file is read in full anyway (prefetch) or small; otherwise the search driver
+    // checks them on the device as it uploads them (codes_validated()).  CUDASW4_AMD_VALIDATE_DB=1|0 forces / skips the
+    // pass here
     const char* v = std::getenv("CUDASW4_AMD_VALIDATE_DB");
     const bool check = v ? v[0] == '1' : (prefetch || db->num_chars() <= (size_t(4) << 30));
     if (check) db->validate_codes();

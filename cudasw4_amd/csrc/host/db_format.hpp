@@ -98,11 +98,15 @@ public:
     const std::array<size_t, kNumLengthPartitions>& partition_counts() const { return counts_; }
     size_t partition_begin(int p) const { return begins_[p]; }
     uint64_t total_residues() const { return residues_; }
+    // every letter code was checked (0..20) when the DB was loaded.  Large memory-mapped DBs that are not prefetched skip
+    // that pass over the whole file; the search driver then checks the chars on the device as it uploads them.
+    bool codes_validated() const { return codes_validated_; }
 
 private:
     Database() = default;
     void finish();  // validates offsets / lengths / ordering, computes partition tables
-    void validate_codes() const;  // every letter code 0..20
+    void validate_codes();  // every letter code 0..20
+    bool codes_validated_ = false;
     struct Storage;
     std::unique_ptr<Storage> storage_;
     const int8_t* chars_ = nullptr;

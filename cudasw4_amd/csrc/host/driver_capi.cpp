@@ -142,6 +142,37 @@ int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64
     });
 }
 
+int swdrv_scan_submit(swdrv* d, const char* query, int32_t qlen) {
+    return guarded([&] { d->driver->submit(query, qlen); });
+}
+
+int swdrv_scan_collect(swdrv* d, int32_t* scores, int64_t* ids, int cap, int* nres, int* num_overflows, double* seconds,
+                       double* gcups) {
+    return guarded([&] {
+        ScanResult r = d->driver->collect();
+        const int n = int(std::min<size_t>(r.scores.size(), size_t(cap > 0 ? cap : 0)));
+        for (int i = 0; i < n; i++) {
+            scores[i] = r.scores[size_t(i)];
+            ids[i] = r.referenceIds[size_t(i)];
+        }
+        if (nres) *nres = n;
+        if (num_overflows) *num_overflows = r.stats.numOverflows;
+        d->lastRescored = r.stats.numRescored;
+        if (seconds) *seconds = r.stats.seconds;
+        if (gcups) *gcups = r.stats.gcups;
+    });
+}
+
+int swdrv_in_flight(swdrv* d) { return d ? d->driver->inFlight() : 0; }
+
+int64_t swdrv_cached_chars(swdrv* d, int gpu) {
+    int64_t v = -1;
+    (void)guarded([&] { v = int64_t(d->driver->cachedChars(gpu)); });
+    return v;
+}
+
+int64_t swdrv_streamed_bytes(swdrv* d) { return d ? int64_t(d->driver->streamedBytesTotal()) : 0; }
+
 int swdrv_record_kernel_events(swdrv* d, int on) {
     return guarded([&] { d->driver->recordKernelEvents(on); });
 }
@@ -152,9 +183,10 @@ int swdrv_take_kernel_events(swdrv* d, double* out, int cap) {
         const auto ev = d->driver->takeKernelEvents();
         n = int(ev.size());
         for (int i = 0; i < n && i < cap; i++) {
-            double* o = out + size_t(i) * 8;
+            double* o = out + size_t(i) * 10;
             const KernelEvent& e = ev[size_t(i)];
             o[0] = e.gpu; o[1] = e.kind; o[2] = e.part_id; o[3] = e.qlen; o[4] = double(e.subjects); o[5] = e.cells; o[6] = e.chars; o[7] = e.ms;
+            o[8] = e.t0_ms; o[9] = e.t1_ms;
         }
     });
     return rc == 0 ? n : -1;

@@ -10,6 +10,7 @@
 #include <cstddef>
 #include <exception>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -39,7 +40,15 @@ void parallel_blocks(size_t n, unsigned max_threads, F&& fn) {
     };
     std::vector<std::thread> threads;
     threads.reserve(nt - 1);
-    for (unsigned t = 1; t < nt; t++) threads.emplace_back(work);
+    // thread creation can fail (a container's pids limit, RLIMIT_NPROC): the threads that did start, and the caller,
+    // finish the loop — an exception here would destroy joinable threads and terminate the process
+    for (unsigned t = 1; t < nt; t++) {
+        try {
+            threads.emplace_back(work);
+        } catch (const std::system_error&) {
+            break;
+        }
+    }
     work();
     for (auto& t : threads) t.join();
     if (error) std::rethrow_exception(error);

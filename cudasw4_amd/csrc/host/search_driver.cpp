@@ -105,7 +105,18 @@ struct SearchDriver::Gpu {
     uint64_t* d_offsets = nullptr;
     int32_t* d_lengths = nullptr;
     int8_t* d_chars = nullptr;
-    bool resident = false, wantResident = false;
+    // Hybrid residency (GpuWorkingSet / assignBatchesToGpuMem, cudasw4.cuh:317-392,1087-1144): the shard-local subjects
+    // [cacheBegin, numLocal) — the longest ones, which every scan takes first — keep their chars in d_chars; the subjects
+    // below cacheBegin are streamed in batches on every query.  cacheBegin == 0: the whole shard is resident;
+    // cacheBegin == numLocal: everything is streamed.  cacheFilled: d_chars holds the data (--uploadFull, or the first scan).
+    size_t cacheBegin = 0;
+    uint64_t cacheBytes = 0;
+    bool cacheFilled = false;
+    uint64_t streamedBytes = 0;  // chars copied host -> device by scans so far
+    // a DB whose letter codes were not validated at load (Database::codes_validated) is checked on the device as its
+    // chars arrive: the cached part after its upload, every streamed batch the first time it is scanned
+    std::vector<bool> batchChecked;
+    bool badCodes = false;
     // streaming: three device staging buffers fed from the (registered) DB mapping, or through pinned host buffers
     std::vector<Batch> batches;
     // Two batches compute at a time (one per work stream) while a third is being copied in: three buffers
@@ -117,8 +128,8 @@ struct SearchDriver::Gpu {
     hipEvent_t copied[kSlots] = {nullptr, nullptr, nullptr}, scanned[kSlots] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> batchEv;  // 2 per batch of the last streamed scan (intervals for tests / tuning)
     hipEvent_t scanStartEv = nullptr;
-    int32_t* h_ovfBatch = nullptr;    // pinned: copy of d_ovfCount after the scan
-    size_t ovfBatchCap = 0;
+    hipEvent_t recordRefEv = nullptr; // recorded when kernel-event recording was switched on: origin of KernelEvent::t0_ms
+    bool recordRefValid = false;
     float* d_scores = nullptr;
     int32_t* d_ids = nullptr;
     int32_t* d_ovfPos = nullptr;
@@ -151,9 +162,23 @@ struct SearchDriver::Gpu {
     float* d_topS = nullptr;
     int32_t* d_topI = nullptr;
     int topCapacity = 0;
-    float* h_topS = nullptr;
-    int32_t* h_topI = nullptr;
+    // what a scan leaves for the host, per query in flight (SearchDriver::kMaxInFlight): pinned copies of the top-K and
+    // of the overflow counters, and the event behind the last of those copies
+    struct ResultSlot {
+        hipEvent_t done = nullptr;
+        float* h_topS = nullptr;
+        int32_t* h_topI = nullptr;
+        int topCap = 0;
+        int32_t* h_ovf = nullptr;  // copy of d_ovfCount after the scan
+        size_t ovfCap = 0;
+        size_t ncounters = 0;
+        int top = 0;
+        bool used = false;         // this GPU took part in the scan (its shard is not empty)
+    };
+    ResultSlot res[SearchDriver::kMaxInFlight];
     int lastTop = 0;
+    const float* lastTopS = nullptr;   // the finished slot's lists (valid until that slot is reused)
+    const int32_t* lastTopI = nullptr;
     int lastOverflows = 0;      // subjects of the last query whose exact score reached the packed kind's limit (the reference's statistic)
     int lastRescored = 0;       // subjects the packed launches flagged and the 32-bit kind re-scored (>= lastOverflows)
     int32_t qlen = 0;
@@ -235,6 +260,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         for (auto& e : g->forkEvent) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&g->join2Event, hipEventDisableTiming));
         HIPCHECK(hipEventCreate(&g->scanStartEv));
+        HIPCHECK(hipEventCreate(&g->recordRefEv));
+        for (auto& r : g->res) HIPCHECK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
         // The auxiliary streams carry the few long subjects that must overlap the bulk launch.  The runtime multiplexes
         // streams of one priority onto GPU_MAX_HW_QUEUES (4) hardware queues, and two streams that share a queue
         // serialise (measured: the giant-subject launch in front of the bulk launch, 167 instead of 106 ms for a
@@ -278,9 +305,13 @@ SearchDriver::~SearchDriver() {
         }
         for (hipEvent_t e : g.batchEv) (void)hipEventDestroy(e);
         if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
+        if (g.recordRefEv) (void)hipEventDestroy(g.recordRefEv);
+        for (auto& r : g.res) {
+            if (r.done) (void)hipEventDestroy(r.done);
+            (void)hipHostFree(r.h_topS); (void)hipHostFree(r.h_topI); (void)hipHostFree(r.h_ovf);
+        }
         for (auto* v : {&g.timed, &g.freeTimed})
             for (TimedLaunch& t : *v) { (void)hipEventDestroy(t.ev0); (void)hipEventDestroy(t.ev1); }
-        (void)hipHostFree(g.h_ovfBatch);
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos); (void)hipFree(g.d_ovfCount);
         for (void* t : g.d_temp) (void)hipFree(t);
         for (int i = 0; i < Gpu::kAux; i++) {
@@ -291,13 +322,37 @@ SearchDriver::~SearchDriver() {
             if (e) (void)hipEventDestroy(e);
         if (g.join2Event) (void)hipEventDestroy(g.join2Event);
         (void)hipFree(g.d_topkTemp); (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
-        (void)hipHostFree(g.h_topS); (void)hipHostFree(g.h_topI);
         if (g.stream) (void)hipStreamDestroy(g.stream);
         if (g.copyStream) (void)hipStreamDestroy(g.copyStream);
         if (g.stream2) (void)hipStreamDestroy(g.stream2);
         if (g.ctx) sw_ctx_destroy(g.ctx);
     }
-    if (db_ && dbRegistered_) (void)hipHostUnregister(const_cast<int8_t*>(db_->chars()));
+    unregisterRanges();
+}
+
+void SearchDriver::unregisterRanges() {
+    for (auto& r : registered_) (void)hipHostUnregister(const_cast<int8_t*>(r.first));
+    registered_.clear();
+    dbRegistered_ = false;
+}
+
+// fn(gpu) for every GPU: on the GPUs' worker threads when there are several, else on the calling thread; the first
+// exception is rethrown after all of them have finished
+template <class F>
+void SearchDriver::forEachGpu(F&& fn) {
+    if (workers_.empty()) {
+        for (auto& g : gpus_) fn(*g);
+        return;
+    }
+    for (size_t i = 0; i < gpus_.size(); i++) {
+        Gpu* g = gpus_[i].get();
+        workers_[i]->post([&fn, g] { fn(*g); });
+    }
+    std::exception_ptr first;
+    for (auto& w : workers_) {
+        try { w->wait(); } catch (...) { if (!first) first = std::current_exception(); }
+    }
+    if (first) std::rethrow_exception(first);
 }
 
 void SearchDriver::setShard(int rank, int world, int64_t idBase) {
@@ -307,7 +362,24 @@ void SearchDriver::setShard(int rank, int world, int64_t idBase) {
     idBase_ = idBase;
 }
 
+// fn(src, bytes, dstOffset) for every contiguous piece of the DB's chars that the shard-local subjects [lbegin, lend)
+// occupy: one slice of the chars file per length partition the range touches, dstOffset counted from the range's start
+template <class GpuT, class F>
+static void for_each_piece(const GpuT& g, const Database& db, size_t lbegin, size_t lend, F&& fn) {
+    const uint64_t* off = db.offsets();
+    uint64_t pos = 0;
+    for (int p = 0; p < kNumLengthPartitions; p++) {
+        const size_t lb = std::max(lbegin, g.localBegin[p]), le = std::min(lend, g.localBegin[p + 1]);
+        if (le <= lb) continue;
+        const size_t gb = g.ranges[p].begin + (lb - g.localBegin[p]), ge = gb + (le - lb);
+        const uint64_t bytes = off[ge] - off[gb];
+        fn(db.chars() + (off[gb] - off[0]), bytes, pos);
+        pos += bytes;
+    }
+}
+
 void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
+    if (pendingCount_) throw std::runtime_error("setDatabase with queries in flight: collect() them first");
     for (auto& gp : gpus_) {  // a prefetch of the old DB's first batch may still be in flight
         gp->use();
         (void)hipStreamSynchronize(gp->copyStream);
@@ -317,11 +389,12 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
         for (bool& u : gp->slotUsed) u = false;
         gp->slotBase = 0;
     }
-    if (db_ && dbRegistered_) { (void)hipHostUnregister(const_cast<int8_t*>(db_->chars())); dbRegistered_ = false; }
+    unregisterRanges();
     db_ = std::move(db);
     if (db_->num_sequences() > size_t(INT32_MAX) - 1) throw std::runtime_error("Too many sequences in DB");
     const int ngpu = int(gpus_.size());
     const auto shards = shard_database(*db_, ngpu * shardWorld_);
+    const char* noHybrid = std::getenv("CUDASW4_AMD_NO_HYBRID");  // 1: a shard that does not fit is streamed in full (A/B measurements)
     bool anyStreamed = false;
     for (int gi = 0; gi < ngpu; gi++) {
         Gpu& g = *gpus_[size_t(gi)];
@@ -334,7 +407,8 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
             if (g.ranges[p].size()) g.maxLen = std::max(g.maxLen, db_->length(g.ranges[p].end - 1));
         }
         g.numLocal = g.localBegin[kNumLengthPartitions];
-        g.resident = false;
+        g.cacheFilled = false;
+        g.badCodes = false;
         g.resPrefix.clear();
         // shard-local byte offsets (the pieces of the partitions follow each other) and true residues
         g.localOffsets.assign(g.numLocal + 1, 0);
@@ -356,6 +430,8 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos);
         (void)hipFree(g.d_offsets); (void)hipFree(g.d_lengths); (void)hipFree(g.d_chars);
         g.d_chars = nullptr;
+        for (int i = 0; i < Gpu::kSlots; i++) { (void)hipFree(g.d_staging[i]); g.d_staging[i] = nullptr; }
+        g.stagingCap = 0;
         HIPCHECK(hipMalloc(&g.d_scores, n * sizeof(float)));
         HIPCHECK(hipMalloc(&g.d_ids, n * sizeof(int32_t)));
         HIPCHECK(hipMalloc(&g.d_ovfPos, n * sizeof(int32_t)));
@@ -368,53 +444,107 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
             HIPCHECK(hipMemcpyAsync(g.d_lengths + g.localBegin[p], db_->lengths() + r.begin, r.size() * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
         }
         HIPCHECK(hipStreamSynchronize(g.stream));
-        // residency decision (GpuWorkingSet, cudasw4.cuh:317-392): the whole shard if it fits the limit
+        // Residency decision (GpuWorkingSet, cudasw4.cuh:317-392,1020-1026).  The limit covers everything this GPU holds:
+        // the per-subject metadata and result arrays allocated above (24 bytes per subject), the scratch of multi-stripe
+        // queries, and the chars — resident when they fit, otherwise three staging buffers of one batch each plus as
+        // much of the shard as still fits next to them (the reference: "N out of M DB batches will be cached").
         size_t freeMem = 0, totalMem = 0;
         HIPCHECK(hipMemGetInfo(&freeMem, &totalMem));
-        size_t limit = std::min(memory_.maxGpuMem, freeMem);
-        const size_t safety = size_t(256) << 20;  // cudasw4.cuh:1020-1026
-        limit = limit > safety ? limit - safety : 0;
-        const size_t fixed = std::min(memory_.maxTempBytes, size_t(1) << 30);
-        g.wantResident = g.localChars + 64 + fixed <= limit;
+        const size_t meta = n * 24 + 8;
+        size_t limit = std::min(memory_.maxGpuMem > meta ? memory_.maxGpuMem - meta : 0, freeMem);
+        const size_t safety = size_t(256) << 20;
+        if (limit > safety) limit -= safety;  // cudasw4.cuh:1020-1026: a limit below the margin is taken as it is
+        const size_t fixed = std::min({memory_.maxTempBytes, size_t(1) << 30, limit / 4});  // scratch of multi-stripe queries
+        const size_t avail = limit - fixed;
         g.batches.clear();
-        if (!g.wantResident) { planBatches(g); anyStreamed = true; }
+        g.cacheBegin = 0;
+        g.cacheBytes = g.localChars;
+        if (g.numLocal && g.localChars + 64 > avail) {
+            // staging takes at most half of what is there, a batch is never smaller than the longest subject
+            const uint64_t minBatch = std::max<uint64_t>(uint64_t(g.maxLen) + 4, std::min<uint64_t>(memory_.maxBatchBytes, uint64_t(1) << 20));
+            const uint64_t batchBytes = std::max<uint64_t>(std::min<uint64_t>(memory_.maxBatchBytes, avail / (2 * Gpu::kSlots)), minBatch);
+            const uint64_t staging = uint64_t(Gpu::kSlots) * (batchBytes + 64);
+            const uint64_t budget = avail > staging + 64 ? avail - staging - 64 : 0;
+            // the cached suffix: the longest subjects, as many as fit; a sliver below one batch is not worth a launch
+            size_t cb = size_t(std::lower_bound(g.localOffsets.begin(), g.localOffsets.end(), g.localChars > budget ? g.localChars - budget : 0) - g.localOffsets.begin());
+            if ((noHybrid && noHybrid[0] == '1') || g.localChars - g.localOffsets[cb] < batchBytes) cb = g.numLocal;
+            g.cacheBegin = cb;
+            g.cacheBytes = g.localChars - g.localOffsets[cb];
+            planBatches(g, batchBytes);
+            g.batchChecked.assign(g.batches.size(), false);
+            anyStreamed = true;
+        }
         if (verbose_) {
-            std::cout << "gpu " << g.device << ": " << g.numLocal << " sequences, " << g.localChars << " chars, "
-                      << (g.wantResident ? "resident" : "streamed in " + std::to_string(g.batches.size()) + " batches") << "\n";
+            std::cout << "gpu " << g.device << ": " << g.numLocal << " sequences, " << g.localChars << " chars, ";
+            if (g.cacheBegin == 0) std::cout << "resident\n";
+            else std::cout << g.cacheBytes << " chars cached in gpu memory, " << (g.localChars - g.cacheBytes) << " streamed in "
+                           << g.batches.size() << " batches\n";
         }
     }
-    // Streamed shards read the DB's chars straight from the host mapping when it can be registered with the
-    // runtime (hipHostRegister: the copies become asynchronous DMA from the page cache, no staging memcpy);
-    // otherwise they go through two pinned staging buffers per GPU.  CUDASW4_AMD_NO_HOSTREGISTER=1 forces the latter.
-    if (anyStreamed && db_->num_chars() > 0) {
-        const char* no = std::getenv("CUDASW4_AMD_NO_HOSTREGISTER");
-        // registering pins the whole mapping (and faults a memory-mapped file in): fine for DBs of tens of GB, not for
-        // ones that rival the host's memory — above CUDASW4_AMD_HOSTREGISTER_MAX_GB (default 64) the pinned staging
-        // buffers are used instead
-        double maxGb = 64.0;
-        if (const char* e = std::getenv("CUDASW4_AMD_HOSTREGISTER_MAX_GB")) maxGb = std::atof(e);
-        const bool small = double(db_->num_chars()) <= maxGb * double(size_t(1) << 30);
-        if (!(no && no[0] == '1') && small) {
-            const hipError_t e = hipHostRegister(const_cast<int8_t*>(db_->chars()), db_->num_chars(), hipHostRegisterPortable);
-            dbRegistered_ = e == hipSuccess;
-            if (!dbRegistered_) (void)hipGetLastError();
+    if (anyStreamed) registerStreamedRanges();
+}
+
+// Streamed shards read the DB's chars straight from the host mapping when it can be registered with the runtime
+// (hipHostRegister: the copies become asynchronous DMA from the page cache, no staging memcpy); otherwise they go through
+// three pinned staging buffers per GPU.  CUDASW4_AMD_NO_HOSTREGISTER=1 forces the latter.  Only the byte ranges this
+// driver streams are registered — with one process per GPU (setShard) that is this rank's overhang, not the whole file —
+// and registering pins them (and faults a memory-mapped file in): above CUDASW4_AMD_HOSTREGISTER_MAX_GB (default 64) of
+// streamed bytes the pinned staging buffers are used instead.
+void SearchDriver::registerStreamedRanges() {
+    const char* no = std::getenv("CUDASW4_AMD_NO_HOSTREGISTER");
+    double maxGb = 64.0;
+    if (const char* e = std::getenv("CUDASW4_AMD_HOSTREGISTER_MAX_GB")) maxGb = std::atof(e);
+    std::vector<std::pair<const int8_t*, size_t>> ranges;
+    for (auto& gp : gpus_)
+        for_each_piece(*gp, *db_, 0, gp->cacheBegin, [&](const int8_t* src, uint64_t bytes, uint64_t) {
+            if (bytes) ranges.emplace_back(src, size_t(bytes));
+        });
+    std::sort(ranges.begin(), ranges.end());
+    // neighbours (the slices of adjacent shards of one partition) and near neighbours (closer than a huge page: their
+    // pages would be pinned twice) become one registration
+    std::vector<std::pair<const int8_t*, size_t>> merged;
+    const size_t gap = size_t(2) << 20;
+    for (const auto& r : ranges) {
+        if (!merged.empty() && r.first <= merged.back().first + merged.back().second + gap)
+            merged.back().second = std::max(merged.back().second, size_t(r.first - merged.back().first) + r.second);
+        else merged.push_back(r);
+    }
+    uint64_t total = 0;
+    for (const auto& r : merged) total += r.second;
+    const bool small = double(total) <= maxGb * double(size_t(1) << 30);
+    if (total && !(no && no[0] == '1') && small) {
+        bool ok = true;
+        for (const auto& r : merged) {
+            if (hipHostRegister(const_cast<int8_t*>(r.first), r.second, hipHostRegisterPortable) != hipSuccess) {
+                (void)hipGetLastError();
+                ok = false;
+                break;
+            }
+            registered_.push_back(r);
         }
-        if (verbose_) std::cout << "DB chars " << (dbRegistered_ ? "registered for direct DMA" : "staged through pinned buffers") << "\n";
+        if (!ok) unregisterRanges();
+        dbRegistered_ = ok;
+    }
+    if (verbose_) {
+        if (dbRegistered_) std::cout << "DB chars: " << total << " streamed bytes in " << merged.size() << " ranges registered for direct DMA\n";
+        else std::cout << "DB chars staged through pinned buffers\n";
     }
 }
 
-// Batches of a streamed shard (computeDbCopyPlan, cudasw4.cuh:1177-1277): consecutive shard-local subjects up to
-// maxBatchBytes / maxBatchSequences; a batch may span adjacent length partitions (its scan is then several launches).
-void SearchDriver::planBatches(Gpu& g) {
+// Batches of the streamed part of a shard (computeDbCopyPlan, cudasw4.cuh:1177-1277): consecutive shard-local subjects
+// below cacheBegin, up to batchBytes / maxBatchSequences each; a batch may span adjacent length partitions (its scan is
+// then several launches).
+void SearchDriver::planBatches(Gpu& g, uint64_t batchBytes) {
     const size_t maxSeq = std::max<size_t>(1, memory_.maxBatchSequences);
-    const uint64_t maxBytes = std::max<uint64_t>(memory_.maxBatchBytes, uint64_t(g.maxLen) + 4);
+    const uint64_t maxBytes = std::max<uint64_t>(batchBytes, uint64_t(g.maxLen) + 4);
+    const auto end = g.localOffsets.begin() + long(g.cacheBegin) + 1;
     size_t cur = 0;
-    while (cur < g.numLocal) {
+    while (cur < g.cacheBegin) {
         // largest e with offsets[e] - offsets[cur] <= maxBytes and e - cur <= maxSeq
         const uint64_t target = g.localOffsets[cur] + maxBytes;
-        size_t e = size_t(std::upper_bound(g.localOffsets.begin() + long(cur), g.localOffsets.end(), target) - g.localOffsets.begin()) - 1;
+        size_t e = size_t(std::upper_bound(g.localOffsets.begin() + long(cur), end, target) - g.localOffsets.begin()) - 1;
         e = std::min(e, cur + maxSeq);
-        e = std::min(std::max(e, cur + 1), g.numLocal);
+        e = std::min(std::max(e, cur + 1), g.cacheBegin);
         Batch b;
         b.lbegin = cur; b.lend = e;
         b.bytes = g.localOffsets[e] - g.localOffsets[cur];
@@ -424,25 +554,36 @@ void SearchDriver::planBatches(Gpu& g) {
     }
 }
 
+// the chars that stay in device memory: the whole shard, or its cached suffix
 void SearchDriver::uploadShard(Gpu& g) {
     g.use();
-    if (!g.d_chars) HIPCHECK(hipMalloc(&g.d_chars, g.localChars + 64));
-    const uint64_t* off = db_->offsets();
-    for (int p = 0; p < kNumLengthPartitions; p++) {
-        const ShardRange r = g.ranges[p];
-        if (!r.size()) continue;
-        HIPCHECK(hipMemcpyAsync(g.d_chars + g.localOffsets[g.localBegin[p]], db_->chars() + (off[r.begin] - off[0]),
-                                off[r.end] - off[r.begin], hipMemcpyHostToDevice, g.stream));
+    if (g.cacheBegin >= g.numLocal) { g.cacheFilled = true; return; }
+    if (!g.d_chars) HIPCHECK(hipMalloc(&g.d_chars, g.cacheBytes + 64));
+    for_each_piece(g, *db_, g.cacheBegin, g.numLocal, [&](const int8_t* src, uint64_t bytes, uint64_t pos) {
+        HIPCHECK(hipMemcpyAsync(g.d_chars + pos, src, bytes, hipMemcpyHostToDevice, g.stream));
+    });
+    HIPCHECK(hipMemsetAsync(g.d_chars + g.cacheBytes, kOtherCode, 64, g.stream));
+    if (!db_->codes_validated()) {
+        // the flag borrows the first overflow counter (no scan is in flight on this GPU during an upload)
+        int32_t bad = 0;
+        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, sizeof(int32_t), g.stream));
+        SWCHECK(sw_check_letter_codes(g.ctx, g.d_chars, g.cacheBytes, g.d_ovfCount, g.stream));
+        HIPCHECK(hipMemcpyAsync(&bad, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipStreamSynchronize(g.stream));
+        if (bad) { g.badCodes = true; throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)"); }
     }
-    HIPCHECK(hipMemsetAsync(g.d_chars + g.localChars, kOtherCode, 64, g.stream));
     HIPCHECK(hipStreamSynchronize(g.stream));
-    g.resident = true;
+    g.cacheFilled = true;
 }
 
+// --uploadFull (cudasw4.cuh:651-696): every GPU takes what it keeps — its whole shard, or the cached part of a shard
+// that does not fit — before the first query, all GPUs at once (one worker thread per GPU)
 void SearchDriver::prefetchDBToGpus() {
     if (!db_) throw std::runtime_error("setDatabase first");
-    for (auto& g : gpus_)
-        if (g->wantResident && !g->resident && g->numLocal) uploadShard(*g);
+    if (pendingCount_) throw std::runtime_error("prefetchDBToGpus with queries in flight");
+    forEachGpu([this](Gpu& g) {
+        if (!g.cacheFilled && g.numLocal) uploadShard(g);
+    });
 }
 
 namespace {
@@ -566,8 +707,9 @@ static void join_aux(GpuT& g) {
         HIPCHECK(hipStreamWaitEvent(g.stream, g.joinEvent[a], 0));
         g.auxUsed[a] = false;
     }
-    for (auto& slot : g.auxPending)
-        for (bool& pending : slot) pending = false;
+    // auxPending stays set: the host no longer waits for the end of a scan before it enqueues the next one, so the copy
+    // that reuses a staging buffer must still wait for the auxiliary launches that read it (an event that has long
+    // completed costs nothing)
     if (g.stream2Used) {
         HIPCHECK(hipEventRecord(g.join2Event, g.stream2));
         HIPCHECK(hipStreamWaitEvent(g.stream, g.join2Event, 0));
@@ -583,18 +725,14 @@ static void ensure_ovf_slots(int32_t*& h, size_t& cap, size_t need) {
     cap = need;
 }
 
-void SearchDriver::scanResident(Gpu& g) {
-    enqueue_batch(g, g.d_chars, 0, g.numLocal, *db_, kernels_, memory_, gop_, gex_, recordEvents_, 0, -1, false);
-}
-
-// DB shard larger than the memory limit: its chars stream through three device staging buffers (copy stream -> the two
-// work streams in turn: two batches compute while the third is copied in), cf. cudasw4.cuh:1560-1712; offsets and
-// lengths are resident.  Batches run longest subjects first, so the tail of the query consists of short subjects.  With
-// the DB mapping registered the whole scan is enqueued without blocking the host; the pinned fallback blocks only on its
-// own host buffers.
+// The part of a shard that does not fit the memory limit: its chars stream through three device staging buffers (copy
+// stream -> the two work streams in turn: two batches compute while the third is copied in), cf. cudasw4.cuh:1560-1712;
+// offsets and lengths are resident.  Batches run longest subjects first, so the tail of the query consists of short
+// subjects.  With the DB mapping registered the whole scan is enqueued without blocking the host; the pinned fallback
+// blocks only on its own host buffers.  Batch k of the scan order uses overflow counters k + 1 (0: the cached part).
 void SearchDriver::scanStreamed(Gpu& g) {
-    const uint64_t* off = db_->offsets();
     const size_t nb = g.batches.size();
+    const bool cached = g.cacheBegin < g.numLocal;
     uint64_t maxBytes = 0;
     for (const Batch& b : g.batches) maxBytes = std::max(maxBytes, b.bytes);
     if (maxBytes + 64 > g.stagingCap) {
@@ -618,7 +756,6 @@ void SearchDriver::scanStreamed(Gpu& g) {
         HIPCHECK(hipEventCreate(&e));
         g.batchEv.push_back(e);
     }
-    HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
     // The buffers rotate across scans (slotBase): the first batch of the next scan then gets the buffer whose last user
     // finishes earliest, two batches before the end of this scan.
     bool* const slotUsed = g.slotUsed;
@@ -638,13 +775,7 @@ void SearchDriver::scanStreamed(Gpu& g) {
         }
         if (!dbRegistered_ && slotUsed[slot]) HIPCHECK(hipEventSynchronize(g.copied[slot]));  // pinned buffer free again
         // the batch's pieces: one contiguous slice of the chars file per length partition it touches
-        uint64_t pos = 0;
-        for (int p = 0; p < kNumLengthPartitions; p++) {
-            const size_t lb = std::max(b.lbegin, g.localBegin[p]), le = std::min(b.lend, g.localBegin[p + 1]);
-            if (le <= lb) continue;
-            const size_t gb = g.ranges[p].begin + (lb - g.localBegin[p]), ge = gb + (le - lb);
-            const uint64_t bytes = off[ge] - off[gb];
-            const int8_t* src = db_->chars() + (off[gb] - off[0]);
+        for_each_piece(g, *db_, b.lbegin, b.lend, [&](const int8_t* src, uint64_t bytes, uint64_t pos) {
             if (dbRegistered_) {
                 HIPCHECK(hipMemcpyAsync(dst + pos, src, bytes, hipMemcpyHostToDevice, g.copyStream));
             } else {
@@ -657,11 +788,11 @@ void SearchDriver::scanStreamed(Gpu& g) {
                     std::memcpy(hdst + o, src + o, std::min(chunk, size_t(bytes) - o));
                 });
             }
-            pos += bytes;
-        }
+        });
         if (!dbRegistered_) HIPCHECK(hipMemcpyAsync(dst, g.h_pinned[slot], b.bytes, hipMemcpyHostToDevice, g.copyStream));
         HIPCHECK(hipMemsetAsync(dst + b.bytes, kOtherCode, 64, g.copyStream));
         HIPCHECK(hipEventRecord(g.copied[slot], g.copyStream));
+        g.streamedBytes += b.bytes;
     };
     for (size_t k = 0; k < nb; k++) {
         const Batch& b = g.batches[nb - 1 - k];
@@ -670,11 +801,13 @@ void SearchDriver::scanStreamed(Gpu& g) {
         // the first batch may already be there: the previous scan copied it in behind its own last batches (below)
         if (k == 0 && g.firstBatchStaged) g.firstBatchStaged = false;
         else copy_batch(k);
-        // created with the first streamed scan that needs it: a driver whose shards are resident keeps the set of
-        // streams it was tuned with (one more stream of the work stream's priority changes which streams end up sharing a
-        // hardware queue: the giants' launch of a RESIDENT Swiss-Prot-like DB went back in front of the bulk launch, 138
-        // instead of 107 ms for the longest query, when stream2 was created in the constructor)
-        const bool second = (k & 1) && g.twoWorkStreams;
+        // Batches alternate between the two work streams; with a cached part in front the first streamed batch takes
+        // the second one, next to the cached part's launch.  stream2 is created with the first streamed scan that needs
+        // it: a driver whose shards are resident keeps the set of streams it was tuned with (one more stream of the work
+        // stream's priority changes which streams end up sharing a hardware queue: the giants' launch of a RESIDENT
+        // Swiss-Prot-like DB went back in front of the bulk launch, 138 instead of 107 ms for the longest query, when
+        // stream2 was created in the constructor)
+        const bool second = ((k + (cached ? 1 : 0)) & 1) && g.twoWorkStreams;
         if (second && !g.stream2) HIPCHECK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
         const hipStream_t work = second ? g.stream2 : g.stream;
         if (second && !g.stream2Used) {
@@ -683,8 +816,13 @@ void SearchDriver::scanStreamed(Gpu& g) {
             g.stream2Used = true;
         }
         HIPCHECK(hipStreamWaitEvent(work, g.copied[slot], 0));
+        if (!db_->codes_validated() && !g.batchChecked[nb - 1 - k]) {
+            // the flag is the word behind this scan's overflow counters (enqueueOnGpu zeroes and copies it back)
+            SWCHECK(sw_check_letter_codes(g.ctx, dst, b.bytes, g.d_ovfCount + 1 + (1 + nb) * Gpu::kOvfLists, work));
+            g.batchChecked[nb - 1 - k] = true;
+        }
         HIPCHECK(hipEventRecord(g.batchEv[2 * k], work));
-        enqueue_batch(g, dst, b.lbegin, b.lend, *db_, kernels_, memory_, gop_, gex_, recordEvents_, k, slot, second);
+        enqueue_batch(g, dst, b.lbegin, b.lend, *db_, kernels_, memory_, gop_, gex_, recordEvents_, k + 1, slot, second);
         HIPCHECK(hipEventRecord(g.batchEv[2 * k + 1], work));
         HIPCHECK(hipEventRecord(g.scanned[slot], work));
         slotUsed[slot] = true;
@@ -700,88 +838,151 @@ void SearchDriver::scanStreamed(Gpu& g) {
     g.slotBase = (g.slotBase + nb) % Gpu::kSlots;
 }
 
-// Everything one GPU does for one query; runs on the GPU's worker thread when there are several GPUs.
-void SearchDriver::scanOnGpu(Gpu& g, int32_t queryLength, int k) {
-    g.lastTop = 0;
-    g.lastOverflows = 0;
-    g.lastRescored = 0;
+// Everything one GPU is GIVEN for one query; runs on the GPU's worker thread when there are several.  Nothing here waits
+// for the GPU (the pinned-staging fallback of a streamed shard waits for its own host buffers): the results land in
+// result slot `slot` and finishOnGpu picks them up.  The scans of consecutive queries are ordered by the streams alone:
+// the query upload, the zeroed counters and the first launches of query i + 1 queue up behind the top-K and the copies of
+// query i on the work stream, the auxiliary streams fork from it and join it again before the top-K.
+void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
+    Gpu::ResultSlot& rs = g.res[slot];
+    rs.used = false;
+    rs.top = 0;
+    rs.ncounters = 0;
     g.spanBegin = g.spanEnd = now_seconds() - scanT0_;
     if (g.numLocal == 0) return;
     g.use();
-    g.qlen = queryLength;
-    if (g.wantResident && !g.resident) uploadShard(g);  // the first query pays the upload unless --uploadFull
-    SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
-    // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
-    const size_t nbatches = g.resident ? 1 : g.batches.size();
-    const size_t ncounters = 1 + nbatches * Gpu::kOvfLists;
-    if (ncounters > g.ovfCountCap) {
-        (void)hipFree(g.d_ovfCount);
-        g.d_ovfCount = nullptr;
-        g.ovfCountCap = 0;
-        HIPCHECK(hipMalloc(&g.d_ovfCount, ncounters * sizeof(int32_t)));
-        g.ovfCountCap = ncounters;
-    }
-    ensure_ovf_slots(g.h_ovfBatch, g.ovfBatchCap, ncounters);
-    HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, ncounters * sizeof(int32_t), g.stream));
-    if (g.resident) scanResident(g);
-    else scanStreamed(g);
-    join_aux(g);
-    const int kk = int(std::min<size_t>(size_t(std::max(k, 0)), g.numLocal));
-    if (kk > 0) {
-        if (kk > g.topCapacity) {
-            (void)hipFree(g.d_topS); (void)hipFree(g.d_topI); (void)hipHostFree(g.h_topS); (void)hipHostFree(g.h_topI);
-            HIPCHECK(hipMalloc(&g.d_topS, kk * sizeof(float)));
-            HIPCHECK(hipMalloc(&g.d_topI, kk * sizeof(int32_t)));
-            HIPCHECK(hipHostMalloc(&g.h_topS, kk * sizeof(float)));
-            HIPCHECK(hipHostMalloc(&g.h_topI, kk * sizeof(int32_t)));
-            g.topCapacity = kk;
+    try {
+        g.qlen = queryLength;
+        if (!g.cacheFilled) uploadShard(g);  // the first query pays the upload unless --uploadFull
+        SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
+        // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
+        if (g.badCodes) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
+        // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed)
+        const size_t ncounters = 1 + (1 + g.batches.size()) * Gpu::kOvfLists;
+        if (ncounters + 1 > g.ovfCountCap) {
+            (void)hipFree(g.d_ovfCount);
+            g.d_ovfCount = nullptr;
+            g.ovfCountCap = 0;
+            HIPCHECK(hipMalloc(&g.d_ovfCount, (ncounters + 1) * sizeof(int32_t)));
+            g.ovfCountCap = ncounters + 1;
         }
-        const size_t tb = sw_topk_temp_bytes(int64_t(g.numLocal), kk);
-        if (tb > g.topkTempBytes) {
-            (void)hipFree(g.d_topkTemp);
-            g.d_topkTemp = nullptr;
-            HIPCHECK(hipMalloc(&g.d_topkTemp, tb));
-            g.topkTempBytes = tb;
+        ensure_ovf_slots(rs.h_ovf, rs.ovfCap, ncounters + 1);
+        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, (ncounters + 1) * sizeof(int32_t), g.stream));
+        HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
+        // the cached part first (the longest subjects: one set of launches over everything that is resident), then the
+        // streamed batches — whose first copies run while the cached part computes
+        if (g.cacheBegin < g.numLocal)
+            enqueue_batch(g, g.d_chars, g.cacheBegin, g.numLocal, *db_, kernels_, memory_, gop_, gex_, recordEvents_, 0, -1, false);
+        if (!g.batches.empty()) scanStreamed(g);
+        join_aux(g);
+        const int kk = int(std::min<size_t>(size_t(std::max(k, 0)), g.numLocal));
+        if (kk > 0) {
+            if (kk > g.topCapacity) {
+                (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
+                g.d_topS = nullptr; g.d_topI = nullptr; g.topCapacity = 0;
+                HIPCHECK(hipMalloc(&g.d_topS, kk * sizeof(float)));
+                HIPCHECK(hipMalloc(&g.d_topI, kk * sizeof(int32_t)));
+                g.topCapacity = kk;
+            }
+            if (kk > rs.topCap) {
+                (void)hipHostFree(rs.h_topS); (void)hipHostFree(rs.h_topI);
+                rs.h_topS = nullptr; rs.h_topI = nullptr; rs.topCap = 0;
+                HIPCHECK(hipHostMalloc(&rs.h_topS, kk * sizeof(float)));
+                HIPCHECK(hipHostMalloc(&rs.h_topI, kk * sizeof(int32_t)));
+                rs.topCap = kk;
+            }
+            const size_t tb = sw_topk_temp_bytes(int64_t(g.numLocal), kk);
+            if (tb > g.topkTempBytes) {
+                (void)hipFree(g.d_topkTemp);
+                g.d_topkTemp = nullptr;
+                g.topkTempBytes = 0;
+                HIPCHECK(hipMalloc(&g.d_topkTemp, tb));
+                g.topkTempBytes = tb;
+            }
+            SWCHECK(sw_topk(g.ctx, g.d_scores, g.d_ids, int64_t(g.numLocal), kk, g.d_topS, g.d_topI, g.d_topkTemp,
+                            g.topkTempBytes, g.stream));
+            HIPCHECK(hipMemcpyAsync(rs.h_topS, g.d_topS, kk * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+            HIPCHECK(hipMemcpyAsync(rs.h_topI, g.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+            rs.top = kk;
         }
-        SWCHECK(sw_topk(g.ctx, g.d_scores, g.d_ids, int64_t(g.numLocal), kk, g.d_topS, g.d_topI, g.d_topkTemp,
-                        g.topkTempBytes, g.stream));
-        HIPCHECK(hipMemcpyAsync(g.h_topS, g.d_topS, kk * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-        HIPCHECK(hipMemcpyAsync(g.h_topI, g.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
-        g.lastTop = kk;
+        // per-query totals (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
+        HIPCHECK(hipMemcpyAsync(rs.h_ovf, g.d_ovfCount, (ncounters + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipEventRecord(rs.done, g.stream));
+        rs.ncounters = ncounters;
+        rs.used = true;
+    } catch (...) {
+        // Work may still be queued on the auxiliary, second and copy streams, and the bookkeeping of who waits for
+        // whom is half-updated: drain the device and forget it, so that a later scan starts from a clean state
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        for (bool& u : g.auxUsed) u = false;
+        g.stream2Used = false;
+        for (auto& sl : g.auxPending)
+            for (bool& pnd : sl) pnd = false;
+        for (bool& u : g.slotUsed) u = false;
+        g.firstBatchStaged = false;
+        g.slotBase = 0;
+        rs.used = false;
+        throw;
     }
-    // per-query totals (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
-    HIPCHECK(hipMemcpyAsync(g.h_ovfBatch, g.d_ovfCount, ncounters * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
-    HIPCHECK(hipStreamSynchronize(g.stream));
-    for (size_t i = 1; i < ncounters; i++) g.lastRescored += g.h_ovfBatch[i];
-    g.lastOverflows = g.h_ovfBatch[0];
+}
+
+// wait for the results of the query that went into result slot `slot` and add up its counters
+void SearchDriver::finishOnGpu(Gpu& g, int slot) {
+    Gpu::ResultSlot& rs = g.res[slot];
+    g.lastTop = 0;
+    g.lastOverflows = 0;
+    g.lastRescored = 0;
+    g.lastTopS = rs.h_topS;
+    g.lastTopI = rs.h_topI;
+    if (!rs.used) return;
+    g.use();
+    HIPCHECK(hipEventSynchronize(rs.done));
+    rs.used = false;
+    if (rs.h_ovf[rs.ncounters]) {
+        g.badCodes = true;
+        throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
+    }
+    for (size_t i = 1; i < rs.ncounters; i++) g.lastRescored += rs.h_ovf[i];
+    g.lastOverflows = rs.h_ovf[0];
+    g.lastTop = rs.top;
+    rs.used = false;
     g.spanEnd = now_seconds() - scanT0_;
 }
 
-ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
+void SearchDriver::submit(const char* query, int32_t queryLength) {
     if (!db_) throw std::runtime_error("setDatabase first");
     if (queryLength <= 0) throw std::runtime_error("empty query");
     if (queryLength > INT32_MAX - 132) throw std::runtime_error("query too long");  // cudasw4.cuh:1281-1285
+    if (pendingCount_ >= size_t(kMaxInFlight)) throw std::runtime_error("too many queries in flight: collect() first");
     encodedQuery_.resize(size_t(queryLength));
     // 25-letter tables: the query keeps B, J, Z, X and '*' apart; the DB side stays the dbdata alphabet (include/cudasw4_amd.h)
     if (matrix_.dim == 25) for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue25(query[i]);
     else for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue(query[i]);
 
-    const double t0 = now_seconds();
-    scanT0_ = t0;
-    const int k = numTop_;
-    if (workers_.empty()) {
-        scanOnGpu(*gpus_[0], queryLength, k);
-    } else {
-        for (size_t i = 0; i < gpus_.size(); i++) {
-            Gpu* g = gpus_[i].get();
-            workers_[i]->post([this, g, queryLength, k] { scanOnGpu(*g, queryLength, k); });
-        }
-        std::exception_ptr first;
-        for (auto& w : workers_) {
-            try { w->wait(); } catch (...) { if (!first) first = std::current_exception(); }
-        }
-        if (first) std::rethrow_exception(first);
+    PendingScan ps;
+    ps.slot = nextSlot_;
+    ps.qlen = queryLength;
+    ps.k = numTop_;
+    ps.t0 = now_seconds();
+    if (pendingCount_ == 0) scanT0_ = ps.t0;
+    const int slot = ps.slot, k = ps.k;
+    forEachGpu([this, queryLength, k, slot](Gpu& g) { enqueueOnGpu(g, queryLength, k, slot); });
+    nextSlot_ = (nextSlot_ + 1) % kMaxInFlight;
+    pending_[(pendingHead_ + pendingCount_) % kMaxInFlight] = ps;
+    pendingCount_++;
+}
+
+ScanResult SearchDriver::collect() {
+    if (!pendingCount_) throw std::runtime_error("collect() without a submitted query");
+    const PendingScan ps = pending_[pendingHead_];
+    pendingHead_ = (pendingHead_ + 1) % kMaxInFlight;
+    pendingCount_--;
+    std::exception_ptr first;
+    for (auto& gp : gpus_) {  // plain waits: no need for the worker threads
+        try { finishOnGpu(*gp, ps.slot); } catch (...) { if (!first) first = std::current_exception(); }
     }
+    if (first) std::rethrow_exception(first);
 
     ScanResult result;
     struct Hit { int score; int64_t id; };
@@ -790,21 +991,29 @@ ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
         Gpu& g = *gp;
         result.stats.numOverflows += g.lastOverflows;
         result.stats.numRescored += g.lastRescored;
-        for (int i = 0; i < g.lastTop; i++) hits.push_back(Hit{int(g.h_topS[i]), idBase_ + g.toGlobal(g.h_topI[i])});
+        for (int i = 0; i < g.lastTop; i++) hits.push_back(Hit{int(g.lastTopS[i]), idBase_ + g.toGlobal(g.lastTopI[i])});
     }
     // host merge of the per-GPU lists (replaces cudasw4.cuh:1415-1463): score desc, id asc
     std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.score != b.score ? a.score > b.score : a.id < b.id; });
-    if (int(hits.size()) > k) hits.resize(size_t(std::max(k, 0)));
+    if (int(hits.size()) > ps.k) hits.resize(size_t(std::max(ps.k, 0)));
     for (const Hit& h : hits) { result.scores.push_back(h.score); result.referenceIds.push_back(h.id); }
 
+    // a query's time runs from its submission, or from the end of the query before it when it had to queue behind that
     const double t1 = now_seconds();
-    result.stats.seconds = t1 - t0;
+    result.stats.seconds = t1 - std::max(ps.t0, lastDone_);
+    lastDone_ = t1;
     uint64_t residues = 0;
     for (auto& gp : gpus_) residues += gp->localResidues;
-    const double cells = double(queryLength) * double(residues);
+    const double cells = double(ps.qlen) * double(residues);
     result.stats.gcups = cells / 1e9 / result.stats.seconds;  // cudasw4.cuh:2264-2271
     if (totalRunning_) { totalCells_ += cells; totalOverflows_ += result.stats.numOverflows; }
     return result;
+}
+
+ScanResult SearchDriver::scan(const char* query, int32_t queryLength) {
+    if (pendingCount_) throw std::runtime_error("scan() with queries in flight: collect() them first");
+    submit(query, queryLength);
+    return collect();
 }
 
 void SearchDriver::totalTimerStart() {
@@ -827,7 +1036,16 @@ BenchmarkStats SearchDriver::totalTimerStop() {
 
 // ---- measurement / verification hooks
 
-void SearchDriver::recordKernelEvents(int mode) { recordEvents_ = mode; }
+void SearchDriver::recordKernelEvents(int mode) {
+    if (mode && !recordEvents_) {
+        for (auto& gp : gpus_) {  // origin of the launches' begin / end times
+            gp->use();
+            HIPCHECK(hipEventRecord(gp->recordRefEv, gp->stream));
+            gp->recordRefValid = true;
+        }
+    }
+    recordEvents_ = mode;
+}
 
 std::vector<KernelEvent> SearchDriver::takeKernelEvents() {
     std::vector<KernelEvent> out;
@@ -846,6 +1064,11 @@ std::vector<KernelEvent> SearchDriver::takeKernelEvents() {
             e.cells = double(t.qlen) * double(g.resPrefix[t.lend] - g.resPrefix[t.lbegin]);
             e.chars = double(g.localOffsets[t.lend] - g.localOffsets[t.lbegin]);
             HIPCHECK(hipEventElapsedTime(&e.ms, t.ev0, t.ev1));
+            e.t0_ms = e.t1_ms = 0.f;
+            if (g.recordRefValid) {
+                HIPCHECK(hipEventElapsedTime(&e.t0_ms, g.recordRefEv, t.ev0));
+                HIPCHECK(hipEventElapsedTime(&e.t1_ms, g.recordRefEv, t.ev1));
+            }
             out.push_back(e);
             g.freeTimed.push_back(t);
         }
@@ -857,7 +1080,16 @@ std::vector<KernelEvent> SearchDriver::takeKernelEvents() {
 size_t SearchDriver::numLocal(int gpu) const { return gpus_.at(size_t(gpu))->numLocal; }
 uint64_t SearchDriver::localResidues(int gpu) const { return gpus_.at(size_t(gpu))->localResidues; }
 uint64_t SearchDriver::localChars(int gpu) const { return gpus_.at(size_t(gpu))->localChars; }
-bool SearchDriver::isResident(int gpu) const { return gpus_.at(size_t(gpu))->resident; }
+bool SearchDriver::isResident(int gpu) const {
+    const Gpu& g = *gpus_.at(size_t(gpu));
+    return g.cacheBegin == 0 && g.cacheFilled;
+}
+uint64_t SearchDriver::cachedChars(int gpu) const { return gpus_.at(size_t(gpu))->cacheBytes; }
+uint64_t SearchDriver::streamedBytesTotal() const {
+    uint64_t t = 0;
+    for (auto& gp : gpus_) t += gp->streamedBytes;
+    return t;
+}
 
 void SearchDriver::lastScores(int gpu, float* scores, int64_t* ids) {
     Gpu& g = *gpus_.at(size_t(gpu));
@@ -872,7 +1104,7 @@ std::vector<SearchDriver::BatchInterval> SearchDriver::lastBatchIntervals() {
     std::vector<BatchInterval> out;
     for (auto& gp : gpus_) {
         Gpu& g = *gp;
-        if (g.resident || g.batches.empty() || g.batchEv.size() < 2 * g.batches.size()) continue;
+        if (g.batches.empty() || g.batchEv.size() < 2 * g.batches.size()) continue;
         g.use();
         HIPCHECK(hipDeviceSynchronize());
         for (size_t k = 0; k < g.batches.size(); k++) {

@@ -98,6 +98,9 @@ struct KernelEvent {
     double cells;       // qlen x true residues of the launch's subjects
     double chars;       // padded subject bytes read by the launch
     float ms;
+    // begin / end on the device clock, relative to the moment recording was switched on: launches on different streams
+    // overlap, so the time the DP kernels kept the GPU busy is the measure of the UNION of these intervals
+    float t0_ms, t1_ms;
 };
 
 class SearchDriver {
@@ -118,6 +121,15 @@ public:
 
     // raw residue letters, as read from the query file (cudasw4.cuh:698-765)
     ScanResult scan(const char* query, int32_t queryLength);
+    // The same in two halves, so that a caller with several queries at hand (align reads whole files, main.cu:157-259)
+    // keeps the GPUs busy across query boundaries: submit() enqueues everything a query needs on every GPU and returns
+    // without waiting for it; collect() waits for the OLDEST submitted query and merges its results.  At most
+    // kMaxInFlight queries may be pending; scan() == submit() + collect().  Results are identical either way: the
+    // queries of one driver still run one after the other on each GPU.
+    static constexpr int kMaxInFlight = 2;
+    void submit(const char* query, int32_t queryLength);
+    ScanResult collect();
+    int inFlight() const { return int(pendingCount_); }
 
     void totalTimerStart();          // cudasw4.cuh:818-824
     BenchmarkStats totalTimerStop(); // cudasw4.cuh:826-839
@@ -137,7 +149,13 @@ public:
     size_t numLocal(int gpu) const;                   // subjects of this GPU's shard
     uint64_t localResidues(int gpu) const;            // true residues of this GPU's shard
     uint64_t localChars(int gpu) const;               // padded subject bytes of this GPU's shard
-    bool isResident(int gpu) const;
+    bool isResident(int gpu) const;                   // the whole shard's chars are kept in device memory
+    // hybrid residency (cudasw4.cuh:1044-1046,1087-1144): padded subject bytes of the shard that stay in device memory
+    // (== localChars when resident, 0 when everything is streamed); the rest crosses the bus on every query
+    uint64_t cachedChars(int gpu) const;
+    // bytes of subject chars copied host -> device by scans since the driver was created (the one-time upload of
+    // resident / cached chars is NOT counted): what a streamed shard costs per query on the bus
+    uint64_t streamedBytesTotal() const;
     // every score of the last scan on `gpu` (the CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756) with
     // the global id of each position; both arrays hold numLocal(gpu) entries
     void lastScores(int gpu, float* scores, int64_t* ids);
@@ -152,10 +170,13 @@ private:
     struct Gpu;
     struct Worker;
     void uploadShard(Gpu& g);
-    void scanResident(Gpu& g);
     void scanStreamed(Gpu& g);
-    void scanOnGpu(Gpu& g, int32_t queryLength, int k);
-    void planBatches(Gpu& g);
+    void enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot);
+    void finishOnGpu(Gpu& g, int slot);
+    void planBatches(Gpu& g, uint64_t batchBytes);
+    void registerStreamedRanges();
+    void unregisterRanges();
+    template <class F> void forEachGpu(F&& fn);
     std::vector<std::unique_ptr<Gpu>> gpus_;
     std::vector<std::unique_ptr<Worker>> workers_;
     std::shared_ptr<Database> db_;
@@ -168,9 +189,16 @@ private:
     int shardRank_ = 0, shardWorld_ = 1;
     int64_t idBase_ = 0;
     int recordEvents_ = 0;
-    bool dbRegistered_ = false;  // hipHostRegister of the DB's chars mapping succeeded (streamed shards copy from it directly)
+    bool dbRegistered_ = false;  // the streamed ranges of the DB's chars mapping are registered with the runtime (direct DMA)
+    std::vector<std::pair<const int8_t*, size_t>> registered_;  // what hipHostRegister was given
     std::vector<int8_t> encodedQuery_;
     double scanT0_ = 0;
+    // queries submitted and not yet collected, oldest first (a ring of kMaxInFlight result slots per GPU)
+    struct PendingScan { int slot = 0; int32_t qlen = 0; int k = 0; double t0 = 0; };
+    PendingScan pending_[kMaxInFlight];
+    size_t pendingHead_ = 0, pendingCount_ = 0;
+    int nextSlot_ = 0;
+    double lastDone_ = 0;
     // total timer
     double totalSeconds_ = 0;
     double totalCells_ = 0;

@@ -119,6 +119,14 @@ struct sw_ctx {
     bool have_matrix = false;
     int8_t* d_query = nullptr;
     size_t query_capacity = 0;
+    // sw_set_query stages the query through a small ring of pinned host buffers, so that the upload needs no host
+    // synchronisation (the caller's buffer is free again when the call returns, the copy runs stream-ordered)
+    static constexpr int kQuerySlots = 4;
+    int8_t* h_query[kQuerySlots] = {};
+    size_t h_query_capacity[kQuerySlots] = {};
+    hipEvent_t query_copied[kQuerySlots] = {};
+    bool query_slot_used[kQuerySlots] = {};
+    int query_next = 0;
     int32_t qlen = 0;
     bool have_query = false;
     Profile profiles[4][3][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups, 2 = 8-lane groups][plain | column-offset recurrence]
@@ -397,6 +405,10 @@ int sw_ctx_destroy(sw_ctx* ctx) {
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_query) (void)hipFree(ctx->d_query);
+    for (int i = 0; i < sw_ctx::kQuerySlots; i++) {
+        if (ctx->h_query[i]) (void)hipHostFree(ctx->h_query[i]);
+        if (ctx->query_copied[i]) (void)hipEventDestroy(ctx->query_copied[i]);
+    }
     for (auto& row : ctx->profiles)
         for (auto& shape : row)
             for (auto& pr : shape) {
@@ -452,14 +464,67 @@ int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void
         ctx->query_capacity = cap;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // profiles built from the previous query may still be in use on `s`: the copy is stream-ordered
-    SW_HIP(hipMemcpyAsync(ctx->d_query, query_codes_host, qlen, hipMemcpyHostToDevice, s));
-    SW_HIP(hipStreamSynchronize(s));  // host buffer may be reused by the caller immediately
+    // Pinned staging ring: the caller's buffer is copied on the host (a few KB) and is free again on return; the upload
+    // itself is stream-ordered — behind the scans of the previous query that still read d_query or its profiles on `s`
+    // — and nothing here waits for the GPU unless the ring has wrapped around onto a copy that is still in flight.
+    const int slot = ctx->query_next;
+    ctx->query_next = (ctx->query_next + 1) % sw_ctx::kQuerySlots;
+    if (ctx->query_slot_used[slot]) SW_HIP(hipEventSynchronize(ctx->query_copied[slot]));
+    if ((size_t)qlen > ctx->h_query_capacity[slot]) {
+        if (ctx->h_query[slot]) SW_HIP(hipHostFree(ctx->h_query[slot]));
+        ctx->h_query[slot] = nullptr;
+        ctx->h_query_capacity[slot] = 0;
+        const size_t cap = std::max<size_t>(((size_t)qlen + 4095) / 4096 * 4096 * 2, size_t(1) << 16);
+        SW_HIP(hipHostMalloc(&ctx->h_query[slot], cap));
+        ctx->h_query_capacity[slot] = cap;
+    }
+    if (!ctx->query_copied[slot]) SW_HIP(hipEventCreateWithFlags(&ctx->query_copied[slot], hipEventDisableTiming));
+    memcpy(ctx->h_query[slot], query_codes_host, (size_t)qlen);
+    SW_HIP(hipMemcpyAsync(ctx->d_query, ctx->h_query[slot], qlen, hipMemcpyHostToDevice, s));
+    SW_HIP(hipEventRecord(ctx->query_copied[slot], s));
+    ctx->query_slot_used[slot] = true;
     ctx->qlen = qlen;
     ctx->have_query = true;
     for (auto& row : ctx->profiles)
         for (auto& shape : row)
             for (auto& pr : shape) pr.valid = false;
+    return SW_OK;
+}
+
+namespace {
+__global__ void __launch_bounds__(256) check_codes_kernel(const int8_t* __restrict__ chars, size_t n, int32_t* bad) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 16;
+    unsigned m = 0;
+    // 16 bytes per lane where the pointer allows, the ragged ends byte by byte
+    const size_t head = (16 - ((size_t)chars & 15)) & 15;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < head && tid < n) m |= (unsigned char)chars[tid] > 20 ? 1u : 0u;
+    const size_t body = n > head ? (n - head) / 16 * 16 : 0;
+    for (size_t i = tid * 16; i < body; i += stride) {
+        const uint4 v = *reinterpret_cast<const uint4*>(chars + head + i);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // a byte is > 20 iff it has a bit of 0xE0 set, or it is 21..31: (b + 11) carries into bit 5
+            m |= w[k] & 0xE0E0E0E0u;
+            m |= ((w[k] & 0x1F1F1F1Fu) + 0x0B0B0B0Bu) & 0x20202020u;
+        }
+    }
+    const size_t tail0 = head + body;
+    if (tail0 + tid < n && tid < 16) m |= (unsigned char)chars[tail0 + tid] > 20 ? 1u : 0u;
+    if (m) atomicOr(bad, 1);
+}
+}  // namespace
+
+int sw_check_letter_codes(sw_ctx* ctx, const int8_t* chars, size_t n, int32_t* bad_flag, void* stream) {
+    if (!ctx || !bad_flag) return fail(SW_ERR_INVALID, "null argument");
+    if (n == 0) return SW_OK;
+    if (!chars) return fail(SW_ERR_INVALID, "null buffer");
+    SW_HIP(hipSetDevice(ctx->device));
+    const size_t want = (n / 16 + 255) / 256 + 1;
+    const int grid = (int)std::min<size_t>(want, (size_t)std::max(1, ctx->num_cus) * 16);
+    hipLaunchKernelGGL(check_codes_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), chars, n, bad_flag);
+    SW_HIP(hipGetLastError());
     return SW_OK;
 }
 

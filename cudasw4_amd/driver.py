@@ -18,7 +18,8 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_reader_next", "swdrv_reader_close", "swdrv_db_from_arrays", "swdrv_set_shard",
            "swdrv_record_kernel_events", "swdrv_take_kernel_events", "swdrv_shard_info", "swdrv_last_scores",
            "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges", "swdrv_matrix25",
-           "swdrv_encode25", "swdrv_last_rescored"]
+           "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
+           "swdrv_cached_chars", "swdrv_streamed_bytes"]
 
 
 class DriverError(RuntimeError):
@@ -51,6 +52,14 @@ def _load():
     L.swdrv_scan.argtypes = [vp, ctypes.c_char_p, i32, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double),
                              ctypes.POINTER(ctypes.c_double)]
+    L.swdrv_scan_submit.argtypes = [vp, ctypes.c_char_p, i32]
+    L.swdrv_scan_collect.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.swdrv_in_flight.argtypes = [vp]
+    L.swdrv_cached_chars.restype = ctypes.c_int64
+    L.swdrv_cached_chars.argtypes = [vp, ctypes.c_int]
+    L.swdrv_streamed_bytes.restype = ctypes.c_int64
+    L.swdrv_streamed_bytes.argtypes = [vp]
     L.swdrv_reference_length.restype = i32
     L.swdrv_reference_length.argtypes = [vp, ctypes.c_int64]
     L.swdrv_reference_header.argtypes = [vp, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int]
@@ -220,25 +229,31 @@ class Driver:
         _check(lib.swdrv_record_kernel_events(self.handle, int(on)))
 
     def take_kernel_events(self):
-        """-> list of dicts (gpu, kind, part_id, qlen, subjects, cells, chars, ms), HIP-event timed launches."""
-        cap = 4096
+        """-> list of dicts (gpu, kind, part_id, qlen, subjects, cells, chars, ms, t0_ms, t1_ms), HIP-event timed
+        launches; t0/t1: begin and end on the device clock since recording was switched on."""
+        cap = 16384
         while True:
-            buf = np.zeros(cap * 8, dtype=np.float64)
+            buf = np.zeros(cap * 10, dtype=np.float64)
             n = lib.swdrv_take_kernel_events(self.handle, buf.ctypes.data, cap)
             if n < 0:
                 raise DriverError(lib.swdrv_last_error().decode())
             if n <= cap:
                 break
             raise DriverError("more than %d kernel events between two takes" % cap)
-        keys = ("gpu", "kind", "part_id", "qlen", "subjects", "cells", "chars", "ms")
+        keys = ("gpu", "kind", "part_id", "qlen", "subjects", "cells", "chars", "ms", "t0_ms", "t1_ms")
         return [dict(zip(keys, (int(v) if k in ("gpu", "kind", "part_id", "qlen", "subjects") else float(v)
-                                for k, v in zip(keys, buf[8 * i:8 * i + 8])))) for i in range(n)]
+                                for k, v in zip(keys, buf[10 * i:10 * i + 10])))) for i in range(n)]
 
     def shard_info(self, gpu=0):
         i64 = ctypes.c_int64
         n, r, c, res = i64(), i64(), i64(), ctypes.c_int()
         _check(lib.swdrv_shard_info(self.handle, gpu, ctypes.byref(n), ctypes.byref(r), ctypes.byref(c), ctypes.byref(res)))
-        return {"subjects": n.value, "residues": r.value, "chars": c.value, "resident": bool(res.value)}
+        return {"subjects": n.value, "residues": r.value, "chars": c.value, "resident": bool(res.value),
+                "cached_chars": int(lib.swdrv_cached_chars(self.handle, gpu))}
+
+    def streamed_bytes(self):
+        """Subject bytes copied host -> device by scans since the driver was created (all GPUs)."""
+        return int(lib.swdrv_streamed_bytes(self.handle))
 
     def last_scores(self, gpu=0):
         """Every score of the last scan on one GPU and the global id of each position."""
@@ -296,6 +311,38 @@ class Driver:
         return {"scores": scores[:n].copy(), "ids": ids[:n].copy(), "num_overflows": novf.value,
                 "num_rescored": int(lib.swdrv_last_rescored(self.handle)),
                 "seconds": sec.value, "gcups": gcups.value}
+
+    def submit(self, query_letters):
+        """First half of scan(): enqueue the query on every GPU without waiting (at most two in flight)."""
+        if isinstance(query_letters, str):
+            query_letters = query_letters.encode()
+        _check(lib.swdrv_scan_submit(self.handle, query_letters, len(query_letters)))
+
+    def collect(self):
+        """Second half of scan(): the merged results of the oldest submitted query."""
+        cap = max(self.num_top, 1)
+        scores = np.zeros(cap, dtype=np.int32)
+        ids = np.zeros(cap, dtype=np.int64)
+        nres, novf = ctypes.c_int(), ctypes.c_int()
+        sec, gcups = ctypes.c_double(), ctypes.c_double()
+        _check(lib.swdrv_scan_collect(self.handle, scores.ctypes.data, ids.ctypes.data, cap, ctypes.byref(nres),
+                                      ctypes.byref(novf), ctypes.byref(sec), ctypes.byref(gcups)))
+        n = nres.value
+        return {"scores": scores[:n].copy(), "ids": ids[:n].copy(), "num_overflows": novf.value,
+                "num_rescored": int(lib.swdrv_last_rescored(self.handle)),
+                "seconds": sec.value, "gcups": gcups.value}
+
+    def scan_many(self, queries):
+        """Every query of a list, pipelined: the next query is submitted before the current one is collected, so the
+        GPUs stay busy across query boundaries (what `align` does with a query file).  -> list of result dicts."""
+        out = []
+        for q in queries:
+            self.submit(q)
+            if lib.swdrv_in_flight(self.handle) >= 2:
+                out.append(self.collect())
+        while lib.swdrv_in_flight(self.handle) > 0:
+            out.append(self.collect())
+        return out
 
     def reference_length(self, i):
         return int(lib.swdrv_reference_length(self.handle, i))

@@ -80,7 +80,9 @@ int sw_ctx_destroy(sw_ctx* ctx);
 int sw_set_matrix(sw_ctx* ctx, const int8_t* matrix_host, int dim);
 
 /* CudaSW4::setQuery (cudasw4.cuh:1280-1310): install the encoded query (HOST pointer, codes
- * 0..dim-1).  Builds the device-side query profile the kernels read (lazily, per kind). */
+ * 0..dim-1).  Builds the device-side query profile the kernels read (lazily, per kind).  The codes are staged in a
+ * pinned buffer of the context: the caller's buffer is free again on return, the upload is enqueued on `stream` behind
+ * the scans of the previous query, and the call does not wait for the GPU. */
 int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void* stream);
 
 /* Bytes of temp memory the sw_scan_partition call with the same (kind, part_id, n, max_subject_len) needs
@@ -159,6 +161,12 @@ int sw_rescore_overflow_stat(sw_ctx* ctx, int kind,
 size_t sw_topk_temp_bytes(int64_t n, int k);
 int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int k,
             float* out_scores, int32_t* out_ids, void* temp, size_t temp_bytes, void* stream);
+
+/* Guard for callers that upload subject chars they have not validated (a memory-mapped DB too large to read at load):
+ * *bad_flag (DEVICE int32, zeroed by the caller) is set to 1 when any of chars[0 .. n) (DEVICE) is not a letter code
+ * 0..20.  The scan kernels turn every letter byte into an LDS row offset (the reference indexes its shared-memory score
+ * table the same way, half2_kernels.cuh:243-261), so a foreign or corrupt DB yields garbage scores: check, then refuse. */
+int sw_check_letter_codes(sw_ctx* ctx, const int8_t* chars, size_t n, int32_t* bad_flag, void* stream);
 
 /* Introspection for tests / tuning: rows per lane and number of query stripes chosen for qlen. */
 int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstripes);

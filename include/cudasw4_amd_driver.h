@@ -57,13 +57,31 @@ int swdrv_scan(swdrv* d, const char* query, int32_t qlen, int32_t* scores, int64
                int* nres, int* num_overflows, double* seconds, double* gcups);
 int swdrv_last_rescored(swdrv* d);
 
+/* The same scan in two halves (SearchDriver::submit / collect): swdrv_scan_submit enqueues everything the query needs on
+ * every GPU and returns without waiting; swdrv_scan_collect waits for the OLDEST submitted query and returns its merged
+ * results.  At most two queries may be in flight, so a caller that knows its next query (align reads whole query files,
+ * main.cu:157-259) submits it before collecting the current one and the GPUs never idle between queries.  Results are
+ * the same as swdrv_scan's. */
+int swdrv_scan_submit(swdrv* d, const char* query, int32_t qlen);
+int swdrv_scan_collect(swdrv* d, int32_t* scores, int64_t* ids, int cap, int* nres, int* num_overflows, double* seconds,
+                       double* gcups);
+int swdrv_in_flight(swdrv* d);
+
 /* ---- measurement / verification hooks (bench.py, tests) ----
- * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 8 doubles per launch
- * (gpu index, kind, part_id, query length, subjects, cells, padded subject bytes, milliseconds); returns the number
- * of launches recorded since the last call (may exceed cap), -1 on error. */
+ * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 10 doubles per launch
+ * (gpu index, kind, part_id, query length, subjects, cells, padded subject bytes, milliseconds, begin ms, end ms — the
+ * last two on the device clock since recording was switched on: launches on different streams overlap, the union of the
+ * intervals is the time the DP kernels kept the GPU busy); returns the number of launches recorded since the last call
+ * (may exceed cap), -1 on error. */
 int swdrv_record_kernel_events(swdrv* d, int on);
 int swdrv_take_kernel_events(swdrv* d, double* out, int cap);
 int swdrv_shard_info(swdrv* d, int gpu, int64_t* num_local, int64_t* residues, int64_t* chars, int* resident);
+/* hybrid residency (cudasw4.cuh:1044-1046,1087-1144): padded subject bytes of the GPU's shard that stay in device memory
+ * (== chars when the shard is resident, 0 when all of it is streamed); -1 on error */
+int64_t swdrv_cached_chars(swdrv* d, int gpu);
+/* subject bytes copied host -> device by scans since swdrv_create (the one-time upload of resident / cached chars is
+ * not counted): the bus traffic of streamed shards */
+int64_t swdrv_streamed_bytes(swdrv* d);
 /* every score of the last scan on GPU `gpu` (shard order) and the global id of every position (the
  * CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756); num_local entries each */
 int swdrv_last_scores(swdrv* d, int gpu, float* scores, int64_t* ids);
