@@ -51,9 +51,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 KIND_BY_NAME = {"half2": 0, "dpxs16": 1, "dpxs32": 2, "float": 3}
 DTYPE_BY_KIND = {0: "f16x2", 1: "i16x2", 2: "i32", 3: "f32"}
-# the int32 kind runs in fp32 lanes whenever the score bound proves that exact (sw_api.hip: effective_kind) — always, at
-# these sizes: the issue peak that applies is the fp32 kind's
-ISSUE_KIND = {0: 0, 1: 1, 2: 3, 3: 3}
 KERNEL_SOURCES = ["cudasw4_amd/csrc/sw_dp_kernel.hpp", "cudasw4_amd/csrc/sw_launch.hpp", "cudasw4_amd/csrc/sw_api.hip",
                   "cudasw4_amd/csrc/Makefile"]
 
@@ -76,6 +73,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="peak workload: skip the Swiss-Prot-like secondary measurement")
     ap.add_argument("--cpu-sample-subjects", type=int, default=None)
+    ap.add_argument("--db-prefix", default=os.environ.get("CUDASW4_SPROT_PREFIX"),
+                    help="sprot-like workload (and the default run's secondary leg): a real DB made by `makedb` (e.g. "
+                         "uniprot_sprot, runsprotbenchmark.sh:18-51) instead of the synthetic stand-in; default: "
+                         "$CUDASW4_SPROT_PREFIX")
+    ap.add_argument("--kernel-table", action="store_true",
+                    help="add the per-kernel table of the timed region to the line (tools/collect_profiles.sh matches it with the PMC passes)")
     return ap.parse_args(argv)
 
 
@@ -186,6 +189,117 @@ def cpu_baseline(queries, chars, offsets, lengths, what):
     return obj, scores
 
 
+# ------------------------------------------------------------------------------------------------- roofline
+def union_ms(intervals):
+    """Measure of the union of (begin, end) intervals: the time at least one of them was running."""
+    total, cur_b, cur_e = 0.0, None, None
+    for b, e in sorted(intervals):
+        if cur_e is None or b > cur_e:
+            if cur_e is not None:
+                total += cur_e - cur_b
+            cur_b, cur_e = b, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        total += cur_e - cur_b
+    return total
+
+
+def kernel_name_of(e):
+    """swk::sw_scan_kernel's template arguments as rocprofv3 prints them (the last one, the form of the recurrence, is
+    left open: it follows from the gap scores, not from the launch)."""
+    return "sw_scan_kernel<%d, %d, %d, %s," % (e["eff_kind"], e["rows"], e["lanes"], "true" if e["nstripes"] > 1 else "false")
+
+
+def residency_of(info):
+    if info["resident"]:
+        return "resident"
+    return "hybrid" if info.get("cached_chars", 0) > 0 else "streamed"
+
+
+def counters_key(workload, kernel_name, residency):
+    return "%s:%s:%s%s" % (workload, kernel_name, residency, ":i32native" if os.environ.get("CUDASW4_AMD_I32_NATIVE") == "1" else "")
+
+
+def roofline_objects(args, workload, kernel_name, events, info):
+    """`roofline` (the HBM view the contract asks for), `valu_roofline` (the binding bound) and the per-kernel table of
+    the timed region, from the HIP events the driver recorded around every DP launch on the stream it ran on.
+
+    * the dominant kernel is the instantiation with the largest summed launch time; `achieved` = its algorithmic bytes
+      per launch (SURVEY.md §8d) / its average launch duration;
+    * `traffic` = the PMC-measured HBM-side bytes PER SUBJECT BYTE of that instantiation (profiles/kernel_counters.json)
+      x the subject bytes of an average launch here — a launch of a 128 MB batch is not charged with the traffic of a
+      532 MB one;
+    * the DP kernels' own rate (`kernel_gcups`) = cells / the measure of the UNION of all launch intervals: launches
+      overlap (long subjects on the auxiliary streams, consecutive batches on two work streams), a sequence of batches
+      does not — neither the sum nor the longest launch of a scan is the time the kernels took."""
+    if not events:
+        return None, None, []
+    groups = {}
+    for e in events:
+        groups.setdefault(kernel_name_of(e), []).append(e)
+    ktable = [{"kernel": k + " *>", "launches": len(v), "total_ms": round(sum(e["ms"] for e in v), 3),
+               "chars": int(sum(e["chars"] for e in v)), "cells": float(sum(e["cells"] for e in v)),
+               "nstripes": sorted(set(e["nstripes"] for e in v))} for k, v in sorted(groups.items())]
+    key = max(groups, key=lambda k: sum(e["ms"] for e in groups[k]))
+    ev = groups[key]
+    kind = ev[0]["eff_kind"]
+    avg_ms = sum(e["ms"] for e in ev) / len(ev)
+    avg_chars = sum(e["chars"] for e in ev) / len(ev)
+    # algorithmic HBM bytes of one launch (SURVEY.md §8d): chars + lengths + offsets + scores/ids + query
+    bytes_per_launch = sum(e["chars"] + 4 * e["subjects"] + 8 * (e["subjects"] + 1) + 8 * e["subjects"] + (e["qlen"] + 3) // 4 * 4 + 128
+                           for e in ev) / len(ev)
+    hbm_gbs = bytes_per_launch / 1e9 / (avg_ms * 1e-3)
+    counters, cnote = load_counters()
+    lanes = ev[0]["lanes"]
+    kname = "sw_scan_kernel<%s, R=%d, %d lanes, %s>" % (DTYPE_BY_KIND[kind], ev[0]["rows"], lanes,
+                                                        "multi-stripe" if ev[0]["nstripes"] > 1 else "single stripe")
+    traffic, tnote = None, cnote
+    if counters:
+        t = (counters.get("traffic_bytes_per_char") or {}).get(key)
+        if t and sorted(set(e["nstripes"] for e in ev)) == t.get("nstripes"):
+            traffic = int(t["value"] * avg_chars)
+            tnote = "%.2f HBM-side bytes per subject byte of this instantiation (%s) x %d subject bytes per launch here" % (
+                t["value"], t["source"], int(avg_chars))
+        else:
+            tnote = "no PMC traffic figure for %s *> with these stripes" % key
+    busy_ms = union_ms([(e["t0_ms"], e["t1_ms"]) for e in events])
+    roof = {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(hbm_gbs / 8000.0, 6), "traffic": traffic, "kernel": kname,
+            "avg_launch_ms": round(avg_ms, 4), "launches": len(ev), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "share_of_kernel_time": round(sum(e["ms"] for e in ev) / sum(e["ms"] for e in events), 3)}
+    if tnote:
+        roof["traffic_note"] = tnote
+    # the binding bound: VALU issue (DESIGN.md §3).  Peak: one wave64 instruction per 4 cycles per SIMD =
+    # 64 lanes/clk/CU, 256 CUs at 2.4 GHz; fp32 kind: v_add_f32 co-issues with v_max3_f32 (99.5 lanes/clk/CU)
+    packed = kind in (0, 1)
+    kern_gcups = sum(e["cells"] for e in events) / 1e9 / (busy_ms * 1e-3)
+    valu_peak = 256 * (99.5 if kind == 3 else 64) * 2.4e9
+    residency = residency_of(info)
+    ipu, ipu_key = None, None
+    if counters:
+        table = counters.get("valu_instr_per_unit") or {}
+        for r in (residency, "resident"):
+            ipu_key = counters_key(workload, kernel_name, r)
+            if ipu_key in table:
+                ipu = table[ipu_key]
+                break
+    valu = {"bound": "valu-issue", "peak": round(valu_peak / 1e12, 3), "unit": "T lane-instr/s",
+            "kernel_gcups": round(kern_gcups, 1), "kernel_busy_ms_per_step": round(busy_ms / max(args.steps, 1), 3),
+            "note": "the binding bound of this path (DESIGN.md §3): the DP recurrence is VALU-issue bound, not HBM "
+                    "bound; roofline.frac above is the HBM view the contract asks for.  kernel_gcups = cells / union of "
+                    "the launches' HIP-event intervals"}
+    if ipu:
+        ach = kern_gcups * 1e9 / (2 if packed else 1) * ipu["value"]
+        valu.update({"achieved": round(ach / 1e12, 3), "frac": round(ach / valu_peak, 4),
+                     "instr_per_cell_pair" if packed else "instr_per_cell": ipu["value"],
+                     "counters": ipu["source"], "counters_key": ipu_key})
+    else:
+        valu.update({"achieved": None, "frac": None,
+                     "counters_note": cnote or "no PMC figure for %s" % counters_key(workload, kernel_name, residency)})
+    return roof, valu, ktable
+
+
 # ------------------------------------------------------------------------------------------------- one rank
 def run_rank(args):
     import torch
@@ -197,6 +311,10 @@ def run_rank(args):
     # BENCH_FORCE_DIST=1 (test hook): go through the process-group code path (RCCL init, gather, reductions, barrier) even
     # with a single rank, which is all a 1-GPU box can run with the real backend
     distributed = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if os.environ.get("BENCH_FAIL_RANK") == str(rank):
+        # test hook: a rank that dies (before it touches the GPU) must take the whole job down with a non-zero exit code
+        sys.stderr.write("bench.py: rank %d fails on request (BENCH_FAIL_RANK)\n" % rank)
+        sys.exit(3)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # test hooks (1-GPU boxes): BENCH_FORCE_DEVICE maps every rank onto one device, BENCH_DIST_BACKEND=gloo
@@ -230,7 +348,7 @@ def run_rank(args):
         a2.workload, a2.kernel, a2.db_size, a2.cpu_sample_subjects = "sprot-like", None, None, None
         sec = measure(env, a2, "sprot-like", want_cpu=not args.no_cpu_baseline and world == 1)
         if rank == 0:
-            out["sprot_like"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "verified", "verified_how",
+            out["sprot_like"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "data", "verified", "verified_how",
                                                       "config", "roofline", "valu_roofline", "cpu_baseline") if k in sec}
     if distributed and world > 1 and args.scaling == "strong" and args.workload == "peak" and not args.no_secondary:
         # next to the strong-scaling headline (ONE DB sharded over the ranks): the same benchmark with one full DB per
@@ -267,6 +385,7 @@ def measure(env, args, workload, want_cpu):
 
     drv = driver.Driver(devices=[local_rank], num_top=K, matrix=62, kinds=kinds, max_gpu_mem=parse_size(args.max_gpu_mem))
     host_db = None
+    data = "synthetic"
     if args.workload == "peak":
         num = args.db_size or 1_000_000
         L = args.db_length
@@ -276,14 +395,28 @@ def measure(env, args, workload, want_cpu):
         total_subjects = num * (1 if strong else world)
         what = "pseudo DB %d x %d%s" % (num, L, "" if strong else " per GPU")
     else:
-        num = args.db_size or synthdb.SPROT_SEQUENCES
-        host_db = synthdb.sprot_like(num)
-        drv.set_shard(rank, world, 0) if strong else drv.set_shard(0, 1, rank * num)
-        drv.db_from_arrays(*host_db)
+        if args.db_prefix:
+            # a real DB in dbdata layout (makedb's output): the driver memory-maps it like `align`; the CPU leg and the
+            # verification read the same files
+            chunk = args.db_prefix + "0"
+            host_db = (np.memmap(chunk + "chars", dtype=np.int8, mode="r"), np.fromfile(chunk + "offsets", dtype=np.uint64),
+                       np.fromfile(chunk + "lengths", dtype=np.int32))
+            num = len(host_db[2])
+            drv.set_shard(rank, world, 0) if strong else drv.set_shard(0, 1, rank * num)
+            drv.open_db(args.db_prefix, prefetch=True)
+            data = "real"
+            label = "DB %s" % args.db_prefix
+        else:
+            num = args.db_size or synthdb.SPROT_SEQUENCES
+            host_db = synthdb.sprot_like(num)
+            drv.set_shard(rank, world, 0) if strong else drv.set_shard(0, 1, rank * num)
+            drv.db_from_arrays(*host_db)
+            label = "Swiss-Prot-like synthetic DB"
         total_residues = float(host_db[2].astype(np.int64).sum()) * (1 if strong else world)
         total_subjects = num * (1 if strong else world)
-        what = "Swiss-Prot-like synthetic DB (%d sequences, %d residues, log-normal lengths, max %d)%s" % (
-            num, int(host_db[2].astype(np.int64).sum()), int(host_db[2].max()), "" if strong else " per GPU")
+        what = "%s (%d sequences, %d residues, %s, max %d)%s" % (
+            label, num, int(host_db[2].astype(np.int64).sum()), "lengths as in the file" if args.db_prefix else "log-normal lengths",
+            int(host_db[2].max()), "" if strong else " per GPU")
     drv.upload()
     info = drv.shard_info(0)
 
@@ -293,8 +426,10 @@ def measure(env, args, workload, want_cpu):
         """20 scans through the C++ driver (each returns this rank's top-K on the host), then ONE exchange of the
         per-rank lists — K (score, id) pairs per query and rank — and the host-side merge on rank 0."""
         mine = np.full((len(queries), max(K, 1), 2), -1, dtype=np.int64)
-        for qi, q in enumerate(query_letters):
-            r = drv.scan(q)
+        # the query file is at hand as a whole (main.cu:217-260): the driver takes the next query while the current
+        # one's top-K is still on its way back (Driver.scan_many == what `align` does); BENCH_NO_PIPELINE=1: one by one
+        results = [drv.scan(q) for q in query_letters] if os.environ.get("BENCH_NO_PIPELINE") == "1" else drv.scan_many(query_letters)
+        for qi, r in enumerate(results):
             n = len(r["scores"])
             mine[qi, :n, 0] = r["scores"]
             mine[qi, :n, 1] = r["ids"]
@@ -398,74 +533,25 @@ def measure(env, args, workload, want_cpu):
         verified = None if ok is None else bool(ok)
 
     if rank == 0:
-        # dominant kernel: group the HIP-event timed launches by kernel instantiation (kind, rows per lane, stripes, shape)
-        groups = {}
-        for e in events:
-            rows, ns = capi.plan_query(e["kind"], e["qlen"])
-            key = (e["kind"], rows, ns > 1, e["part_id"] >= 34)
-            groups.setdefault(key, []).append(e)
-        roof, valu = None, None
-        if groups:
-            key = max(groups, key=lambda k: sum(e["ms"] for e in groups[k]))
-            ev = groups[key]
-            kind = key[0]
-            avg_ms = sum(e["ms"] for e in ev) / len(ev)
-            # algorithmic HBM bytes of one launch: chars + lengths + offsets + scores/ids + query
-            bytes_per_launch = sum(e["chars"] + 4 * e["subjects"] + 8 * (e["subjects"] + 1) + 8 * e["subjects"] + (e["qlen"] + 3) // 4 * 4 + 128
-                                   for e in ev) / len(ev)
-            hbm_gbs = bytes_per_launch / 1e9 / (avg_ms * 1e-3)
-            counters, cnote = load_counters()
-            kname = "sw_scan_kernel<%s, R=%d, %s, %s>" % (DTYPE_BY_KIND[kind], key[1], "16 lanes" if not key[3] else "long-subject shape",
-                                                         "multi-stripe" if key[2] else "single stripe")
-            traffic = None
-            if counters:
-                traffic = (counters.get("traffic_bytes_per_launch") or {}).get("%s:%s:R%d" % (args.workload, DTYPE_BY_KIND[kind], key[1]))
-            roof = {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(hbm_gbs / 8000.0, 6), "traffic": traffic, "kernel": kname,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": len(ev), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "share_of_kernel_time": round(sum(e["ms"] for e in ev) / sum(e["ms"] for e in events), 3)}
-            if cnote:
-                roof["traffic_note"] = cnote
-            # the binding bound: VALU issue.  Peak: one wave64 instruction per 4 cycles per SIMD =
-            # 64 lanes/clk/CU, 256 CUs at 2.4 GHz; fp32 kind: v_add_f32 co-issues with v_max3_f32 (99.5 lanes/clk/CU)
-            packed = kind in (0, 1)
-            # GCUPS of the DP launches alone.  The launches of one scan run concurrently (the few long subjects on the
-            # auxiliary streams next to the bulk launch), so a scan counts with its longest launch, not with their sum
-            scans, cur = [], None
-            for e in events:
-                if cur is None or cur["qlen"] != e["qlen"]:
-                    cur = {"qlen": e["qlen"], "ms": 0.0, "cells": 0.0}
-                    scans.append(cur)
-                cur["ms"] = max(cur["ms"], e["ms"])
-                cur["cells"] += e["cells"]
-            kern_gcups = sum(x["cells"] for x in scans) / 1e9 / (sum(x["ms"] for x in scans) * 1e-3)
-            valu_peak = 256 * (99.5 if ISSUE_KIND[kind] == 3 else 64) * 2.4e9
-            ipu = (counters.get("valu_instr_per_unit") or {}).get("%s:%s" % (args.workload, DTYPE_BY_KIND[kind])) if counters else None
-            valu = {"bound": "valu-issue", "peak": round(valu_peak / 1e12, 3), "unit": "T lane-instr/s",
-                    "kernel_gcups": round(kern_gcups, 1),
-                    "note": "the binding bound of this path (DESIGN.md §3): the DP recurrence is VALU-issue bound, not HBM "
-                            "bound; roofline.frac above is the HBM view the contract asks for"}
-            if ipu:
-                ach = kern_gcups * 1e9 / (2 if packed else 1) * ipu
-                valu.update({"achieved": round(ach / 1e12, 3), "frac": round(ach / valu_peak, 4),
-                             "instr_per_cell_pair" if packed else "instr_per_cell": ipu,
-                             "counters": counters.get("source")})
-            else:
-                valu.update({"achieved": None, "frac": None, "counters_note": cnote or "no PMC figure for this workload/kind"})
+        roof, valu, ktable = roofline_objects(args, workload, kernel_name, events, info)
         out = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True,
             "scaling": "strong" if (strong and distributed) else "weak", "vs_baseline": None,
-            "dtype": DTYPE_BY_KIND[kinds[0]] + (" (int32 results computed in fp32 lanes: exact below 2^24, bound checked per launch)" if kinds[0] == 2 else ""),
-            "data": "synthetic", "verified": verified, "verified_how": verify_note,
+            "dtype": DTYPE_BY_KIND[kinds[0]] + (" (int32 results computed in fp32 lanes: exact below 2^24, bound checked per launch)"
+                                                if kinds[0] == 2 and os.environ.get("CUDASW4_AMD_I32_NATIVE") != "1" else ""),
+            "data": data, "verified": verified, "verified_how": verify_note,
             "config": {"workload": "%s: allqueries.fasta (20 queries, %d residues) vs %s, %s kernel configuration, blosum62, "
                                    "gop -11 gex -1, top %d, C++ host driver" % (args.workload, sum_q, what, kernel_name, K),
                        "db_subjects": total_subjects, "db_residues": int(total_residues), "queries": len(queries),
                        "kernel": kernel_name, "host": "libcudasw4_host.so (SearchDriver)",
-                       "resident": info["resident"],
+                       "resident": info["resident"], "residency": residency_of(info),
+                       "cached_chars": info.get("cached_chars"), "shard_chars": info["chars"],
                        "parallelism": "db-shard x%d (%s), one top-K gather per step + host merge" % (world, "one DB sharded" if strong else "one DB per rank")},
             "roofline": roof, "valu_roofline": valu,
         }
+        if args.kernel_table:
+            out["kernels"] = ktable
         if want_cpu and cpu_obj is None:
             # peak workload: a bounded sample of the same DB (identical subjects)
             import oracle_lib as O

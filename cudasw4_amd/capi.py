@@ -23,7 +23,7 @@ ERR_NAMES = {-1: "SW_ERR_INVALID", -2: "SW_ERR_HIP", -3: "SW_ERR_NO_QUERY", -4: 
 EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "sw_ctx_destroy", "sw_set_matrix",
            "sw_set_query", "sw_scan_temp_bytes", "sw_scan_partition", "sw_rescore_overflow", "sw_rescore_overflow_stat",
            "sw_topk_temp_bytes",
-           "sw_topk", "sw_plan_query", "sw_check_letter_codes"]
+           "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch"]
 
 
 class SwError(RuntimeError):

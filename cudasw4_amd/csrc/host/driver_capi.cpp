@@ -183,10 +183,10 @@ int swdrv_take_kernel_events(swdrv* d, double* out, int cap) {
         const auto ev = d->driver->takeKernelEvents();
         n = int(ev.size());
         for (int i = 0; i < n && i < cap; i++) {
-            double* o = out + size_t(i) * 10;
+            double* o = out + size_t(i) * 14;
             const KernelEvent& e = ev[size_t(i)];
             o[0] = e.gpu; o[1] = e.kind; o[2] = e.part_id; o[3] = e.qlen; o[4] = double(e.subjects); o[5] = e.cells; o[6] = e.chars; o[7] = e.ms;
-            o[8] = e.t0_ms; o[9] = e.t1_ms;
+            o[8] = e.t0_ms; o[9] = e.t1_ms; o[10] = e.eff_kind; o[11] = e.rows; o[12] = e.nstripes; o[13] = e.lanes;
         }
     });
     return rc == 0 ? n : -1;

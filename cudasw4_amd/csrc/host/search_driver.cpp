@@ -81,6 +81,7 @@ struct Batch {
 struct TimedLaunch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int kind = 0, part_id = 0;
+    int32_t eff_kind = 0, rows = 0, nstripes = 0, lanes = 0;
     int32_t qlen = 0;
     size_t lbegin = 0, lend = 0;
 };
@@ -647,6 +648,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
             if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
             else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
             t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end;
+            SWCHECK(sw_plan_launch(g.ctx, int(r.kind), r.part_id, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
             HIPCHECK(hipEventRecord(t.ev0, stream));
         }
         const bool packed = ovfList[ri] >= 0;
@@ -852,11 +854,11 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
     if (g.numLocal == 0) return;
     g.use();
     try {
+        if (g.badCodes) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
         g.qlen = queryLength;
         if (!g.cacheFilled) uploadShard(g);  // the first query pays the upload unless --uploadFull
         SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
         // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
-        if (g.badCodes) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
         // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed)
         const size_t ncounters = 1 + (1 + g.batches.size()) * Gpu::kOvfLists;
         if (ncounters + 1 > g.ovfCountCap) {
@@ -1060,6 +1062,7 @@ std::vector<KernelEvent> SearchDriver::takeKernelEvents() {
         for (TimedLaunch& t : g.timed) {
             KernelEvent e{};
             e.gpu = g.index; e.kind = t.kind; e.part_id = t.part_id; e.qlen = t.qlen;
+            e.eff_kind = t.eff_kind; e.rows = t.rows; e.nstripes = t.nstripes; e.lanes = t.lanes;
             e.subjects = int64_t(t.lend - t.lbegin);
             e.cells = double(t.qlen) * double(g.resPrefix[t.lend] - g.resPrefix[t.lbegin]);
             e.chars = double(g.localOffsets[t.lend] - g.localOffsets[t.lbegin]);

@@ -101,6 +101,9 @@ struct KernelEvent {
     // begin / end on the device clock, relative to the moment recording was switched on: launches on different streams
     // overlap, so the time the DP kernels kept the GPU busy is the measure of the UNION of these intervals
     float t0_ms, t1_ms;
+    // the kernel instantiation the library chose (sw_plan_launch): arithmetic kind actually computed in, rows per lane,
+    // query stripes, lanes per alignment group
+    int eff_kind, rows, nstripes, lanes;
 };
 
 class SearchDriver {

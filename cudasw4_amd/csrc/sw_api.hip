@@ -94,11 +94,13 @@ struct Profile {
 }  // namespace
 
 constexpr uint32_t kWorkSlots = 4096;
-// Longest query that runs on 8-lane groups (measured on the peak DB, tools/short_query_sweep.py: at L = 512 the packed
-// kinds gain +14 % at 144 residues, +8 % at 280 and lose 1 % from 320 on, where the 8-lane kernels need the registers of
-// two waves per SIMD; the 32-bit kinds gain up to 222 residues; shorter subjects move both limits up)
+// Longest query that runs on 8-lane groups.  Tuned on RAGGED subjects (tools/ragged_query_sweep.py, Swiss-Prot-like DB
+// through the C++ driver): the packed kinds gain 2.4 ... 7.3 % up to 256 residues (R = 32: still three waves per SIMD)
+// and nothing consistent above (272: -1 %, 288: +1.5 %, 304: -3 %); the 32-bit kinds gain 4 ... 14 % up to 256 and lose
+// from 272 on.  (Round 2 tuned on the peak DB, whose identical subjects hid the LDS bank conflicts of the second group
+// of a DPP row — fixed since, Geometry / dp_step: laneStep — and chose 288 / 240: +14 % at 144 residues there.)
 #ifndef SW_LANES8_MAX_QUERY_PACKED
-#define SW_LANES8_MAX_QUERY_PACKED 288
+#define SW_LANES8_MAX_QUERY_PACKED 256
 #endif
 #ifndef SW_LANES8_MAX_SUBJECT
 #define SW_LANES8_MAX_SUBJECT 192
@@ -162,7 +164,7 @@ int shape_index(int lanes) { return lanes == 64 ? 1 : lanes == 8 ? 2 : 0; }
 // 2^24 the int32 launch is served by the fp32 kernels with bit-identical results (they are written as floats either way,
 // like the reference's BatchResultList).  Anything beyond the bound, e.g. a 2-million-residue query against a subject
 // of the same size, gets the true int32 kernels.
-int effective_kind(const sw_ctx* ctx, int kind, int32_t max_subject_len) {
+int effective_kind_of(const sw_ctx* ctx, int kind, int32_t max_subject_len) {
     if (kind != SW_KIND_I32 || ctx->i32_native || !ctx->have_query) return kind;
     const int64_t bound = (int64_t)std::min(ctx->qlen, max_subject_len) * std::max(1, ctx->matrix_max) + ((int64_t)1 << 22) + 4096;
     return bound < ((int64_t)1 << 24) ? SW_KIND_F32 : SW_KIND_I32;
@@ -536,9 +538,24 @@ int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstri
     return SW_OK;
 }
 
+int sw_plan_launch(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len, int32_t* effective_kind,
+                   int32_t* rows_per_lane, int32_t* nstripes, int32_t* lanes) {
+    if (!ctx || !kind_launch(kind)) return fail(SW_ERR_INVALID, "null context or unknown kind");
+    if (!ctx->have_query) return fail(SW_ERR_NO_QUERY, "sw_set_query has not been called");
+    if (part_id >= SW_NUM_LENGTH_PARTITIONS || max_subject_len < 0) return fail(SW_ERR_INVALID, "bad partition id or length");
+    kind = effective_kind_of(ctx, kind, max_subject_len);
+    const int ln = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, kind, part_id, n, max_subject_len);
+    const QueryPlan pl = plan_query(kind, ctx->qlen, ln);
+    if (effective_kind) *effective_kind = kind;
+    if (rows_per_lane) *rows_per_lane = pl.rows;
+    if (nstripes) *nstripes = pl.nstripes;
+    if (lanes) *lanes = ln;
+    return SW_OK;
+}
+
 size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0 || n <= 0) return 0;
-    kind = effective_kind(ctx, kind, max_subject_len);
+    kind = effective_kind_of(ctx, kind, max_subject_len);
     const int lanes = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, kind, part_id, n, max_subject_len);
     const QueryPlan pl = plan_query(kind, ctx->qlen, lanes);
     if (pl.nstripes <= 1) return 0;
@@ -555,7 +572,7 @@ int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, c
     if (part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS) return fail(SW_ERR_INVALID, "partition id out of range");
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
     if (!kind_launch(kind)) return fail(SW_ERR_INVALID, "unknown kind");
-    kind = effective_kind(ctx, kind, max_subject_len);
+    kind = effective_kind_of(ctx, kind, max_subject_len);
     return scan_common(ctx, kind, lanes_for_partition(ctx, kind, part_id, n, max_subject_len), chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
                        scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
                        static_cast<hipStream_t>(stream));
@@ -577,7 +594,7 @@ int sw_rescore_overflow_stat(sw_ctx* ctx, int kind, const int32_t* ovf_pos, cons
     if (!ovf_pos || !ovf_count) return fail(SW_ERR_INVALID, "null overflow buffers");
     if (max_count <= 0) return SW_OK;
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
-    kind = effective_kind(ctx, kind, max_subject_len);
+    kind = effective_kind_of(ctx, kind, max_subject_len);
     // grid sized for max_count; the kernel reads the real count on the device (no host round trip,
     // no device-side launch — cf. float_kernels.cuh:1206-1258)
     const int lanes = rescore_lanes(max_subject_len);

@@ -295,6 +295,46 @@ struct Arith<F32> {
 //   letter row  = NCH chunks-rows of 256 bytes: chunk k of lane l at  k*256 + l*16
 //   tile        = 21 letter rows, preceded by 16 bytes (lane addresses carry a +16 bias, see Step)
 // ------------------------------------------------------------------------------------------------
+// How the NW words a lane reads per letter are cut into 16-byte LDS slots ("chunks").  LDS serves ds_read_b128 and
+// ds_read_b96 of this layout (one 16-byte slot per lane, letter rows a multiple of 256 bytes apart) without bank
+// conflicts for ANY mix of letter rows across the groups of a wave, but not ds_read_b32 / ds_read_b64: those are
+// processed 64 / 32 lanes at a time, and the lanes of different groups then meet in the same banks at different
+// addresses (measured on ragged subjects, where the groups read different letters: 11-37 % of the LDS cycles of the
+// NW mod 4 = 1 kernels were conflicts, 4-12 % for NW mod 4 = 2; the identical subjects of the peak DB hid it).  So a
+// word count that is no multiple of 4 is cut into 4-word chunks and one to three 3-WORD chunks (42 = 9 x 4 + 2 x 3,
+// 45 = 9 x 4 + 3 x 3, 43 = 10 x 4 + 3): the same number of reads and of LDS bytes as full chunks plus a short tail, no
+// register holds a word nobody needs (reading the short tail as b96 and dropping a word cost 2.5 % in the 256-VGPR
+// kernels), and every read is conflict-free.  NW = 1, 2, 5 cannot be cut that way: their tail is a b96 read of which
+// one or two words are used.
+template <int NW>
+struct Chunks {
+    static constexpr int kRem = NW % 4;
+    static constexpr int kWant3 = (4 - kRem) % 4;
+    static constexpr bool kSplit = NW >= 3 * kWant3;
+    static constexpr int kN3 = kSplit ? kWant3 : 1;                      // 3-word chunks (not kSplit: ONE partly used one)
+    static constexpr int kN4 = kSplit ? (NW - 3 * kWant3) / 4 : NW / 4;  // 4-word chunks, in front
+    static constexpr int kCount = kN4 + kN3;
+    static constexpr int first(int c) { return c < kN4 ? 4 * c : 4 * kN4 + 3 * (c - kN4); }  // first word of chunk c
+    static constexpr int words(int c) { return c < kN4 ? 4 : (kSplit ? 3 : kRem); }            // words of chunk c in use
+    static constexpr int chunk_of(int w) { return w < 4 * kN4 ? w / 4 : kN4 + (w - 4 * kN4) / 3; }
+    static constexpr bool starts_chunk(int w) { return first(chunk_of(w)) == w; }
+    // progressive reads: `lead` chunks are issued at the top of a step, chunk c + lead when the chain reaches the first
+    // word of chunk c; a word that is consumed `ahead` words before the chain reaches it must have been issued at least
+    // `slack` rows earlier (the LDS latency hides behind them)
+    static constexpr bool lead_ok(int lead, int ahead, int slack) {
+        for (int r = 0; r < NW; r++) {
+            const int need = chunk_of(r + ahead < NW ? r + ahead : NW - 1);
+            if (need >= lead && first(need - lead) + slack > r) return false;
+        }
+        return true;
+    }
+    static constexpr int lead_for(int ahead, int slack) {
+        int lead = 1;
+        while (lead < kCount && !lead_ok(lead, ahead, slack)) lead++;
+        return lead;
+    }
+};
+
 template <int KIND, int R, int LANES = kGroup>
 struct Geometry {
     static constexpr bool kPacked = Arith<KIND>::kPacked;
@@ -303,7 +343,8 @@ struct Geometry {
     // word (an odd R leaves the upper half of the last word unused) and pair the scores with v_perm_b32.
     static constexpr bool kWide = kPacked && LANES <= 16;
     static constexpr int NW = (kPacked && !kWide) ? (R + 1) / 2 : R;
-    static constexpr int NCH = (NW + 3) / 4;
+    using C = Chunks<NW>;
+    static constexpr int NCH = C::kCount;
     // chunk k of lane l at k*kChunkRowBytes + l*16; 8-lane groups keep the 16 slots of a DPP row (slots 8..15 unused:
     // the second group of a row reads the first one's slots, in a later LDS cycle) so that the letter arithmetic is the same
     static constexpr int kChunkRowBytes = (LANES <= 16 ? 16 : LANES) * 16;
@@ -346,24 +387,37 @@ struct ScanParams {
     int32_t stat_limit;        // reference's notion of an overflow (half2_kernels.cuh:1087-1109), for the printed statistic
 };
 
+typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+
+// chunk c of a lane's words for one letter (Chunks<NW>); c folds to a constant in the unrolled callers
+template <int NW, int CHUNK_ROW_BYTES>
+__device__ __forceinline__ void lds_read_chunk(u32 (&dst)[NW], const unsigned char* p, int c) {
+    using C = Chunks<NW>;
+    const int w = C::first(c);
+    if (c < C::kN4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + c * CHUNK_ROW_BYTES);
+        dst[w + 0] = v.x; dst[w + 1] = v.y; dst[w + 2] = v.z; dst[w + 3] = v.w;
+    } else if (c < C::kCount) {
+        const u32x3 v = *reinterpret_cast<const u32x3*>(p + c * CHUNK_ROW_BYTES);
+        if constexpr (C::kSplit) {
+            dst[w + 0] = v.x; dst[w + 1] = v.y; dst[w + 2] = v.z;
+        } else {
+            // NW = 1, 2, 5: one or two of the three words are used.  x passes through an empty asm that also takes the
+            // unused words: a pure data dependency (no ordering against the hand-scheduled step) that keeps the compiler
+            // from narrowing the load to a conflicting ds_read_b32 / b64 again
+            u32 x = v.x;
+            if constexpr (C::kRem == 1) asm("" : "+v"(x) : "v"(v.y), "v"(v.z));
+            if constexpr (C::kRem == 2) asm("" : "+v"(x) : "v"(v.z));
+            dst[w] = x;
+            if constexpr (C::kRem == 2) dst[w + 1] = v.y;
+        }
+    }
+}
+
 template <int NW, int CHUNK_ROW_BYTES>
 __device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned char* p) {
-    constexpr int N4 = NW / 4, REM = NW % 4;
 #pragma unroll
-    for (int k = 0; k < N4; k++) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p + k * CHUNK_ROW_BYTES);
-        dst[4 * k + 0] = v.x; dst[4 * k + 1] = v.y; dst[4 * k + 2] = v.z; dst[4 * k + 3] = v.w;
-    }
-    if constexpr (REM == 1) {
-        dst[4 * N4] = *reinterpret_cast<const u32*>(p + N4 * CHUNK_ROW_BYTES);
-    } else if constexpr (REM == 2) {
-        const uint2 v = *reinterpret_cast<const uint2*>(p + N4 * CHUNK_ROW_BYTES);
-        dst[4 * N4] = v.x; dst[4 * N4 + 1] = v.y;
-    } else if constexpr (REM == 3) {
-        const uint2 v = *reinterpret_cast<const uint2*>(p + N4 * CHUNK_ROW_BYTES);
-        dst[4 * N4] = v.x; dst[4 * N4 + 1] = v.y;
-        dst[4 * N4 + 2] = *reinterpret_cast<const u32*>(p + N4 * CHUNK_ROW_BYTES + 8);
-    }
+    for (int c = 0; c < Chunks<NW>::kCount; c++) lds_read_chunk<NW, CHUNK_ROW_BYTES>(dst, p, c);
 }
 
 // Row classes of the column-offset frame (dp_step<OFFS>): lane-local row r belongs to class r mod P and is kept raised
@@ -401,58 +455,22 @@ constexpr int frame_classes(bool packed, int R, int lanes, bool multi) {
 // the words of two letters, chunk by chunk (A's chunk k, B's chunk k, ...): LDS answers in order, so the first rows'
 // score words arrive after two reads instead of after all of A's
 template <int NW, int CHUNK_ROW_BYTES>
-__device__ __forceinline__ void lds_read_words2(u32 (&da)[NW], u32 (&db)[NW], const unsigned char* pa, const unsigned char* pb) {
-    constexpr int N4 = NW / 4, REM = NW % 4;
-#pragma unroll
-    for (int k = 0; k < N4; k++) {
-        const uint4 va = *reinterpret_cast<const uint4*>(pa + k * CHUNK_ROW_BYTES);
-        const uint4 vb = *reinterpret_cast<const uint4*>(pb + k * CHUNK_ROW_BYTES);
-        da[4 * k + 0] = va.x; da[4 * k + 1] = va.y; da[4 * k + 2] = va.z; da[4 * k + 3] = va.w;
-        db[4 * k + 0] = vb.x; db[4 * k + 1] = vb.y; db[4 * k + 2] = vb.z; db[4 * k + 3] = vb.w;
-        __builtin_amdgcn_sched_barrier(0);  // keep this issue order (the scheduler would sort the reads by register)
-    }
-    if constexpr (REM != 0) {
-        u32 ta[REM], tb[REM];
-        lds_read_words<REM, CHUNK_ROW_BYTES>(ta, pa + N4 * CHUNK_ROW_BYTES);
-        lds_read_words<REM, CHUNK_ROW_BYTES>(tb, pb + N4 * CHUNK_ROW_BYTES);
-#pragma unroll
-        for (int i = 0; i < REM; i++) { da[4 * N4 + i] = ta[i]; db[4 * N4 + i] = tb[i]; }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+__device__ __forceinline__ void lds_read_chunk2(u32 (&da)[NW], u32 (&db)[NW], const unsigned char* pa, const unsigned char* pb, int c) {
+    lds_read_chunk<NW, CHUNK_ROW_BYTES>(da, pa, c);
+    lds_read_chunk<NW, CHUNK_ROW_BYTES>(db, pb, c);
+    __builtin_amdgcn_sched_barrier(0);  // keep this issue order (the scheduler would sort the reads by register)
 }
 
-// one 16-byte chunk (the last one may be shorter) of both letters; k folds to a constant in the unrolled callers
 template <int NW, int CHUNK_ROW_BYTES>
-__device__ __forceinline__ void lds_read_chunk2(u32 (&da)[NW], u32 (&db)[NW], const unsigned char* pa, const unsigned char* pb, int k) {
-    constexpr int N4 = NW / 4, REM = NW % 4;
-    if (k < N4) {
-        const uint4 va = *reinterpret_cast<const uint4*>(pa + k * CHUNK_ROW_BYTES);
-        const uint4 vb = *reinterpret_cast<const uint4*>(pb + k * CHUNK_ROW_BYTES);
-        da[4 * k + 0] = va.x; da[4 * k + 1] = va.y; da[4 * k + 2] = va.z; da[4 * k + 3] = va.w;
-        db[4 * k + 0] = vb.x; db[4 * k + 1] = vb.y; db[4 * k + 2] = vb.z; db[4 * k + 3] = vb.w;
-    } else if (REM != 0 && k == N4) {
-        u32 ta[REM ? REM : 1], tb[REM ? REM : 1];
-        lds_read_words<(REM ? REM : 1), CHUNK_ROW_BYTES>(ta, pa + N4 * CHUNK_ROW_BYTES);
-        lds_read_words<(REM ? REM : 1), CHUNK_ROW_BYTES>(tb, pb + N4 * CHUNK_ROW_BYTES);
+__device__ __forceinline__ void lds_read_words2(u32 (&da)[NW], u32 (&db)[NW], const unsigned char* pa, const unsigned char* pb) {
 #pragma unroll
-        for (int i = 0; i < REM; i++) { da[4 * N4 + i] = ta[i]; db[4 * N4 + i] = tb[i]; }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep this issue order (the scheduler would sort the reads by register)
+    for (int c = 0; c < Chunks<NW>::kCount; c++) lds_read_chunk2<NW, CHUNK_ROW_BYTES>(da, db, pa, pb, c);
 }
 
 // the same for one letter (32-bit kinds)
 template <int NW, int CHUNK_ROW_BYTES>
-__device__ __forceinline__ void lds_read_chunk1(u32 (&da)[NW], const unsigned char* pa, int k) {
-    constexpr int N4 = NW / 4, REM = NW % 4;
-    if (k < N4) {
-        const uint4 va = *reinterpret_cast<const uint4*>(pa + k * CHUNK_ROW_BYTES);
-        da[4 * k + 0] = va.x; da[4 * k + 1] = va.y; da[4 * k + 2] = va.z; da[4 * k + 3] = va.w;
-    } else if (REM != 0 && k == N4) {
-        u32 ta[REM ? REM : 1];
-        lds_read_words<(REM ? REM : 1), CHUNK_ROW_BYTES>(ta, pa + N4 * CHUNK_ROW_BYTES);
-#pragma unroll
-        for (int i = 0; i < REM; i++) da[4 * N4 + i] = ta[i];
-    }
+__device__ __forceinline__ void lds_read_chunk1(u32 (&da)[NW], const unsigned char* pa, int c) {
+    lds_read_chunk<NW, CHUNK_ROW_BYTES>(da, pa, c);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -492,9 +510,17 @@ struct StripeState {
 template <int KIND, int R, int LANES, int BYTE, bool MULTI, bool OFFS = false, int P = 1>
 __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsigned char* tile,
                                         u32 lettersA, u32 lettersB, u32 gop, u32 gex, u32 inH, u32 inF,
-                                        u32 apos = 0, bool first = false, u32 wrapP = 0, u32 wrapLast = 0, bool head = false) {
+                                        u32 apos = 0, bool first = false, u32 wrapP = 0, u32 wrapLast = 0, bool head = false,
+                                        u32 laneStep = 0) {
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
+    // what a lane adds to the LDS address it receives: one 16-byte slot.  8-lane groups: the second group of a DPP row
+    // works in slots 8..15 of the chunk row (the profile builder fills them with a copy), so its head lane adds 128 bytes
+    // more — a per-lane constant (laneStep) in place of the literal, no instruction more.  With both groups in slots
+    // 0..7 they met in the same banks with different letter rows: every second LDS cycle of the 8-lane kernels was a
+    // conflict on ragged subjects.
+    const u32 step2 = LANES == 8 ? laneStep : 0x00100010u;
+    const u32 step1 = LANES == 8 ? laneStep : 16u;
     constexpr u32 kSel = 0x0c0c000cu | ((u32)BYTE << 8);  // letter byte BYTE -> bits 15:8
     constexpr int kPostShift = G::kLetterShift - 8;        // row offset = byte << kLetterShift
 
@@ -510,15 +536,15 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         // both LDS addresses (< 64 KB) travel in one register: one permute, one DPP move and one add for the pair
         constexpr u32 kSel2 = ((u32)(4 + BYTE) << 24) | 0x000c000cu | ((u32)BYTE << 8);  // B's byte -> 31:24, A's -> 15:8
         const u32 inj = __builtin_amdgcn_perm(lettersB, lettersA, kSel2);
-        st.yA = prev_lane<LANES, false>(inj, st.yA, head) + 0x00100010u;
+        st.yA = prev_lane<LANES, false>(inj, st.yA, head) + step2;
         if constexpr (!OFFS) lds_read_words2<G::NW, G::kChunkRowBytes>(wa, wb, tile + (st.yA & 0xffffu), tile + (st.yA >> 16));
     } else {
         const u32 injA = __builtin_amdgcn_perm(0u, lettersA, kSel) << kPostShift;
-        st.yA = prev_lane<LANES, false>(injA, st.yA, head) + 16u;
+        st.yA = prev_lane<LANES, false>(injA, st.yA, head) + step1;
         if constexpr (A::kPacked || !OFFS || !kProgScalar) lds_read_words<G::NW, G::kChunkRowBytes>(wa, tile + st.yA);
         if constexpr (A::kPacked) {
             const u32 injB = __builtin_amdgcn_perm(0u, lettersB, kSel) << kPostShift;
-            st.yB = prev_lane<LANES, false>(injB, st.yB, head) + 16u;
+            st.yB = prev_lane<LANES, false>(injB, st.yB, head) + step1;
             lds_read_words<G::NW, G::kChunkRowBytes>(wb, tile + st.yB);
         }
     }
@@ -573,7 +599,12 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         // ... and the LDS reads themselves are issued progressively: the chunks the first kAhead + 4 rows need at the top
         // of the step, chunk k + kChunks0 when the chain reaches row 4k — a few chunks are in flight instead of all
         // (2R registers), which is what lets R go up to 48
-        constexpr int kChunks0 = kAhead / 4 + 1, kChunksAll = (G::NW + 3) / 4;
+        using CH = Chunks<G::NW>;
+        constexpr int kChunksAll = CH::kCount;
+        // with full chunks: the chunks of the first kAhead + 4 rows at the top (a read is issued at least four rows before
+        // its first word is used), as many more as it takes where 3-word chunks shift the rows
+        constexpr int kChunks0 = G::kWide ? CH::lead_for(kAhead, 4) : 1;
+        static_assert(!G::kWide || kChunks0 >= kChunksAll || CH::lead_ok(kChunks0, kAhead, 4), "a score word would be used before its read is issued");
         const unsigned char* const pa = tile + (st.yA & 0xffffu);
         const unsigned char* const pb = tile + (st.yA >> 16);
         u32 tq[G::kWide ? R : 1];
@@ -584,10 +615,12 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
             for (int r = 0; r < kAhead; r++) tq[r] = A::add_pair(wa[r], wb[r], r == 0 ? diag : st.H[r - 1]);
         }
         constexpr bool kProg1 = !A::kPacked && kProgScalar;
-        constexpr int kChunks0S = 2;  // rows 0..7 at the top of the step, chunk k + 2 when the chain reaches row 4k
+        // the score of row r + 2 is picked up when the chain is at row r: rows 0..7 at the top of the step when the chunks
+        // are full ones, the chunk after those when the chain reaches a chunk's first row
+        constexpr int kChunks0S = kProg1 ? CH::lead_for(2, 6) : 1;
         if constexpr (kProg1) {
 #pragma unroll
-            for (int k = 0; k < kChunks0S && k < (G::NW + 3) / 4; k++) lds_read_chunk1<G::NW, G::kChunkRowBytes>(wa, tile + st.yA, k);
+            for (int k = 0; k < kChunks0S && k < kChunksAll; k++) lds_read_chunk1<G::NW, G::kChunkRowBytes>(wa, tile + st.yA, k);
         }
         u32 s_next = score(0);
         u32 t_next = G::kWide ? 0u : diag_term(0, diag, s_next);
@@ -597,17 +630,15 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
             const int c = r % P;
             const u32 zop = st.Zc[Q + c + 1];
             if constexpr (G::kWide) {
-                if (r % 4 == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (r / 4 + kChunks0 < kChunksAll) lds_read_chunk2<G::NW, G::kChunkRowBytes>(wa, wb, pa, pb, r / 4 + kChunks0);
-                }
+                if (r % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                if (CH::starts_chunk(r) && CH::chunk_of(r) + kChunks0 < kChunksAll)
+                    lds_read_chunk2<G::NW, G::kChunkRowBytes>(wa, wb, pa, pb, CH::chunk_of(r) + kChunks0);
                 t_next = tq[r];
             }
             if constexpr (kProg1) {
-                if (r % 4 == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (r / 4 + kChunks0S < (G::NW + 3) / 4) lds_read_chunk1<G::NW, G::kChunkRowBytes>(wa, tile + st.yA, r / 4 + kChunks0S);
-                }
+                if (r % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                if (CH::starts_chunk(r) && CH::chunk_of(r) + kChunks0S < kChunksAll)
+                    lds_read_chunk1<G::NW, G::kChunkRowBytes>(wa, tile + st.yA, CH::chunk_of(r) + kChunks0S);
             }
             const u32 t = t_next;
             const u32 h = A::cell_h(t, st.E[r], F);
@@ -743,6 +774,12 @@ constexpr int border_region_words(int lcap) { return (border_junk_words<LANES>()
 #ifndef SWK_I32_WAVES3_MAX_R_MULTI
 #define SWK_I32_WAVES3_MAX_R_MULTI 32
 #endif
+#ifndef SWK_F32_WAVES3_MAX_R
+#define SWK_F32_WAVES3_MAX_R 48
+#endif
+#ifndef SWK_F32_WAVES3_MAX_R_MULTI
+#define SWK_F32_WAVES3_MAX_R_MULTI 48
+#endif
 template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
     // packed kinds: 2 waves/SIMD (256 VGPRs) for the tall kernels; up to SWK_WAVES3_MAX_R rows a third wave is asked for
@@ -753,6 +790,7 @@ constexpr int min_waves() {
     // co-issue anyway).  Up to 32 rows the third wave is worth more than the spills it causes in the multi-stripe kernels
     // from R = 24 up (two-stripe queries of 850 / 1000 residues: 6.36 / 6.42 with three waves, 6.12 / 6.22 TCUPS with two)
     if (KIND == I32 && LANES <= 16 && R > (MULTI ? SWK_I32_WAVES3_MAX_R_MULTI : SWK_I32_WAVES3_MAX_R)) return 2;
+    if (KIND == F32 && LANES <= 16 && R > (MULTI ? SWK_F32_WAVES3_MAX_R_MULTI : SWK_F32_WAVES3_MAX_R)) return 2;
     // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
     return (R <= 16 && !MULTI && LANES <= 16) ? 4 : 3;
 }
@@ -772,6 +810,9 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     const int lane = tid & (LANES - 1);  // position in the alignment group
     const int group = tid / LANES;
     const bool head = lane == 0;
+    // 8-lane groups: the two groups of a DPP row use the two halves of the row's 16 profile slots (dp_step: laneStep)
+    const int slot = LANES == 8 ? (tid & 15) : lane;
+    const u32 laneStep = (A::kPacked ? 0x00100010u : 16u) * ((LANES == 8 && (tid & 15) == 8) ? 9u : 1u);
     const int n = p.count_ptr ? *p.count_ptr : p.n;
     constexpr int kSubjPerBatch = kGroups * A::kSubjects;
     const int nbatches = (n + kSubjPerBatch - 1) / kSubjPerBatch;
@@ -865,7 +906,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 #pragma unroll
                 for (int d = 0; d < P + 3; d++) st.maxv[d] = OFFS ? A::add(maxv, zc[A::kWindow ? d + 1 : d]) : maxv;
             }
-            st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(lane + 1);
+            st.yA = ((u32)(kPadLetter * G::kLetterUnits) << G::kLetterShift) + 16u * (u32)(slot + 1);
             st.yB = st.yA;
             if constexpr (A::kPacked && LANES <= 16) st.yA |= st.yA << 16;  // (address for subject B, address for subject A)
 
@@ -926,16 +967,16 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     for (int d = 0; d < P + 3; d++) st.maxv[d] = A::gap(st.maxv[d], gw);
                 };
                 if constexpr (LOWER) lower_frame(lower_lane + 0);
-                dp_step<KIND, R, LANES, 0, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first, p.wrap_class, p.wrap_last, head);
+                dp_step<KIND, R, LANES, 0, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
                 if constexpr (MULTI) { bh0 = st.Hlast; bf0 = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 1);
-                dp_step<KIND, R, LANES, 1, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first, p.wrap_class, p.wrap_last, head);
+                dp_step<KIND, R, LANES, 1, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
                 if constexpr (MULTI) { bh1 = st.Hlast; bf1 = st.Fout; *reinterpret_cast<uint4*>(outHF) = make_uint4(bh0, bf0, bh1, bf1); }
                 if constexpr (LOWER) lower_frame(lower_lane + 2);
-                dp_step<KIND, R, LANES, 2, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first, p.wrap_class, p.wrap_last, head);
+                dp_step<KIND, R, LANES, 2, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
                 if constexpr (MULTI) { bh2 = st.Hlast; bf2 = st.Fout; }
                 if constexpr (LOWER) lower_frame(lower_lane + 3);
-                dp_step<KIND, R, LANES, 3, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first, p.wrap_class, p.wrap_last, head);
+                dp_step<KIND, R, LANES, 3, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
                 if constexpr (MULTI) { *reinterpret_cast<uint4*>(outHF + 4) = make_uint4(bh2, bf2, st.Hlast, st.Fout); outHF += walkOut; }
                 lettersA = dpp<SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
@@ -1051,9 +1092,9 @@ __global__ void sw_build_profile_kernel(const int8_t* __restrict__ query, int32_
         const int letter = (int)((i / kWordsPerRow) % kLetters);
         const int stripe = (int)(i / ((size_t)kWordsPerRow * kLetters));
         const int chunk = word / kWordsPerChunkRow, lane = ((word % kWordsPerChunkRow) / 4) % LANES, sub = word % 4;
-        const int w = chunk * 4 + sub;  // word index within the lane's NW words
+        const int w = G::C::first(chunk) + sub;  // word index within the lane's NW words (Chunks: 4- and 3-word chunks)
         u32 v = 0;
-        if (w < G::NW) {
+        if (sub < G::C::words(chunk) && w < G::NW) {
             auto entry = [&](int row_in_lane) -> u32 {
                 if (row_in_lane >= R) return 0u;  // unused upper half of an odd R's last word
                 const int64_t row = (int64_t)stripe * G::kStripeRows + lane * R + row_in_lane;

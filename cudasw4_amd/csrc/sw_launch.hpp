@@ -19,7 +19,10 @@ constexpr int kMaxRowsPacked = SWK_MAX_ROWS_PACKED;  // stripe = 768 query rows,
 #define SWK_MAX_ROWS_SCALAR 36
 #endif
 constexpr int kMaxRowsScalar = SWK_MAX_ROWS_SCALAR;  // fp32: its add/max3 co-issue wants three waves per SIMD: a single stripe up to 576 query rows (47 KB tile, three workgroups per CU; the 567-residue query 7.55 -> 8.71 TCUPS against two stripes of 18 rows), several stripes up to 32 rows per lane (kMaxRowsScalarMulti)
-constexpr int kMaxRowsScalarMulti = 32;
+#ifndef SWK_MAX_ROWS_SCALAR_MULTI
+#define SWK_MAX_ROWS_SCALAR_MULTI 32
+#endif
+constexpr int kMaxRowsScalarMulti = SWK_MAX_ROWS_SCALAR_MULTI;
 #ifndef SWK_MAX_ROWS_I32
 #define SWK_MAX_ROWS_I32 48
 #endif

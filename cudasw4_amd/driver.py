@@ -229,20 +229,23 @@ class Driver:
         _check(lib.swdrv_record_kernel_events(self.handle, int(on)))
 
     def take_kernel_events(self):
-        """-> list of dicts (gpu, kind, part_id, qlen, subjects, cells, chars, ms, t0_ms, t1_ms), HIP-event timed
-        launches; t0/t1: begin and end on the device clock since recording was switched on."""
+        """-> list of dicts (gpu, kind, part_id, qlen, subjects, cells, chars, ms, t0_ms, t1_ms, eff_kind, rows,
+        nstripes, lanes), HIP-event timed launches; t0/t1: begin and end on the device clock since recording was
+        switched on; the last four name the kernel instantiation."""
         cap = 16384
         while True:
-            buf = np.zeros(cap * 10, dtype=np.float64)
+            buf = np.zeros(cap * 14, dtype=np.float64)
             n = lib.swdrv_take_kernel_events(self.handle, buf.ctypes.data, cap)
             if n < 0:
                 raise DriverError(lib.swdrv_last_error().decode())
             if n <= cap:
                 break
             raise DriverError("more than %d kernel events between two takes" % cap)
-        keys = ("gpu", "kind", "part_id", "qlen", "subjects", "cells", "chars", "ms", "t0_ms", "t1_ms")
-        return [dict(zip(keys, (int(v) if k in ("gpu", "kind", "part_id", "qlen", "subjects") else float(v)
-                                for k, v in zip(keys, buf[10 * i:10 * i + 10])))) for i in range(n)]
+        keys = ("gpu", "kind", "part_id", "qlen", "subjects", "cells", "chars", "ms", "t0_ms", "t1_ms", "eff_kind", "rows",
+                "nstripes", "lanes")
+        floats = ("cells", "chars", "ms", "t0_ms", "t1_ms")
+        return [dict(zip(keys, (float(v) if k in floats else int(v) for k, v in zip(keys, buf[14 * i:14 * i + 14]))))
+                for i in range(n)]
 
     def shard_info(self, gpu=0):
         i64 = ctypes.c_int64

@@ -168,6 +168,13 @@ int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int
  * table the same way, half2_kernels.cuh:243-261), so a foreign or corrupt DB yields garbage scores: check, then refuse. */
 int sw_check_letter_codes(sw_ctx* ctx, const int8_t* chars, size_t n, int32_t* bad_flag, void* stream);
 
+/* Introspection for measurement: which kernel instantiation sw_scan_partition (part_id >= 0) or sw_rescore_overflow
+ * (part_id = -1) would launch for the CURRENT query: the arithmetic kind actually computed in (SW_KIND_I32 may be served
+ * in fp32 lanes, see SW_KIND_I32), rows per lane, query stripes and lanes per alignment group (8 | 16 | 64) — the
+ * template arguments of swk::sw_scan_kernel as rocprofv3 prints them.  Any output pointer may be NULL. */
+int sw_plan_launch(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len,
+                   int32_t* effective_kind, int32_t* rows_per_lane, int32_t* nstripes, int32_t* lanes);
+
 /* Introspection for tests / tuning: rows per lane and number of query stripes chosen for qlen. */
 int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstripes);
 

@@ -68,10 +68,11 @@ int swdrv_scan_collect(swdrv* d, int32_t* scores, int64_t* ids, int cap, int* nr
 int swdrv_in_flight(swdrv* d);
 
 /* ---- measurement / verification hooks (bench.py, tests) ----
- * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 10 doubles per launch
- * (gpu index, kind, part_id, query length, subjects, cells, padded subject bytes, milliseconds, begin ms, end ms — the
- * last two on the device clock since recording was switched on: launches on different streams overlap, the union of the
- * intervals is the time the DP kernels kept the GPU busy); returns the number of launches recorded since the last call
+ * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 14 doubles per launch
+ * (gpu index, kind, part_id, query length, subjects, cells, padded subject bytes, milliseconds, begin ms, end ms — these
+ * two on the device clock since recording was switched on: launches on different streams overlap, the union of the
+ * intervals is the time the DP kernels kept the GPU busy — and the kernel instantiation: kind computed in, rows per lane,
+ * query stripes, lanes per group); returns the number of launches recorded since the last call
  * (may exceed cap), -1 on error. */
 int swdrv_record_kernel_events(swdrv* d, int on);
 int swdrv_take_kernel_events(swdrv* d, double* out, int cap);

@@ -111,3 +111,52 @@ def test_synthetic_sprot_like_db_layout():
     a = synthdb.sprot_like(2000)
     b = synthdb.sprot_like(2000)
     assert all((x == y).all() for x, y in zip(a, b))
+
+
+def test_union_of_launch_intervals():
+    b = load_bench()
+    assert b.union_ms([]) == 0.0
+    assert b.union_ms([(0.0, 2.0), (1.0, 3.0), (5.0, 6.0)]) == 4.0          # overlap counted once, gap not at all
+    assert b.union_ms([(5.0, 6.0), (0.0, 10.0)]) == 10.0                    # a launch inside another
+    assert b.union_ms([(0.0, 1.0), (1.0, 2.0), (2.0, 3.0)]) == 3.0          # a sequence of batches adds up
+
+
+def fake_event(kind, rows, lanes, nstripes, t0, t1, chars, qlen=512, eff=None):
+    n = chars // 512
+    return {"gpu": 0, "kind": kind, "part_id": 21, "qlen": qlen, "subjects": n, "cells": float(qlen) * chars, "chars": float(chars),
+            "ms": t1 - t0, "t0_ms": t0, "t1_ms": t1, "eff_kind": kind if eff is None else eff, "rows": rows, "nstripes": nstripes,
+            "lanes": lanes}
+
+
+def test_roofline_accounting_of_sequential_and_overlapping_launches(monkeypatch):
+    """A streamed scan is a SEQUENCE of batch launches (round 2 counted it with its longest launch and reported a VALU
+    fraction of 2.457); launches on different streams overlap.  The kernels' own rate is cells / the union of the
+    intervals, the HBM traffic of a launch scales with its subject bytes, and no fraction can exceed 1 by construction
+    when the per-cell instruction count is the measured one."""
+    b = load_bench()
+    args = b.parse_args(["--steps", "1"])
+    counters = {"kernel_src_sha16": "x",
+                "valu_instr_per_unit": {"peak:half2:resident": {"value": 6.3, "source": "profiles/fake_pmc.txt"}},
+                "traffic_bytes_per_char": {"sw_scan_kernel<0, 43, 16, true,": {"value": 60.0, "nstripes": [8], "source": "profiles/fake_pmc.txt"}}}
+    monkeypatch.setattr(b, "load_counters", lambda: (counters, None))
+    # four 128 MB batches one after the other, 64 ms each, at the rate of a VALU-bound kernel (~11.5 TCUPS at qlen 5478)
+    batch = 128 << 20
+    ev = [fake_event(0, 43, 16, 8, 64.0 * i, 64.0 * (i + 1), batch, qlen=5478) for i in range(4)]
+    # a long-subject launch on an auxiliary stream next to the first batch: overlaps, adds cells but no busy time
+    ev.append(fake_event(3, 8, 64, 11, 0.0, 40.0, 1 << 20, qlen=5478))
+    roof, valu, table = b.roofline_objects(args, "peak", "half2", ev, {"resident": False, "cached_chars": 0, "chars": 4 * batch})
+    assert valu["kernel_busy_ms_per_step"] == 256.0
+    cells = sum(e["cells"] for e in ev)
+    assert abs(valu["kernel_gcups"] - cells / 1e9 / 0.256) < 1.0
+    assert 0 < valu["frac"] <= 1.0 and valu["counters_key"] == "peak:half2:resident"   # falls back to the resident figure
+    assert roof["launches"] == 4 and roof["kernel"].startswith("sw_scan_kernel<f16x2, R=43, 16 lanes, multi")
+    assert roof["traffic"] == int(60.0 * batch)      # per subject byte x THIS launch's subject bytes
+    assert 0 < roof["frac"] < 1e-2
+    assert len(table) == 2 and sum(k["launches"] for k in table) == 5
+    # other stripes than the counter was measured with: no figure rather than a wrong one
+    ev2 = [fake_event(0, 43, 16, 4, 0.0, 10.0, batch, qlen=2700)]
+    roof2, _, _ = b.roofline_objects(args, "peak", "half2", ev2, {"resident": True, "cached_chars": batch, "chars": batch})
+    assert roof2["traffic"] is None and "no PMC traffic figure" in roof2["traffic_note"]
+    # a configuration without a counter entry reports null, never a borrowed number
+    _, valu3, _ = b.roofline_objects(args, "peak", "float", ev2, {"resident": True, "cached_chars": batch, "chars": batch})
+    assert valu3["frac"] is None and "peak:float:resident" in valu3["counters_note"]

@@ -161,6 +161,31 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
     assert weak["config"]["db_subjects"] == 400000
 
 
+def test_bench_eight_ranks_on_one_gpu_default_line():
+    """What the first real 8-GPU scaling run will execute — `bench.py --gpus 8`, default flags: eight ranks (here all on
+    GPU 0, gloo), ONE 10^6 x 512 DB in eight shards, every score of every rank verified, the merged top-10 equal to the
+    1-rank line's, the weak-scaling run and the Swiss-Prot-like workload in the same line."""
+    hooks = {"BENCH_FORCE_DEVICE": "0", "BENCH_DIST_BACKEND": "gloo"}
+    one = run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"])
+    out = run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0"], hooks)
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["verified"] is True
+    assert out["config"]["db_subjects"] == 1_000_000
+    assert out["config"]["top_merged_example"] == one["config"]["top_merged_example"]
+    assert out["weak_scaling"]["verified"] is True and out["weak_scaling"]["config"]["db_subjects"] == 8_000_000
+    assert out["sprot_like"]["verified"] is True and out["sprot_like"]["config"]["db_subjects"] == 570000
+    assert out["cpu_baseline"] is None  # rank 0 times the CPU leg at N = 1 only
+
+
+def test_bench_rank_failure_fails_the_job():
+    """A rank that dies takes the job down: the parent (which started the ranks as fresh child processes before touching
+    the GPU) exits non-zero and prints no result line."""
+    env = dict(os.environ, BENCH_FORCE_DEVICE="0", BENCH_DIST_BACKEND="gloo", BENCH_FAIL_RANK="2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0",
+                        "--db-size", "50000", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_two_rank_default_line_carries_weak_scaling_and_sprot_like():
     """The default multi-rank line: strong scaling headline + the weak-scaling run + the Swiss-Prot-like workload."""
     hooks = {"BENCH_FORCE_DEVICE": "0", "BENCH_DIST_BACKEND": "gloo"}
@@ -202,3 +227,64 @@ def test_bench_sprot_like_workload_small():
                      "--cpu-sample-subjects", "400"])
     assert out["verified"] is True and out["dtype"] == "i16x2" and out["cpu_baseline"]["value"] > 0
     assert out["roofline"]["achieved"] > 0 and out["value"] > 0
+
+
+def test_bench_real_db_switch(tmp_path):
+    """`bench.py --db-prefix P` / $CUDASW4_SPROT_PREFIX (runsprotbenchmark.sh:18-51): the sprot-like leg runs on a real
+    DB made by `makedb` — here a 50 000-sequence FASTA — instead of the synthetic stand-in, says so in `data`, and
+    its scores are verified against the CPU oracle on a sample of the same files."""
+    from cudasw4_amd import driver, synthdb
+    lengths = synthdb.sprot_like_lengths(50000, seed=41, max_len=12000)
+    chars, offsets, lengths = synthdb.random_db(lengths, seed=42, other_fraction=0.005)
+    alphabet = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVX", dtype=np.uint8)
+    fasta = tmp_path / "db.fasta"
+    rng = np.random.default_rng(43)
+    order = rng.permutation(len(lengths))   # makedb sorts by length itself
+    with open(fasta, "wb") as f:
+        for i in order:
+            s = alphabet[chars[int(offsets[i]):int(offsets[i]) + int(lengths[i])]]
+            f.write(b">seq%d some header\n" % i)
+            f.write(s.tobytes() + b"\n")
+    prefix = str(tmp_path / "realdb")
+    p = subprocess.run([driver.MAKEDB, str(fasta), prefix], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = run_bench(["--workload", "sprot-like", "--db-prefix", prefix, "--steps", "1", "--warmup", "0", "--cpu-sample-subjects", "300"])
+    assert out["data"] == "real" and out["verified"] is True and out["config"]["db_subjects"] == 50000
+    assert out["config"]["db_residues"] == int(lengths.astype(np.int64).sum()) and prefix in out["config"]["workload"]
+    assert out["cpu_baseline"]["value"] > 0 and out["dtype"] == "i16x2"
+    # the default command picks the prefix up from the environment for its secondary leg
+    out = run_bench(["--steps", "1", "--warmup", "0", "--db-size", "100000", "--no-cpu-baseline"], {"CUDASW4_SPROT_PREFIX": prefix})
+    assert out["data"] == "synthetic" and out["sprot_like"]["data"] == "real" and out["sprot_like"]["verified"] is True
+    assert out["sprot_like"]["config"]["db_subjects"] == 50000
+
+
+@pytest.mark.parametrize("extra,kernel,residency", [([], "half2", "resident"), (["--max-gpu-mem", "600M"], "half2", "hybrid"),
+                                                    (["--kernel", "float"], "float", "resident"),
+                                                    (["--kernel", "dpxs32"], "dpxs32", "resident"),
+                                                    (["--kernel", "dpxs32", "--max-gpu-mem", "600M"], "dpxs32", "hybrid")])
+def test_bench_roofline_is_true_for_every_configuration(extra, kernel, residency):
+    """The accounting behind `roofline` / `valu_roofline` (a streamed line reported frac 2.457): the DP
+    kernels' busy time (union of the HIP-event intervals) fits the timed region, their own rate is at least the
+    whole-job rate and below what the chip can issue, the traffic figure is scaled to the launch, and the VALU fraction
+    — present whenever profiles/kernel_counters.json was measured on these kernel sources — lies in (0, 1]."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    out = run_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"] + extra)
+    assert out["verified"] is True and out["config"]["kernel"] == kernel and out["config"]["residency"] == residency
+    roof, valu = out["roofline"], out["valu_roofline"]
+    assert 0 < valu["kernel_busy_ms_per_step"] <= out["ms_per_step"] * 1.001
+    assert out["value"] <= valu["kernel_gcups"] * 1.001
+    assert valu["kernel_gcups"] < (13500 if kernel == "half2" else 10500)
+    assert 0 < roof["frac"] < 0.01 and roof["achieved"] > 0
+    if residency == "hybrid":
+        assert 0 < out["config"]["cached_chars"] < out["config"]["shard_chars"]
+        assert roof["algorithmic_bytes_per_launch"] < 400e6     # a batch or the cached part, not the whole DB
+    counters, _ = b.load_counters()
+    if counters is not None:
+        assert valu["frac"] is not None and 0 < valu["frac"] <= 1.0, valu
+        if roof["traffic"] is not None:
+            assert roof["traffic"] >= 0.9 * roof["algorithmic_bytes_per_launch"]
+    else:
+        assert valu["frac"] is None and "kernel_counters.json" in valu["counters_note"]

@@ -69,10 +69,17 @@ def traffic(fetch_db, write_db):
 
 
 def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
-    """profiles/kernel_counters.json for bench.py: VALU lane-instructions per useful cell (pair) over one pass of the
-    workload (SQ_INSTS_VALU x 64 over all DP launches / cells of the pass) and the HBM traffic per launch of the dominant
-    DP kernel, tied to the sha of the kernel sources they were measured on.  `bench_log` holds the JSON line of the
-    profiled command (bench.py --steps 1 --warmup 0 --no-verify --no-cpu-baseline: exactly one pass)."""
+    """profiles/kernel_counters.json for bench.py, from one profiled pass of a bench.py command
+    (`--steps 1 --warmup 0 --no-verify --no-cpu-baseline --no-secondary --kernel-table`: exactly one pass, and the line
+    carries the per-kernel table of that pass):
+
+    * valu_instr_per_unit[workload:kernel configuration:residency]: VALU lane-instructions per useful cell (pair) over
+      the pass = SQ_INSTS_VALU x 64 over all DP launches / cells of the pass;
+    * traffic_bytes_per_char[kernel instantiation]: HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, in KB, corrected as
+      MI355X_MICROARCH.md prescribes for gfx950) over all launches of the instantiation / the subject bytes those
+      launches read (from the line's table) — bench.py scales it by the subject bytes of ITS launches.
+
+    Every entry names its own source file; the whole file is tied to the sha of the kernel sources."""
     import hashlib
     import json
     import os
@@ -81,10 +88,11 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
     line = [l for l in open(bench_log).read().splitlines() if l.startswith("{")][-1]
     b = json.loads(line)
     workload = b["config"]["workload"].split(":")[0]
-    dtype = b["dtype"]
-    sum_q = int(re.search(r"\((\d+) queries, (\d+) residues\)", b["config"]["workload"]).group(2))
-    cells = float(sum_q) * float(b["config"]["db_residues"]) * (b["steps"] + b["warmup"])
-    packed = dtype in ("f16x2", "i16x2")
+    kernel_cfg = b["config"]["kernel"]
+    residency = b["config"]["residency"]
+    native = ":i32native" if os.environ.get("CUDASW4_AMD_I32_NATIVE") == "1" else ""
+    packed = b["dtype"].split()[0] in ("f16x2", "i16x2")
+    cells = sum(k["cells"] for k in b["kernels"])
     db = sqlite3.connect(valu_db)
     insts = sum(v for (v,) in db.execute(
         "select value from counters_collection where counter_name = 'SQ_INSTS_VALU' and kernel_name like '%sw_scan_kernel%'"))
@@ -98,42 +106,42 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
     for rel in ("cudasw4_amd/csrc/sw_dp_kernel.hpp", "cudasw4_amd/csrc/sw_launch.hpp", "cudasw4_amd/csrc/sw_api.hip", "cudasw4_amd/csrc/Makefile"):
         h.update(open(os.path.join(root, rel), "rb").read())
     sha = h.hexdigest()[:16]
-    if cur.get("kernel_src_sha16") != sha:
-        cur = {"kernel_src_sha16": sha, "valu_instr_per_unit": {}, "traffic_bytes_per_launch": {}}
-    cur["commit"] = commit
-    cur["source"] = source
-    cur["valu_instr_per_unit"]["%s:%s" % (workload, dtype)] = round(ipu, 3)
+    if cur.get("kernel_src_sha16") != sha or "traffic_bytes_per_char" not in cur:
+        cur = {"kernel_src_sha16": sha, "valu_instr_per_unit": {}, "traffic_bytes_per_char": {}}
+    key = "%s:%s:%s%s" % (workload, kernel_cfg, residency, native)
+    cur["valu_instr_per_unit"][key] = {"value": round(ipu, 3), "unit": "lane-instructions per cell pair" if packed else "lane-instructions per cell",
+                                       "source": source, "commit": commit}
 
-    def mean_per_kernel(path, counter):
-        acc = defaultdict(lambda: [0, 0.0, 0.0])
-        for name, value, dur in sqlite3.connect(path).execute(
-                "select kernel_name, value, duration from counters_collection where counter_name = ?", (counter,)):
+    def sum_per_kernel(path, counter):
+        acc = defaultdict(lambda: [0, 0.0])
+        for name, value in sqlite3.connect(path).execute(
+                "select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
             if "sw_scan_kernel" in name:
-                a = acc[name]
-                a[0] += 1
-                a[1] += value
-                a[2] += dur
+                acc[name][0] += 1
+                acc[name][1] += value
         return acc
 
-    f = mean_per_kernel(fetch_db, "FETCH_SIZE")
-    w = mean_per_kernel(write_db, "WRITE_SIZE")
+    f = sum_per_kernel(fetch_db, "FETCH_SIZE")
+    w = sum_per_kernel(write_db, "WRITE_SIZE")
+    table = {k["kernel"].replace(" *>", ""): k for k in b["kernels"]}
     detail = {}
     for name in f:
-        m = re.search(r"sw_scan_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", name)
-        if not m:
+        m = re.search(r"(sw_scan_kernel<\d+, \d+, \d+, (?:true|false),)", name)
+        if not m or m.group(1) not in table:
             continue
-        kind = ["f16x2", "i16x2", "i32", "f32"][int(m.group(1))]
-        fetch_kb = f[name][1] / f[name][0]
-        write_kb = w[name][1] / w[name][0] if name in w else 0.0
+        t = table[m.group(1)]
+        if t["launches"] != f[name][0] or t["chars"] <= 0:
+            continue  # another form of the recurrence shares the prefix, or the passes differ: no figure rather than a wrong one
         # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports by 2x on gfx950
-        key = "%s:%s:R%s" % (workload, kind, m.group(2))
-        tr = int((2.0 * fetch_kb + write_kb) * 1024)
-        if m.group(3) == "16":
-            cur["traffic_bytes_per_launch"][key] = tr
-        detail[name] = {"launches": f[name][0], "fetch_kb_raw_mean": fetch_kb, "write_kb_mean": write_kb, "traffic_bytes_per_launch": tr,
-                        "avg_launch_ns_under_pmc": f[name][2] / f[name][0]}
-    json.dump(cur, open(out_path, "w"), indent=1)
-    print(json.dumps({"kernel_counters": cur, "valu_wave_instructions": insts, "cells": cells, "per_kernel_traffic": detail}, indent=1))
+        total = (2.0 * f[name][1] + (w[name][1] if name in w else 0.0)) * 1024
+        cur["traffic_bytes_per_char"][m.group(1)] = {"value": round(total / t["chars"], 4), "nstripes": t["nstripes"],
+                                                     "launches": t["launches"], "chars_per_launch": int(t["chars"] / t["launches"]),
+                                                     "source": source, "commit": commit}
+        detail[name] = {"launches": f[name][0], "fetch_kb_raw_sum": f[name][1], "write_kb_sum": w[name][1] if name in w else 0.0,
+                        "traffic_bytes": int(total), "subject_bytes": t["chars"]}
+    json.dump(cur, open(out_path, "w"), indent=1, sort_keys=True)
+    print(json.dumps({"key": key, "valu_instr_per_unit": round(ipu, 3), "valu_wave_instructions": insts, "cells": cells,
+                      "per_kernel_traffic": detail}, indent=1))
 
 
 if __name__ == "__main__":
