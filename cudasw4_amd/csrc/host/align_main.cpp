@@ -86,7 +86,7 @@ void processQueryFile(const std::string& file, const ProgramOptions& o, SearchDr
         while (reader.next()) {
             pending.push_back(Pending{query_num++, reader.header(), reader.sequence()});
             driver.submit(pending.back().sequence.data(), int32_t(pending.back().sequence.size()));
-            if (driver.inFlight() >= SearchDriver::kMaxInFlight) finish_oldest();
+            if (driver.inFlight() >= driver.maxInFlight()) finish_oldest();
         }
         while (driver.inFlight() > 0) finish_oldest();
     } catch (...) {
