@@ -426,9 +426,10 @@ def measure(env, args, workload, want_cpu):
         """20 scans through the C++ driver (each returns this rank's top-K on the host), then ONE exchange of the
         per-rank lists — K (score, id) pairs per query and rank — and the host-side merge on rank 0."""
         mine = np.full((len(queries), max(K, 1), 2), -1, dtype=np.int64)
-        # the query file is at hand as a whole (main.cu:217-260): the driver takes the next query while the current
-        # one's top-K is still on its way back (Driver.scan_many == what `align` does); BENCH_NO_PIPELINE=1: one by one
-        results = [drv.scan(q) for q in query_letters] if os.environ.get("BENCH_NO_PIPELINE") == "1" else drv.scan_many(query_letters)
+        # One query at a time, like the reference (main.cu:217-260).  BENCH_PIPELINE=1: the driver takes the next query
+        # while the current one's top-K is still on its way back (Driver.scan_many, SearchDriver::submit / collect) —
+        # measured: +0.4 % on a 125 000-subject shard, +-0.1 % on the 10^6 x 512 DB, -0.8 % on the Swiss-Prot-like DB
+        results = drv.scan_many(query_letters) if os.environ.get("BENCH_PIPELINE") == "1" else [drv.scan(q) for q in query_letters]
         for qi, r in enumerate(results):
             n = len(r["scores"])
             mine[qi, :n, 0] = r["scores"]

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <deque>
 #include <fstream>
 #include <iostream>
@@ -54,15 +55,18 @@ void reportScan(const ProgramOptions& o, const ScanResult& r) {
     else std::cout << "Done.\n";
 }
 
-// All queries of a file (main.cu:217-260).  The file is at hand as a whole, so the next query is submitted before the
-// current one is collected (SearchDriver::submit / collect): its upload, profile build and first launches queue up behind
-// the current query's top-K on the GPU instead of waiting for the host to come back.  Output order and format are the
-// reference's; a query's line is printed when its results are in.
+// All queries of a file (main.cu:217-260), one at a time like the reference.  With CUDASW4_AMD_PIPELINE=1 the next query
+// is submitted before the current one is collected (SearchDriver::submit / collect): its upload, profile build and first
+// launches queue up behind the current query's top-K on the GPU instead of waiting for the host to come back — worth
+// +0.4 % on small shards (125 000 subjects), nothing on a 10^6-subject DB and -0.8 % on a Swiss-Prot-like one, hence off
+// by default.  Output order and format are the reference's either way; a query's line is printed when its results are in.
 void processQueryFile(const std::string& file, const ProgramOptions& o, SearchDriver& driver, std::ostream& out, bool interactive) {
     SequenceReader reader(file);
     struct Pending { int64_t num; std::string header, sequence; };
     std::deque<Pending> pending;
     int64_t query_num = 0;
+    const char* pipe = std::getenv("CUDASW4_AMD_PIPELINE");
+    const int maxInFlight = (pipe && pipe[0] == '1') ? SearchDriver::kMaxInFlight : 1;
     if (!interactive) driver.totalTimerStart();
     auto finish_oldest = [&]() {
         const Pending q = std::move(pending.front());
@@ -86,7 +90,7 @@ void processQueryFile(const std::string& file, const ProgramOptions& o, SearchDr
         while (reader.next()) {
             pending.push_back(Pending{query_num++, reader.header(), reader.sequence()});
             driver.submit(pending.back().sequence.data(), int32_t(pending.back().sequence.size()));
-            if (driver.inFlight() >= driver.maxInFlight()) finish_oldest();
+            if (driver.inFlight() >= maxInFlight) finish_oldest();
         }
         while (driver.inFlight() > 0) finish_oldest();
     } catch (...) {

@@ -164,7 +164,6 @@ int swdrv_scan_collect(swdrv* d, int32_t* scores, int64_t* ids, int cap, int* nr
 }
 
 int swdrv_in_flight(swdrv* d) { return d ? d->driver->inFlight() : 0; }
-int swdrv_max_in_flight(swdrv* d) { return d ? d->driver->maxInFlight() : 0; }
 
 int64_t swdrv_cached_chars(swdrv* d, int gpu) {
     int64_t v = -1;

@@ -86,57 +86,14 @@ struct TimedLaunch {
     size_t lbegin = 0, lend = 0;
 };
 
-// What one query in flight owns on one GPU.  A driver keeps SearchDriver::kMaxInFlight lanes per GPU and gives consecutive
-// queries alternating lanes: the scan of query i + 1 (its own context — query, profiles — work stream, score and overflow
-// buffers) is enqueued while query i still runs, and its first workgroups take the CUs that the under-filled last round
-// of query i's launches leaves idle; its top-K runs next to the following query's first launches.  On an equal-length DB
-// the tail of a launch is a fixed fraction of a round of the persistent grid: a 125 000-subject shard (what each of 8
-// GPUs gets of the 10^6 x 512 DB) is 7.6 rounds, and the last one ran at 63 % occupancy for every query.
-struct Lane {
-    int index = 0;
-    sw_ctx* ctx = nullptr;
-    // the lane's work stream: resident scans, every other batch of a streamed scan (the batches in between use the OTHER
-    // lane's stream, so that the first workgroups of a batch fill the CUs the last round of the batch before leaves idle),
-    // top-K, copy-back
-    hipStream_t stream = nullptr;
-    hipEvent_t forkEvent[2] = {nullptr, nullptr}, joinEvent[2] = {nullptr, nullptr}, join2Event = nullptr, scanStartEv = nullptr;
-    float* d_scores = nullptr;
-    int32_t* d_ids = nullptr;
-    int32_t* d_ovfPos = nullptr;
-    // [0]: subjects whose exact score reached the packed limit (the reference's statistic); [1 + k * kOvfLists + i]:
-    // length of overflow list i of batch k — every packed run of a batch has its own list, and the lists of one scan
-    // never share a counter, because the long-subject runs of a batch keep running next to the following batches;
-    // behind them the bad-letter flag of batches that are checked on the device
-    int32_t* d_ovfCount = nullptr;
-    size_t ovfCountCap = 0;
-    void* d_topkTemp = nullptr;
-    size_t topkTempBytes = 0;
-    float* d_topS = nullptr;
-    int32_t* d_topI = nullptr;
-    int topCapacity = 0;
-    bool auxUsed[2] = {false, false};  // this scan put work on the auxiliary stream: joined before the top-K
-    bool altUsed = false;              // ... on the other lane's stream
-    int32_t qlen = 0;
-    // what the scan leaves for the host: pinned copies of the top-K and of the overflow counters, and the event behind
-    // the last of those copies
-    hipEvent_t done = nullptr;
-    float* h_topS = nullptr;
-    int32_t* h_topI = nullptr;
-    int topCap = 0;
-    int32_t* h_ovf = nullptr;
-    size_t ovfCap = 0;
-    size_t ncounters = 0;
-    int top = 0;
-    bool used = false;  // this GPU took part in the scan (its shard is not empty)
-};
-
 struct SearchDriver::Gpu {
     int index = 0;   // position in gpus_
     int device = 0;
-    static constexpr int kLanes = SearchDriver::kMaxInFlight;
-    Lane lanes[kLanes];
-    int lastLane = 0;  // lane of the query collected last: lastScores reads its buffers
-    hipStream_t copyStream = nullptr;
+    sw_ctx* ctx = nullptr;
+    // stream: the work stream (resident scans, every other batch of a streamed scan, top-K, copy-back); stream2: the
+    // batches in between, so that the first workgroups of a batch fill the CUs the last round of the batch before
+    // leaves idle
+    hipStream_t stream = nullptr, stream2 = nullptr, copyStream = nullptr;
     std::array<ShardRange, kNumLengthPartitions> ranges{};
     std::array<size_t, kNumLengthPartitions + 1> localBegin{};
     size_t numLocal = 0;
@@ -171,32 +128,61 @@ struct SearchDriver::Gpu {
     size_t pinnedCap = 0;
     hipEvent_t copied[kSlots] = {nullptr, nullptr, nullptr}, scanned[kSlots] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> batchEv;  // 2 per batch of the last streamed scan (intervals for tests / tuning)
-    hipEvent_t lastScanStartEv = nullptr;  // the scanStartEv of the lane that ran the last streamed scan
+    hipEvent_t scanStartEv = nullptr;
     hipEvent_t recordRefEv = nullptr; // recorded when kernel-event recording was switched on: origin of KernelEvent::t0_ms
     bool recordRefValid = false;
+    float* d_scores = nullptr;
+    int32_t* d_ids = nullptr;
+    int32_t* d_ovfPos = nullptr;
+    // [0]: subjects whose exact score reached the packed limit (the reference's statistic); [1 + k * kOvfLists + i]:
+    // length of overflow list i of batch k — every packed run of a batch has its own list, and the lists of one scan
+    // never share a counter, because the long-subject runs of a batch keep running next to the following batches
+    int32_t* d_ovfCount = nullptr;
+    size_t ovfCountCap = 0;
     static constexpr int kOvfLists = 4;
-    // The few long subjects of a batch run on auxiliary streams next to the bulk launch (the reference round-robins 10
-    // work streams, cudasw4.cuh:293,1745-1748); both lanes use the same two.  Launches that run concurrently need their
-    // own stripe-border scratch: one per STREAM (launches of one stream follow each other, whichever lane they belong
-    // to): [0], [1] the lanes' work streams, [2 ..] the auxiliary streams
+    // Launches that run concurrently need their own stripe-border scratch: slot 0 = work stream,
+    // slots 1.. = auxiliary streams (the reference round-robins 10 work streams, cudasw4.cuh:293,1745-1748)
     static constexpr int kAux = 2;
     hipStream_t aux[kAux] = {nullptr, nullptr};
+    hipEvent_t forkEvent[2] = {nullptr, nullptr}, joinEvent[kAux] = {nullptr, nullptr}, join2Event = nullptr;
     // the auxiliary launches of a streamed batch read the batch's staging buffer: recorded after the last of them on each
     // auxiliary stream, waited for before the buffer is overwritten
     hipEvent_t auxDone[kSlots][kAux] = {};
     bool auxPending[kSlots][kAux] = {};
+    bool auxUsed[kAux] = {false, false};  // this scan put work on the stream: joined before the top-K
+    bool stream2Used = false;
     bool firstBatchStaged = false;  // staging buffer slotBase already holds the first batch of the next streamed scan
     size_t slotBase = 0;            // staging buffer of the first batch of the next streamed scan
     bool slotUsed[kSlots] = {};     // the buffer has been scanned from since the DB was set: scanned[] is valid
     bool prefetchNext = true;       // CUDASW4_AMD_NO_NEXT_PREFETCH=1 turns that off (A/B measurements)
-    bool twoWorkStreams = true;     // CUDASW4_AMD_ONE_WORK_STREAM=1: every batch of a streamed scan on the lane's own stream (A/B measurements)
-    void* d_temp[kLanes + kAux] = {};
-    size_t tempBytes[kLanes + kAux] = {};
+    bool twoWorkStreams = true;   // CUDASW4_AMD_ONE_WORK_STREAM=1: every batch of a streamed scan on the work stream (A/B measurements)
+    void* d_temp[kAux + 2] = {nullptr, nullptr, nullptr, nullptr};  // work stream, auxiliary streams, stream2
+    size_t tempBytes[kAux + 2] = {0, 0, 0, 0};
+    void* d_topkTemp = nullptr;
+    size_t topkTempBytes = 0;
+    float* d_topS = nullptr;
+    int32_t* d_topI = nullptr;
+    int topCapacity = 0;
+    // what a scan leaves for the host, per query in flight (SearchDriver::kMaxInFlight): pinned copies of the top-K and
+    // of the overflow counters, and the event behind the last of those copies
+    struct ResultSlot {
+        hipEvent_t done = nullptr;
+        float* h_topS = nullptr;
+        int32_t* h_topI = nullptr;
+        int topCap = 0;
+        int32_t* h_ovf = nullptr;  // copy of d_ovfCount after the scan
+        size_t ovfCap = 0;
+        size_t ncounters = 0;
+        int top = 0;
+        bool used = false;         // this GPU took part in the scan (its shard is not empty)
+    };
+    ResultSlot res[SearchDriver::kMaxInFlight];
     int lastTop = 0;
-    const float* lastTopS = nullptr;   // the finished lane's lists (valid until that lane is reused)
+    const float* lastTopS = nullptr;   // the finished slot's lists (valid until that slot is reused)
     const int32_t* lastTopI = nullptr;
     int lastOverflows = 0;      // subjects of the last query whose exact score reached the packed kind's limit (the reference's statistic)
     int lastRescored = 0;       // subjects the packed launches flagged and the 32-bit kind re-scored (>= lastOverflows)
+    int32_t qlen = 0;
     double spanBegin = 0, spanEnd = 0;  // host clock, seconds since the scan started
     std::vector<TimedLaunch> timed;     // launches recorded since the last takeKernelEvents
     std::vector<TimedLaunch> freeTimed; // event pairs to reuse
@@ -268,36 +254,26 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         g->index = int(gpus_.size());
         g->device = dev;
         g->use();
+        SWCHECK(sw_ctx_create(dev, &g->ctx));
+        SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), matrix_.dim));
+        HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
+        for (auto& e : g->forkEvent) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&g->join2Event, hipEventDisableTiming));
+        HIPCHECK(hipEventCreate(&g->scanStartEv));
+        HIPCHECK(hipEventCreate(&g->recordRefEv));
+        for (auto& r : g->res) HIPCHECK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
         // The auxiliary streams carry the few long subjects that must overlap the bulk launch.  The runtime multiplexes
         // streams of one priority onto GPU_MAX_HW_QUEUES (4) hardware queues, and two streams that share a queue
         // serialise (measured: the giant-subject launch in front of the bulk launch, 167 instead of 106 ms for a
         // 5478-residue query on the Swiss-Prot-like DB).  High-priority streams come from a queue pool of their own, so
-        // they never share a hardware queue with the work streams — and the giants get their workgroups first.
+        // they never share a hardware queue with the work stream — and the giants get their workgroups first.
         int prioLow = 0, prioHigh = 0;
         HIPCHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-        int order = 1;
-        if (const char* e = std::getenv("CUDASW4_AMD_STREAM_ORDER")) order = std::atoi(e);
-        auto make_aux = [&] { for (int i = 0; i < Gpu::kAux; i++) HIPCHECK(hipStreamCreateWithPriority(&g->aux[i], hipStreamNonBlocking, prioHigh)); };
-        auto make_lane_stream = [&](int li) { HIPCHECK(hipStreamCreateWithFlags(&g->lanes[li].stream, hipStreamNonBlocking)); };
-        auto make_copy = [&] { HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking)); };
-        if (order == 0) { make_aux(); make_lane_stream(0); make_lane_stream(1); make_copy(); }
-        else if (order == 1) { make_lane_stream(0); make_copy(); make_aux(); make_lane_stream(1); }
-        else if (order == 2) { make_lane_stream(0); make_lane_stream(1); make_copy(); make_aux(); }
-        else { make_lane_stream(0); make_copy(); make_lane_stream(1); make_aux(); }
-        for (int li = 0; li < Gpu::kLanes; li++) {
-            Lane& L = g->lanes[li];
-            L.index = li;
-            SWCHECK(sw_ctx_create(dev, &L.ctx));
-            SWCHECK(sw_set_matrix(L.ctx, matrix_.m.data(), matrix_.dim));
-            for (auto& e : L.forkEvent) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            for (auto& e : L.joinEvent) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            HIPCHECK(hipEventCreateWithFlags(&L.join2Event, hipEventDisableTiming));
-            HIPCHECK(hipEventCreate(&L.scanStartEv));
-            HIPCHECK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
-            L.ovfCountCap = 2 + Gpu::kOvfLists;
-            HIPCHECK(hipMalloc(&L.d_ovfCount, L.ovfCountCap * sizeof(int32_t)));
+        for (int i = 0; i < Gpu::kAux; i++) {
+            HIPCHECK(hipStreamCreateWithPriority(&g->aux[i], hipStreamNonBlocking, prioHigh));
+            HIPCHECK(hipEventCreateWithFlags(&g->joinEvent[i], hipEventDisableTiming));
         }
-        HIPCHECK(hipEventCreate(&g->recordRefEv));
         for (int i = 0; i < Gpu::kSlots; i++) {
             HIPCHECK(hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&g->scanned[i], hipEventDisableTiming));
@@ -305,11 +281,12 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         }
         if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
+        g->ovfCountCap = 1 + Gpu::kOvfLists;
+        HIPCHECK(hipMalloc(&g->d_ovfCount, g->ovfCountCap * sizeof(int32_t)));
         gpus_.push_back(std::move(g));
     }
     if (gpus_.size() > 1)
         for (size_t i = 0; i < gpus_.size(); i++) workers_.push_back(std::make_unique<Worker>());
-    if (const char* e = std::getenv("CUDASW4_AMD_ONE_LANE")) oneLane_ = e[0] == '1';  // every query on lane 0 (A/B measurements)
 }
 
 SearchDriver::~SearchDriver() {
@@ -328,25 +305,28 @@ SearchDriver::~SearchDriver() {
                 if (g.auxDone[i][a]) (void)hipEventDestroy(g.auxDone[i][a]);
         }
         for (hipEvent_t e : g.batchEv) (void)hipEventDestroy(e);
+        if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
         if (g.recordRefEv) (void)hipEventDestroy(g.recordRefEv);
+        for (auto& r : g.res) {
+            if (r.done) (void)hipEventDestroy(r.done);
+            (void)hipHostFree(r.h_topS); (void)hipHostFree(r.h_topI); (void)hipHostFree(r.h_ovf);
+        }
         for (auto* v : {&g.timed, &g.freeTimed})
             for (TimedLaunch& t : *v) { (void)hipEventDestroy(t.ev0); (void)hipEventDestroy(t.ev1); }
+        (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos); (void)hipFree(g.d_ovfCount);
         for (void* t : g.d_temp) (void)hipFree(t);
-        for (Lane& L : g.lanes) {
-            if (L.done) (void)hipEventDestroy(L.done);
-            (void)hipHostFree(L.h_topS); (void)hipHostFree(L.h_topI); (void)hipHostFree(L.h_ovf);
-            (void)hipFree(L.d_scores); (void)hipFree(L.d_ids); (void)hipFree(L.d_ovfPos); (void)hipFree(L.d_ovfCount);
-            (void)hipFree(L.d_topkTemp); (void)hipFree(L.d_topS); (void)hipFree(L.d_topI);
-            for (hipEvent_t e : L.forkEvent) if (e) (void)hipEventDestroy(e);
-            for (hipEvent_t e : L.joinEvent) if (e) (void)hipEventDestroy(e);
-            if (L.join2Event) (void)hipEventDestroy(L.join2Event);
-            if (L.scanStartEv) (void)hipEventDestroy(L.scanStartEv);
-            if (L.stream) (void)hipStreamDestroy(L.stream);
-            if (L.ctx) sw_ctx_destroy(L.ctx);
-        }
-        for (int i = 0; i < Gpu::kAux; i++)
+        for (int i = 0; i < Gpu::kAux; i++) {
             if (g.aux[i]) (void)hipStreamDestroy(g.aux[i]);
+            if (g.joinEvent[i]) (void)hipEventDestroy(g.joinEvent[i]);
+        }
+        for (hipEvent_t e : g.forkEvent)
+            if (e) (void)hipEventDestroy(e);
+        if (g.join2Event) (void)hipEventDestroy(g.join2Event);
+        (void)hipFree(g.d_topkTemp); (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
+        if (g.stream) (void)hipStreamDestroy(g.stream);
         if (g.copyStream) (void)hipStreamDestroy(g.copyStream);
+        if (g.stream2) (void)hipStreamDestroy(g.stream2);
+        if (g.ctx) sw_ctx_destroy(g.ctx);
     }
     unregisterRanges();
 }
@@ -405,7 +385,8 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
         gp->use();
         (void)hipStreamSynchronize(gp->copyStream);
         gp->firstBatchStaged = false;
-        for (Lane& L : gp->lanes) (void)hipStreamSynchronize(L.stream);
+        (void)hipStreamSynchronize(gp->stream);
+        if (gp->stream2) (void)hipStreamSynchronize(gp->stream2);
         for (bool& u : gp->slotUsed) u = false;
         gp->slotBase = 0;
     }
@@ -447,34 +428,30 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
         g.localResidues = residues;
 
         const size_t n = std::max<size_t>(g.numLocal, 1);
+        (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos);
         (void)hipFree(g.d_offsets); (void)hipFree(g.d_lengths); (void)hipFree(g.d_chars);
         g.d_chars = nullptr;
         for (int i = 0; i < Gpu::kSlots; i++) { (void)hipFree(g.d_staging[i]); g.d_staging[i] = nullptr; }
         g.stagingCap = 0;
-        for (Lane& L : g.lanes) {  // result arrays of every query in flight: 12 bytes per subject and lane
-            (void)hipFree(L.d_scores); (void)hipFree(L.d_ids); (void)hipFree(L.d_ovfPos);
-            L.d_scores = nullptr; L.d_ids = nullptr; L.d_ovfPos = nullptr;
-            HIPCHECK(hipMalloc(&L.d_scores, n * sizeof(float)));
-            HIPCHECK(hipMalloc(&L.d_ids, n * sizeof(int32_t)));
-            HIPCHECK(hipMalloc(&L.d_ovfPos, n * sizeof(int32_t)));
-        }
-        hipStream_t s0 = g.lanes[0].stream;
+        HIPCHECK(hipMalloc(&g.d_scores, n * sizeof(float)));
+        HIPCHECK(hipMalloc(&g.d_ids, n * sizeof(int32_t)));
+        HIPCHECK(hipMalloc(&g.d_ovfPos, n * sizeof(int32_t)));
         HIPCHECK(hipMalloc(&g.d_offsets, (n + 1) * sizeof(uint64_t)));
         HIPCHECK(hipMalloc(&g.d_lengths, n * sizeof(int32_t)));
-        HIPCHECK(hipMemcpyAsync(g.d_offsets, g.localOffsets.data(), (g.numLocal + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s0));
+        HIPCHECK(hipMemcpyAsync(g.d_offsets, g.localOffsets.data(), (g.numLocal + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
         for (int p = 0; p < kNumLengthPartitions; p++) {
             const ShardRange r = g.ranges[p];
             if (!r.size()) continue;
-            HIPCHECK(hipMemcpyAsync(g.d_lengths + g.localBegin[p], db_->lengths() + r.begin, r.size() * sizeof(int32_t), hipMemcpyHostToDevice, s0));
+            HIPCHECK(hipMemcpyAsync(g.d_lengths + g.localBegin[p], db_->lengths() + r.begin, r.size() * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
         }
-        HIPCHECK(hipStreamSynchronize(s0));
+        HIPCHECK(hipStreamSynchronize(g.stream));
         // Residency decision (GpuWorkingSet, cudasw4.cuh:317-392,1020-1026).  The limit covers everything this GPU holds:
-        // the per-subject metadata and result arrays allocated above (36 bytes per subject), the scratch of multi-stripe
+        // the per-subject metadata and result arrays allocated above (24 bytes per subject), the scratch of multi-stripe
         // queries, and the chars — resident when they fit, otherwise three staging buffers of one batch each plus as
         // much of the shard as still fits next to them (the reference: "N out of M DB batches will be cached").
         size_t freeMem = 0, totalMem = 0;
         HIPCHECK(hipMemGetInfo(&freeMem, &totalMem));
-        const size_t meta = n * (12 + 12 * Gpu::kLanes) + 8;
+        const size_t meta = n * 24 + 8;
         size_t limit = std::min(memory_.maxGpuMem > meta ? memory_.maxGpuMem - meta : 0, freeMem);
         const size_t safety = size_t(256) << 20;
         if (limit > safety) limit -= safety;  // cudasw4.cuh:1020-1026: a limit below the margin is taken as it is
@@ -582,23 +559,21 @@ void SearchDriver::planBatches(Gpu& g, uint64_t batchBytes) {
 void SearchDriver::uploadShard(Gpu& g) {
     g.use();
     if (g.cacheBegin >= g.numLocal) { g.cacheFilled = true; return; }
-    Lane& L = g.lanes[0];
     if (!g.d_chars) HIPCHECK(hipMalloc(&g.d_chars, g.cacheBytes + 64));
     for_each_piece(g, *db_, g.cacheBegin, g.numLocal, [&](const int8_t* src, uint64_t bytes, uint64_t pos) {
-        HIPCHECK(hipMemcpyAsync(g.d_chars + pos, src, bytes, hipMemcpyHostToDevice, L.stream));
+        HIPCHECK(hipMemcpyAsync(g.d_chars + pos, src, bytes, hipMemcpyHostToDevice, g.stream));
     });
-    HIPCHECK(hipMemsetAsync(g.d_chars + g.cacheBytes, kOtherCode, 64, L.stream));
+    HIPCHECK(hipMemsetAsync(g.d_chars + g.cacheBytes, kOtherCode, 64, g.stream));
     if (!db_->codes_validated()) {
-        // the flag borrows lane 0's first overflow counter (no scan is in flight on this GPU during an upload)
+        // the flag borrows the first overflow counter (no scan is in flight on this GPU during an upload)
         int32_t bad = 0;
-        HIPCHECK(hipMemsetAsync(L.d_ovfCount, 0, sizeof(int32_t), L.stream));
-        SWCHECK(sw_check_letter_codes(L.ctx, g.d_chars, g.cacheBytes, L.d_ovfCount, L.stream));
-        HIPCHECK(hipMemcpyAsync(&bad, L.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
-        HIPCHECK(hipStreamSynchronize(L.stream));
+        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, sizeof(int32_t), g.stream));
+        SWCHECK(sw_check_letter_codes(g.ctx, g.d_chars, g.cacheBytes, g.d_ovfCount, g.stream));
+        HIPCHECK(hipMemcpyAsync(&bad, g.d_ovfCount, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipStreamSynchronize(g.stream));
         if (bad) { g.badCodes = true; throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)"); }
     }
-    HIPCHECK(hipStreamSynchronize(L.stream));
-    // the other lanes' streams have not seen this upload: every scan starts with work that is ordered behind it on the host
+    HIPCHECK(hipStreamSynchronize(g.stream));
     g.cacheFilled = true;
 }
 
@@ -629,21 +604,20 @@ void* ensure_temp(void*& ptr, size_t& have, size_t need, size_t cap) {
 }  // namespace
 
 // Enqueue the scan of the shard-local subjects [lbegin, lend) whose chars start at `chars` (device) as batch `batch` of
-// lane L's query, staged in buffer `slot` (-1: resident chars).  The run with the most subjects goes to a work stream — the
-// lane's own, or with `alt` the other lane's — together with its re-score; the others (few long subjects) are launched on the
-// auxiliary streams, re-scored there, and
+// the current query, staged in buffer `slot` (-1: resident chars).  The run with the most subjects goes to the work stream
+// together with its re-score; the others (few long subjects) are launched on the auxiliary streams, re-scored there, and
 // NOT joined at the end of the batch: a giant subject of a Swiss-Prot-like DB keeps one wave busy for as long as the whole
 // batch takes (61 ms for a 5478-residue query), and joining it per batch put that time in front of every following batch
-// (streamed Swiss-Prot-like DB: 133 instead of 107 ms for that query).  enqueueOnGpu joins the auxiliary streams before the
+// (streamed Swiss-Prot-like DB: 133 instead of 107 ms for that query).  scanOnGpu joins the auxiliary streams before the
 // top-K; a staging buffer is overwritten only after the auxiliary launches that read it (auxDone).
 template <class GpuT>
-static void enqueue_batch(GpuT& g, Lane& L, const int8_t* chars, size_t lbegin, size_t lend, const Database& db,
+static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t lend, const Database& db,
                           const KernelTypeConfig& kt, const MemoryConfig& mem, int gop, int gex, int recordMode,
-                          size_t batch, int slot, bool alt) {
-    // the scratch belongs to the stream (launches of one stream follow each other, whichever lane enqueued them)
-    const int workTemp = alt ? 1 - L.index : L.index;
-    const hipStream_t work = g.lanes[workTemp].stream;
-    const hipEvent_t fork = L.forkEvent[alt ? 1 : 0];
+                          size_t batch, int slot, bool second) {
+    // every other batch of a streamed scan runs on stream2 with a scratch of its own (see Gpu::stream2)
+    const hipStream_t work = second ? g.stream2 : g.stream;
+    const int workTemp = second ? GpuT::kAux + 1 : 0;
+    const hipEvent_t fork = g.forkEvent[second ? 1 : 0];
     const auto runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, lend,
                                        [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); });
     const uint64_t* offsets = g.d_offsets + lbegin;
@@ -651,7 +625,7 @@ static void enqueue_batch(GpuT& g, Lane& L, const int8_t* chars, size_t lbegin, 
     // Every packed run keeps its own overflow list (the slice of d_ovfPos at its first subject) and counter, and is
     // re-scored by a launch of its own: the group shape of a re-score follows the run's longest subject (16-lane groups for
     // the bulk of the DB, the wave-wide shape only for the list of partition 34), not the longest subject of the batch.
-    int32_t* const counters = L.d_ovfCount + 1 + batch * GpuT::kOvfLists;  // zeroed at the start of the scan
+    int32_t* const counters = g.d_ovfCount + 1 + batch * GpuT::kOvfLists;  // zeroed at the start of the scan
     size_t mainIdx = 0;
     for (size_t i = 1; i < runs.size(); i++)
         if (runs[i].end - runs[i].begin > runs[mainIdx].end - runs[mainIdx].begin) mainIdx = i;
@@ -666,21 +640,21 @@ static void enqueue_batch(GpuT& g, Lane& L, const int8_t* chars, size_t lbegin, 
     auto launch = [&](size_t ri, hipStream_t stream, int tslot) {
         const LaunchRun& r = runs[ri];
         const int32_t n = int32_t(r.end - r.begin);
-        const size_t need = sw_scan_temp_bytes(L.ctx, int(r.kind), r.part_id, n, r.maxlen);
+        const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, r.maxlen);
         void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, mem.maxTempBytes);
         TimedLaunch t;
         const bool record = recordMode == 1 || (recordMode == 2 && tslot == workTemp);
         if (record) {
             if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
             else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
-            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = L.qlen; t.lbegin = r.begin; t.lend = r.end;
-            SWCHECK(sw_plan_launch(L.ctx, int(r.kind), r.part_id, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
+            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end;
+            SWCHECK(sw_plan_launch(g.ctx, int(r.kind), r.part_id, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
             HIPCHECK(hipEventRecord(t.ev0, stream));
         }
         const bool packed = ovfList[ri] >= 0;
-        SWCHECK(sw_scan_partition(L.ctx, int(r.kind), r.part_id, chars, offsets, lengths, int32_t(r.begin - lbegin), n,
-                                  r.maxlen, gop, gex, L.d_scores + lbegin, L.d_ids + lbegin, int64_t(lbegin),
-                                  packed ? L.d_ovfPos + r.begin : nullptr, packed ? counters + ovfList[ri] : nullptr,
+        SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, chars, offsets, lengths, int32_t(r.begin - lbegin), n,
+                                  r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin),
+                                  packed ? g.d_ovfPos + r.begin : nullptr, packed ? counters + ovfList[ri] : nullptr,
                                   packed ? 1 : 0, temp, g.tempBytes[tslot], stream));
         if (record) {
             HIPCHECK(hipEventRecord(t.ev1, stream));
@@ -691,13 +665,13 @@ static void enqueue_batch(GpuT& g, Lane& L, const int8_t* chars, size_t lbegin, 
         if (ovfList[ri] < 0) return;
         const LaunchRun& r = runs[ri];
         const int32_t n = int32_t(r.end - r.begin);
-        const size_t need = sw_scan_temp_bytes(L.ctx, int(kt.overflowType), -1, n, r.maxlen);
+        const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, n, r.maxlen);
         void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, mem.maxTempBytes);
-        SWCHECK(sw_rescore_overflow_stat(L.ctx, int(kt.overflowType), L.d_ovfPos + r.begin, counters + ovfList[ri], n,
-                                         chars, offsets, lengths, r.maxlen, gop, gex, L.d_scores + lbegin, L.d_ids + lbegin,
+        SWCHECK(sw_rescore_overflow_stat(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[ri], n,
+                                         chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
                                          int64_t(lbegin), temp, g.tempBytes[tslot],
                                          r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16,
-                                         L.d_ovfCount, stream));
+                                         g.d_ovfCount, stream));
     };
     int auxNext = 0;
     bool auxBusy[GpuT::kAux] = {};
@@ -708,17 +682,17 @@ static void enqueue_batch(GpuT& g, Lane& L, const int8_t* chars, size_t lbegin, 
         if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], fork, 0));
         auxBusy[a] = true;
         streamOf[i] = a;
-        launch(i, g.aux[a], GpuT::kLanes + a);
+        launch(i, g.aux[a], a + 1);
     }
     for (size_t i = 0; i < runs.size(); i++)
         if (streamOf[i] < 0) launch(i, work, workTemp);
     for (size_t i = 0; i < runs.size(); i++) {
-        if (streamOf[i] >= 0) rescore(i, g.aux[streamOf[i]], GpuT::kLanes + streamOf[i]);
+        if (streamOf[i] >= 0) rescore(i, g.aux[streamOf[i]], streamOf[i] + 1);
         else rescore(i, work, workTemp);
     }
     for (int a = 0; a < GpuT::kAux; a++) {
         if (!auxBusy[a]) continue;
-        L.auxUsed[a] = true;
+        g.auxUsed[a] = true;
         if (slot >= 0) {
             HIPCHECK(hipEventRecord(g.auxDone[slot][a], g.aux[a]));
             g.auxPending[slot][a] = true;
@@ -726,23 +700,22 @@ static void enqueue_batch(GpuT& g, Lane& L, const int8_t* chars, size_t lbegin, 
     }
 }
 
-// the lane's work stream continues only after everything the auxiliary streams and the other lane's stream were given in
-// this scan
+// the work stream continues only after everything the auxiliary streams were given in this scan
 template <class GpuT>
-static void join_aux(GpuT& g, Lane& L) {
+static void join_aux(GpuT& g) {
     for (int a = 0; a < GpuT::kAux; a++) {
-        if (!L.auxUsed[a]) continue;
-        HIPCHECK(hipEventRecord(L.joinEvent[a], g.aux[a]));
-        HIPCHECK(hipStreamWaitEvent(L.stream, L.joinEvent[a], 0));
-        L.auxUsed[a] = false;
+        if (!g.auxUsed[a]) continue;
+        HIPCHECK(hipEventRecord(g.joinEvent[a], g.aux[a]));
+        HIPCHECK(hipStreamWaitEvent(g.stream, g.joinEvent[a], 0));
+        g.auxUsed[a] = false;
     }
-    // auxPending stays set: the host does not wait for the end of a scan before it enqueues the next one, so the copy
+    // auxPending stays set: the host no longer waits for the end of a scan before it enqueues the next one, so the copy
     // that reuses a staging buffer must still wait for the auxiliary launches that read it (an event that has long
     // completed costs nothing)
-    if (L.altUsed) {
-        HIPCHECK(hipEventRecord(L.join2Event, g.lanes[1 - L.index].stream));
-        HIPCHECK(hipStreamWaitEvent(L.stream, L.join2Event, 0));
-        L.altUsed = false;
+    if (g.stream2Used) {
+        HIPCHECK(hipEventRecord(g.join2Event, g.stream2));
+        HIPCHECK(hipStreamWaitEvent(g.stream, g.join2Event, 0));
+        g.stream2Used = false;
     }
 }
 
@@ -759,7 +732,7 @@ static void ensure_ovf_slots(int32_t*& h, size_t& cap, size_t need) {
 // offsets and lengths are resident.  Batches run longest subjects first, so the tail of the query consists of short
 // subjects.  With the DB mapping registered the whole scan is enqueued without blocking the host; the pinned fallback
 // blocks only on its own host buffers.  Batch k of the scan order uses overflow counters k + 1 (0: the cached part).
-void SearchDriver::scanStreamed(Gpu& g, Lane& L) {
+void SearchDriver::scanStreamed(Gpu& g) {
     const size_t nb = g.batches.size();
     const bool cached = g.cacheBegin < g.numLocal;
     uint64_t maxBytes = 0;
@@ -830,23 +803,28 @@ void SearchDriver::scanStreamed(Gpu& g, Lane& L) {
         // the first batch may already be there: the previous scan copied it in behind its own last batches (below)
         if (k == 0 && g.firstBatchStaged) g.firstBatchStaged = false;
         else copy_batch(k);
-        // Batches alternate between the lane's own work stream and the other lane's; with a cached part in front the
-        // first streamed batch takes the other one, next to the cached part's launch
+        // Batches alternate between the two work streams; with a cached part in front the first streamed batch takes
+        // the second one, next to the cached part's launch.  stream2 is created with the first streamed scan that needs
+        // it: a driver whose shards are resident keeps the set of streams it was tuned with (one more stream of the work
+        // stream's priority changes which streams end up sharing a hardware queue: the giants' launch of a RESIDENT
+        // Swiss-Prot-like DB went back in front of the bulk launch, 138 instead of 107 ms for the longest query, when
+        // stream2 was created in the constructor)
         const bool second = ((k + (cached ? 1 : 0)) & 1) && g.twoWorkStreams;
-        const hipStream_t work = second ? g.lanes[1 - L.index].stream : L.stream;
-        if (second && !L.altUsed) {
-            // ordered after the query upload and the zeroed counters on the lane's stream
-            HIPCHECK(hipStreamWaitEvent(work, L.scanStartEv, 0));
-            L.altUsed = true;
+        if (second && !g.stream2) HIPCHECK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+        const hipStream_t work = second ? g.stream2 : g.stream;
+        if (second && !g.stream2Used) {
+            // ordered after the query upload and the zeroed counters on the work stream
+            HIPCHECK(hipStreamWaitEvent(g.stream2, g.scanStartEv, 0));
+            g.stream2Used = true;
         }
         HIPCHECK(hipStreamWaitEvent(work, g.copied[slot], 0));
         if (!db_->codes_validated() && !g.batchChecked[nb - 1 - k]) {
             // the flag is the word behind this scan's overflow counters (enqueueOnGpu zeroes and copies it back)
-            SWCHECK(sw_check_letter_codes(L.ctx, dst, b.bytes, L.d_ovfCount + 1 + (1 + nb) * Gpu::kOvfLists, work));
+            SWCHECK(sw_check_letter_codes(g.ctx, dst, b.bytes, g.d_ovfCount + 1 + (1 + nb) * Gpu::kOvfLists, work));
             g.batchChecked[nb - 1 - k] = true;
         }
         HIPCHECK(hipEventRecord(g.batchEv[2 * k], work));
-        enqueue_batch(g, L, dst, b.lbegin, b.lend, *db_, kernels_, memory_, gop_, gex_, recordEvents_, k + 1, slot, second);
+        enqueue_batch(g, dst, b.lbegin, b.lend, *db_, kernels_, memory_, gop_, gex_, recordEvents_, k + 1, slot, second);
         HIPCHECK(hipEventRecord(g.batchEv[2 * k + 1], work));
         HIPCHECK(hipEventRecord(g.scanned[slot], work));
         slotUsed[slot] = true;
@@ -863,117 +841,114 @@ void SearchDriver::scanStreamed(Gpu& g, Lane& L) {
 }
 
 // Everything one GPU is GIVEN for one query; runs on the GPU's worker thread when there are several.  Nothing here waits
-// for the GPU (the pinned-staging fallback of a streamed shard waits for its own host buffers): the results land in the
-// lane's pinned buffers and finishOnGpu picks them up.  Consecutive queries use different lanes — different contexts,
-// work streams and result arrays — so their scans overlap where the hardware has room; what they share (the staging
-// buffers of a streamed shard, the auxiliary streams and the per-stream scratch) is ordered by events and stream order.
+// for the GPU (the pinned-staging fallback of a streamed shard waits for its own host buffers): the results land in
+// result slot `slot` and finishOnGpu picks them up.  The scans of consecutive queries are ordered by the streams alone:
+// the query upload, the zeroed counters and the first launches of query i + 1 queue up behind the top-K and the copies of
+// query i on the work stream, the auxiliary streams fork from it and join it again before the top-K.
 void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
-    Lane& L = g.lanes[slot];
-    L.used = false;
-    L.top = 0;
-    L.ncounters = 0;
+    Gpu::ResultSlot& rs = g.res[slot];
+    rs.used = false;
+    rs.top = 0;
+    rs.ncounters = 0;
     g.spanBegin = g.spanEnd = now_seconds() - scanT0_;
     if (g.numLocal == 0) return;
     g.use();
     try {
         if (g.badCodes) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
-        L.qlen = queryLength;
+        g.qlen = queryLength;
         if (!g.cacheFilled) uploadShard(g);  // the first query pays the upload unless --uploadFull
-        SWCHECK(sw_set_query(L.ctx, encodedQuery_.data(), queryLength, L.stream));
+        SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
         // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
         // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed)
         const size_t ncounters = 1 + (1 + g.batches.size()) * Gpu::kOvfLists;
-        if (ncounters + 1 > L.ovfCountCap) {
-            (void)hipFree(L.d_ovfCount);
-            L.d_ovfCount = nullptr;
-            L.ovfCountCap = 0;
-            HIPCHECK(hipMalloc(&L.d_ovfCount, (ncounters + 1) * sizeof(int32_t)));
-            L.ovfCountCap = ncounters + 1;
+        if (ncounters + 1 > g.ovfCountCap) {
+            (void)hipFree(g.d_ovfCount);
+            g.d_ovfCount = nullptr;
+            g.ovfCountCap = 0;
+            HIPCHECK(hipMalloc(&g.d_ovfCount, (ncounters + 1) * sizeof(int32_t)));
+            g.ovfCountCap = ncounters + 1;
         }
-        ensure_ovf_slots(L.h_ovf, L.ovfCap, ncounters + 1);
-        HIPCHECK(hipMemsetAsync(L.d_ovfCount, 0, (ncounters + 1) * sizeof(int32_t), L.stream));
-        HIPCHECK(hipEventRecord(L.scanStartEv, L.stream));
-        g.lastScanStartEv = L.scanStartEv;
+        ensure_ovf_slots(rs.h_ovf, rs.ovfCap, ncounters + 1);
+        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, (ncounters + 1) * sizeof(int32_t), g.stream));
+        HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
         // the cached part first (the longest subjects: one set of launches over everything that is resident), then the
         // streamed batches — whose first copies run while the cached part computes
         if (g.cacheBegin < g.numLocal)
-            enqueue_batch(g, L, g.d_chars, g.cacheBegin, g.numLocal, *db_, kernels_, memory_, gop_, gex_, recordEvents_, 0, -1, false);
-        if (!g.batches.empty()) scanStreamed(g, L);
-        join_aux(g, L);
+            enqueue_batch(g, g.d_chars, g.cacheBegin, g.numLocal, *db_, kernels_, memory_, gop_, gex_, recordEvents_, 0, -1, false);
+        if (!g.batches.empty()) scanStreamed(g);
+        join_aux(g);
         const int kk = int(std::min<size_t>(size_t(std::max(k, 0)), g.numLocal));
         if (kk > 0) {
-            if (kk > L.topCapacity) {
-                (void)hipFree(L.d_topS); (void)hipFree(L.d_topI);
-                L.d_topS = nullptr; L.d_topI = nullptr; L.topCapacity = 0;
-                HIPCHECK(hipMalloc(&L.d_topS, kk * sizeof(float)));
-                HIPCHECK(hipMalloc(&L.d_topI, kk * sizeof(int32_t)));
-                L.topCapacity = kk;
+            if (kk > g.topCapacity) {
+                (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
+                g.d_topS = nullptr; g.d_topI = nullptr; g.topCapacity = 0;
+                HIPCHECK(hipMalloc(&g.d_topS, kk * sizeof(float)));
+                HIPCHECK(hipMalloc(&g.d_topI, kk * sizeof(int32_t)));
+                g.topCapacity = kk;
             }
-            if (kk > L.topCap) {
-                (void)hipHostFree(L.h_topS); (void)hipHostFree(L.h_topI);
-                L.h_topS = nullptr; L.h_topI = nullptr; L.topCap = 0;
-                HIPCHECK(hipHostMalloc(&L.h_topS, kk * sizeof(float)));
-                HIPCHECK(hipHostMalloc(&L.h_topI, kk * sizeof(int32_t)));
-                L.topCap = kk;
+            if (kk > rs.topCap) {
+                (void)hipHostFree(rs.h_topS); (void)hipHostFree(rs.h_topI);
+                rs.h_topS = nullptr; rs.h_topI = nullptr; rs.topCap = 0;
+                HIPCHECK(hipHostMalloc(&rs.h_topS, kk * sizeof(float)));
+                HIPCHECK(hipHostMalloc(&rs.h_topI, kk * sizeof(int32_t)));
+                rs.topCap = kk;
             }
             const size_t tb = sw_topk_temp_bytes(int64_t(g.numLocal), kk);
-            if (tb > L.topkTempBytes) {
-                (void)hipFree(L.d_topkTemp);
-                L.d_topkTemp = nullptr;
-                L.topkTempBytes = 0;
-                HIPCHECK(hipMalloc(&L.d_topkTemp, tb));
-                L.topkTempBytes = tb;
+            if (tb > g.topkTempBytes) {
+                (void)hipFree(g.d_topkTemp);
+                g.d_topkTemp = nullptr;
+                g.topkTempBytes = 0;
+                HIPCHECK(hipMalloc(&g.d_topkTemp, tb));
+                g.topkTempBytes = tb;
             }
-            SWCHECK(sw_topk(L.ctx, L.d_scores, L.d_ids, int64_t(g.numLocal), kk, L.d_topS, L.d_topI, L.d_topkTemp,
-                            L.topkTempBytes, L.stream));
-            HIPCHECK(hipMemcpyAsync(L.h_topS, L.d_topS, kk * sizeof(float), hipMemcpyDeviceToHost, L.stream));
-            HIPCHECK(hipMemcpyAsync(L.h_topI, L.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
-            L.top = kk;
+            SWCHECK(sw_topk(g.ctx, g.d_scores, g.d_ids, int64_t(g.numLocal), kk, g.d_topS, g.d_topI, g.d_topkTemp,
+                            g.topkTempBytes, g.stream));
+            HIPCHECK(hipMemcpyAsync(rs.h_topS, g.d_topS, kk * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+            HIPCHECK(hipMemcpyAsync(rs.h_topI, g.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+            rs.top = kk;
         }
         // per-query totals (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
-        HIPCHECK(hipMemcpyAsync(L.h_ovf, L.d_ovfCount, (ncounters + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
-        HIPCHECK(hipEventRecord(L.done, L.stream));
-        L.ncounters = ncounters;
-        L.used = true;
+        HIPCHECK(hipMemcpyAsync(rs.h_ovf, g.d_ovfCount, (ncounters + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipEventRecord(rs.done, g.stream));
+        rs.ncounters = ncounters;
+        rs.used = true;
     } catch (...) {
-        // Work may still be queued on the work, auxiliary and copy streams, and the bookkeeping of who waits for whom is
-        // half-updated: drain the device and forget it, so that a later scan starts from a clean state
+        // Work may still be queued on the auxiliary, second and copy streams, and the bookkeeping of who waits for
+        // whom is half-updated: drain the device and forget it, so that a later scan starts from a clean state
         (void)hipDeviceSynchronize();
         (void)hipGetLastError();
-        for (Lane& x : g.lanes) {
-            for (bool& u : x.auxUsed) u = false;
-            x.altUsed = false;
-        }
+        for (bool& u : g.auxUsed) u = false;
+        g.stream2Used = false;
         for (auto& sl : g.auxPending)
             for (bool& pnd : sl) pnd = false;
         for (bool& u : g.slotUsed) u = false;
         g.firstBatchStaged = false;
         g.slotBase = 0;
-        L.used = false;
+        rs.used = false;
         throw;
     }
 }
 
-// wait for the results of the query that went into lane `slot` and add up its counters
+// wait for the results of the query that went into result slot `slot` and add up its counters
 void SearchDriver::finishOnGpu(Gpu& g, int slot) {
-    Lane& L = g.lanes[slot];
+    Gpu::ResultSlot& rs = g.res[slot];
     g.lastTop = 0;
     g.lastOverflows = 0;
     g.lastRescored = 0;
-    g.lastTopS = L.h_topS;
-    g.lastTopI = L.h_topI;
-    g.lastLane = slot;
-    if (!L.used) return;
+    g.lastTopS = rs.h_topS;
+    g.lastTopI = rs.h_topI;
+    if (!rs.used) return;
     g.use();
-    HIPCHECK(hipEventSynchronize(L.done));
-    L.used = false;
-    if (L.h_ovf[L.ncounters]) {
+    HIPCHECK(hipEventSynchronize(rs.done));
+    rs.used = false;
+    if (rs.h_ovf[rs.ncounters]) {
         g.badCodes = true;
         throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
     }
-    for (size_t i = 1; i < L.ncounters; i++) g.lastRescored += L.h_ovf[i];
-    g.lastOverflows = L.h_ovf[0];
-    g.lastTop = L.top;
+    for (size_t i = 1; i < rs.ncounters; i++) g.lastRescored += rs.h_ovf[i];
+    g.lastOverflows = rs.h_ovf[0];
+    g.lastTop = rs.top;
+    rs.used = false;
     g.spanEnd = now_seconds() - scanT0_;
 }
 
@@ -981,7 +956,7 @@ void SearchDriver::submit(const char* query, int32_t queryLength) {
     if (!db_) throw std::runtime_error("setDatabase first");
     if (queryLength <= 0) throw std::runtime_error("empty query");
     if (queryLength > INT32_MAX - 132) throw std::runtime_error("query too long");  // cudasw4.cuh:1281-1285
-    if (pendingCount_ >= size_t(maxInFlight())) throw std::runtime_error("too many queries in flight: collect() first");
+    if (pendingCount_ >= size_t(kMaxInFlight)) throw std::runtime_error("too many queries in flight: collect() first");
     encodedQuery_.resize(size_t(queryLength));
     // 25-letter tables: the query keeps B, J, Z, X and '*' apart; the DB side stays the dbdata alphabet (include/cudasw4_amd.h)
     if (matrix_.dim == 25) for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue25(query[i]);
@@ -995,7 +970,7 @@ void SearchDriver::submit(const char* query, int32_t queryLength) {
     if (pendingCount_ == 0) scanT0_ = ps.t0;
     const int slot = ps.slot, k = ps.k;
     forEachGpu([this, queryLength, k, slot](Gpu& g) { enqueueOnGpu(g, queryLength, k, slot); });
-    if (!oneLane_) nextSlot_ = (nextSlot_ + 1) % kMaxInFlight;
+    nextSlot_ = (nextSlot_ + 1) % kMaxInFlight;
     pending_[(pendingHead_ + pendingCount_) % kMaxInFlight] = ps;
     pendingCount_++;
 }
@@ -1067,7 +1042,7 @@ void SearchDriver::recordKernelEvents(int mode) {
     if (mode && !recordEvents_) {
         for (auto& gp : gpus_) {  // origin of the launches' begin / end times
             gp->use();
-            HIPCHECK(hipEventRecord(gp->recordRefEv, gp->lanes[0].stream));
+            HIPCHECK(hipEventRecord(gp->recordRefEv, gp->stream));
             gp->recordRefValid = true;
         }
     }
@@ -1123,7 +1098,7 @@ void SearchDriver::lastScores(int gpu, float* scores, int64_t* ids) {
     Gpu& g = *gpus_.at(size_t(gpu));
     if (!g.numLocal) return;
     g.use();
-    HIPCHECK(hipMemcpy(scores, g.lanes[g.lastLane].d_scores, g.numLocal * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(scores, g.d_scores, g.numLocal * sizeof(float), hipMemcpyDeviceToHost));
     for (int p = 0; p < kNumLengthPartitions; p++)
         for (size_t i = 0; i < g.ranges[p].size(); i++) ids[g.localBegin[p] + i] = idBase_ + int64_t(g.ranges[p].begin + i);
 }
@@ -1132,13 +1107,13 @@ std::vector<SearchDriver::BatchInterval> SearchDriver::lastBatchIntervals() {
     std::vector<BatchInterval> out;
     for (auto& gp : gpus_) {
         Gpu& g = *gp;
-        if (g.batches.empty() || g.batchEv.size() < 2 * g.batches.size() || !g.lastScanStartEv) continue;
+        if (g.batches.empty() || g.batchEv.size() < 2 * g.batches.size()) continue;
         g.use();
         HIPCHECK(hipDeviceSynchronize());
         for (size_t k = 0; k < g.batches.size(); k++) {
             BatchInterval bi{g.index, 0.f, 0.f};
-            HIPCHECK(hipEventElapsedTime(&bi.begin_ms, g.lastScanStartEv, g.batchEv[2 * k]));
-            HIPCHECK(hipEventElapsedTime(&bi.end_ms, g.lastScanStartEv, g.batchEv[2 * k + 1]));
+            HIPCHECK(hipEventElapsedTime(&bi.begin_ms, g.scanStartEv, g.batchEv[2 * k]));
+            HIPCHECK(hipEventElapsedTime(&bi.end_ms, g.scanStartEv, g.batchEv[2 * k + 1]));
             out.push_back(bi);
         }
     }

@@ -24,8 +24,6 @@ struct sw_ctx;
 
 namespace swh {
 
-struct Lane;
-
 // types.hpp:11-16, same numbering as SW_KIND_*
 enum class KernelType { Half2 = 0, DPXs16 = 1, DPXs32 = 2, Float = 3 };
 const char* to_string(KernelType t);
@@ -135,7 +133,6 @@ public:
     void submit(const char* query, int32_t queryLength);
     ScanResult collect();
     int inFlight() const { return int(pendingCount_); }
-    int maxInFlight() const { return oneLane_ ? 1 : kMaxInFlight; }
 
     void totalTimerStart();          // cudasw4.cuh:818-824
     BenchmarkStats totalTimerStop(); // cudasw4.cuh:826-839
@@ -176,7 +173,7 @@ private:
     struct Gpu;
     struct Worker;
     void uploadShard(Gpu& g);
-    void scanStreamed(Gpu& g, struct Lane& L);
+    void scanStreamed(Gpu& g);
     void enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot);
     void finishOnGpu(Gpu& g, int slot);
     void planBatches(Gpu& g, uint64_t batchBytes);
@@ -204,7 +201,6 @@ private:
     PendingScan pending_[kMaxInFlight];
     size_t pendingHead_ = 0, pendingCount_ = 0;
     int nextSlot_ = 0;
-    bool oneLane_ = false;  // CUDASW4_AMD_ONE_LANE=1: every query on lane 0, i.e. one after the other on the GPU
     double lastDone_ = 0;
     // total timer
     double totalSeconds_ = 0;

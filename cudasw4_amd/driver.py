@@ -19,7 +19,7 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_record_kernel_events", "swdrv_take_kernel_events", "swdrv_shard_info", "swdrv_last_scores",
            "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges", "swdrv_matrix25",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
-           "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_max_in_flight"]
+           "swdrv_cached_chars", "swdrv_streamed_bytes"]
 
 
 class DriverError(RuntimeError):
@@ -56,7 +56,6 @@ def _load():
     L.swdrv_scan_collect.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.swdrv_in_flight.argtypes = [vp]
-    L.swdrv_max_in_flight.argtypes = [vp]
     L.swdrv_cached_chars.restype = ctypes.c_int64
     L.swdrv_cached_chars.argtypes = [vp, ctypes.c_int]
     L.swdrv_streamed_bytes.restype = ctypes.c_int64
@@ -342,7 +341,7 @@ class Driver:
         out = []
         for q in queries:
             self.submit(q)
-            if lib.swdrv_in_flight(self.handle) >= lib.swdrv_max_in_flight(self.handle):
+            if lib.swdrv_in_flight(self.handle) >= 2:
                 out.append(self.collect())
         while lib.swdrv_in_flight(self.handle) > 0:
             out.append(self.collect())

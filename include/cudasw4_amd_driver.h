@@ -66,7 +66,6 @@ int swdrv_scan_submit(swdrv* d, const char* query, int32_t qlen);
 int swdrv_scan_collect(swdrv* d, int32_t* scores, int64_t* ids, int cap, int* nres, int* num_overflows, double* seconds,
                        double* gcups);
 int swdrv_in_flight(swdrv* d);
-int swdrv_max_in_flight(swdrv* d); /* 2; 1 with CUDASW4_AMD_ONE_LANE=1 (A/B measurements: one query at a time on the GPU) */
 
 /* ---- measurement / verification hooks (bench.py, tests) ----
  * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 14 doubles per launch
