@@ -69,6 +69,7 @@ def parse_args(argv=None):
                     help="kernel configuration (peak default: half2; sprot-like default: dpx = DPXs16/DPXs16/DPXs32/DPXs32)")
     ap.add_argument("--top", type=int, default=10, help="top-K per query inside the timed region (reference scripts: 0)")
     ap.add_argument("--max-gpu-mem", default="0", help="per-GPU memory limit (K/M/G suffix); small values force batch streaming")
+    ap.add_argument("--max-batch-bytes", default="0", help="batch size of the streamed part of a shard (K/M/G suffix; default 128M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="peak workload: skip the Swiss-Prot-like secondary measurement")
@@ -383,7 +384,8 @@ def measure(env, args, workload, want_cpu):
     strong = args.scaling == "strong" or not distributed
     K = max(args.top, 0)
 
-    drv = driver.Driver(devices=[local_rank], num_top=K, matrix=62, kinds=kinds, max_gpu_mem=parse_size(args.max_gpu_mem))
+    drv = driver.Driver(devices=[local_rank], num_top=K, matrix=62, kinds=kinds, max_gpu_mem=parse_size(args.max_gpu_mem),
+                        max_batch_bytes=parse_size(args.max_batch_bytes))
     host_db = None
     data = "synthetic"
     if args.workload == "peak":

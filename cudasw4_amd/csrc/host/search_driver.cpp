@@ -873,8 +873,12 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
         HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
         // the cached part first (the longest subjects: one set of launches over everything that is resident), then the
         // streamed batches — whose first copies run while the cached part computes
-        if (g.cacheBegin < g.numLocal)
+        if (g.cacheBegin < g.numLocal) {
             enqueue_batch(g, g.d_chars, g.cacheBegin, g.numLocal, *db_, kernels_, memory_, gop_, gex_, recordEvents_, 0, -1, false);
+            // (the first streamed batch, usually staged already by the previous scan, starts on the second work stream next
+            // to this launch; making it wait for the cached part was measured and is slower: 10.49 against 10.71 TCUPS on the
+            // Swiss-Prot-like DB with 65 % cached, 10.91 against 11.21 on the peak DB with 25 % cached)
+        }
         if (!g.batches.empty()) scanStreamed(g);
         join_aux(g);
         const int kk = int(std::min<size_t>(size_t(std::max(k, 0)), g.numLocal));
