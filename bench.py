@@ -257,7 +257,7 @@ def roofline_objects(args, workload, kernel_name, events, info):
                                                         "multi-stripe" if ev[0]["nstripes"] > 1 else "single stripe")
     traffic, tnote = None, cnote
     if counters:
-        t = (counters.get("traffic_bytes_per_char") or {}).get(key)
+        t = (counters.get("traffic_bytes_per_char") or {}).get("%s|%s" % (workload, key))
         if t and sorted(set(e["nstripes"] for e in ev)) == t.get("nstripes"):
             traffic = int(t["value"] * avg_chars)
             tnote = "%.2f HBM-side bytes per subject byte of this instantiation (%s) x %d subject bytes per launch here" % (
@@ -275,7 +275,12 @@ def roofline_objects(args, workload, kernel_name, events, info):
     # 64 lanes/clk/CU, 256 CUs at 2.4 GHz; fp32 kind: v_add_f32 co-issues with v_max3_f32 (99.5 lanes/clk/CU)
     packed = kind in (0, 1)
     kern_gcups = sum(e["cells"] for e in events) / 1e9 / (busy_ms * 1e-3)
-    valu_peak = 256 * (99.5 if kind == 3 else 64) * 2.4e9
+    # lanes/clk/CU the kind's instruction mix can issue at best (tools/ubench/valu_rate.hip, mix_rate.hip):
+    # packed 16-bit ops are VOP3P, one wave64 instruction per 4 cycles per SIMD = 64; the fp32 kind's v_add_f32 co-issues
+    # with v_max3_f32: 99.5 for its 8:7 mix; the int32 kind cannot co-issue, but its v_add_u32 (VOP2) issue at 98 when alone
+    # and its v_max3_i32 at 64: 2.25 adds + 3.5 max3 per cell -> 5.75 / (2.25 / 98 + 3.5 / 64) = 74
+    lanes_per_clk = {0: 64.0, 1: 64.0, 2: 5.75 / (2.25 / 98.0 + 3.5 / 64.0), 3: 99.5}[kind]
+    valu_peak = 256 * lanes_per_clk * 2.4e9
     residency = residency_of(info)
     ipu, ipu_key = None, None
     if counters:

@@ -137,7 +137,7 @@ def test_roofline_accounting_of_sequential_and_overlapping_launches(monkeypatch)
     args = b.parse_args(["--steps", "1"])
     counters = {"kernel_src_sha16": "x",
                 "valu_instr_per_unit": {"peak:half2:resident": {"value": 6.3, "source": "profiles/fake_pmc.txt"}},
-                "traffic_bytes_per_char": {"sw_scan_kernel<0, 43, 16, true,": {"value": 60.0, "nstripes": [8], "source": "profiles/fake_pmc.txt"}}}
+                "traffic_bytes_per_char": {"peak|sw_scan_kernel<0, 43, 16, true,": {"value": 60.0, "nstripes": [8], "source": "profiles/fake_pmc.txt"}}}
     monkeypatch.setattr(b, "load_counters", lambda: (counters, None))
     # four 128 MB batches one after the other, 64 ms each, at the rate of a VALU-bound kernel (~11.5 TCUPS at qlen 5478)
     batch = 128 << 20

@@ -237,7 +237,7 @@ def test_align_with_the_vector_loader_fallback():
 
 def test_more_than_4_gib_of_subject_chars_resident_and_streamed():
     """Offsets beyond 2^32: a pseudo DB of 8.5 million subjects x 512 residues (4.35 GB of chars) through the C++ driver,
-    resident and streamed in 1 GiB batches; every score equals the reference's golden score, ids are global."""
+    resident and above a 2 GiB memory limit (part cached, the rest streamed); every score equals the reference's golden score, ids are global."""
     from cudasw4_amd import driver
     g = O.golden("ref_scores.json")
     _, seqs = O.read_fasta(FASTA)

@@ -75,7 +75,7 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
 
     * valu_instr_per_unit[workload:kernel configuration:residency]: VALU lane-instructions per useful cell (pair) over
       the pass = SQ_INSTS_VALU x 64 over all DP launches / cells of the pass;
-    * traffic_bytes_per_char[kernel instantiation]: HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, in KB, corrected as
+    * traffic_bytes_per_char[workload|kernel instantiation]: HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, in KB, corrected as
       MI355X_MICROARCH.md prescribes for gfx950) over all launches of the instantiation / the subject bytes those
       launches read (from the line's table) — bench.py scales it by the subject bytes of ITS launches.
 
@@ -134,7 +134,7 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
             continue  # another form of the recurrence shares the prefix, or the passes differ: no figure rather than a wrong one
         # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports by 2x on gfx950
         total = (2.0 * f[name][1] + (w[name][1] if name in w else 0.0)) * 1024
-        cur["traffic_bytes_per_char"][m.group(1)] = {"value": round(total / t["chars"], 4), "nstripes": t["nstripes"],
+        cur["traffic_bytes_per_char"]["%s|%s" % (workload, m.group(1))] = {"value": round(total / t["chars"], 4), "nstripes": t["nstripes"],
                                                      "launches": t["launches"], "chars_per_launch": int(t["chars"] / t["launches"]),
                                                      "source": source, "commit": commit}
         detail[name] = {"launches": f[name][0], "fetch_kb_raw_sum": f[name][1], "write_kb_sum": w[name][1] if name in w else 0.0,
