@@ -134,7 +134,11 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
             continue  # another form of the recurrence shares the prefix, or the passes differ: no figure rather than a wrong one
         # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports by 2x on gfx950
         total = (2.0 * f[name][1] + (w[name][1] if name in w else 0.0)) * 1024
-        cur["traffic_bytes_per_char"]["%s|%s" % (workload, m.group(1))] = {"value": round(total / t["chars"], 4), "nstripes": t["nstripes"],
+        tkey = "%s|%s" % (workload, m.group(1))
+        old = cur["traffic_bytes_per_char"].get(tkey)
+        if old and old.get("chars_per_launch", 0) > t["chars"] / t["launches"]:
+            continue  # the figure of the larger launches (the resident run) stays: batches only add launch-edge traffic
+        cur["traffic_bytes_per_char"][tkey] = {"value": round(total / t["chars"], 4), "nstripes": t["nstripes"],
                                                      "launches": t["launches"], "chars_per_launch": int(t["chars"] / t["launches"]),
                                                      "source": source, "commit": commit}
         detail[name] = {"launches": f[name][0], "fetch_kb_raw_sum": f[name][1], "write_kb_sum": w[name][1] if name in w else 0.0,
