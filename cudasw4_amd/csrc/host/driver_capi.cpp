@@ -271,6 +271,28 @@ int swdrv_shard_ranges(const int32_t* sorted_lengths, const uint64_t* offsets, s
     });
 }
 
+int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_len, size_t max_gpu_mem, size_t max_batch_bytes,
+                         size_t max_batch_sequences, size_t max_temp_bytes, size_t free_mem, int allow_cache, int64_t* cache_begin,
+                         int64_t* cache_bytes, int64_t* batch_bytes, int64_t* batches, int cap) {
+    int nb = -1;
+    const int rc = guarded([&] {
+        if (!local_offsets) throw std::runtime_error("null offsets");
+        MemoryConfig mc;
+        if (max_gpu_mem) mc.maxGpuMem = max_gpu_mem;
+        if (max_batch_bytes) mc.maxBatchBytes = max_batch_bytes;
+        if (max_batch_sequences) mc.maxBatchSequences = max_batch_sequences;
+        if (max_temp_bytes) mc.maxTempBytes = max_temp_bytes;
+        const std::vector<uint64_t> off(local_offsets, local_offsets + n + 1);
+        const ResidencyPlan rp = plan_residency(off, max_len, mc, free_mem, 3, allow_cache != 0);
+        if (cache_begin) *cache_begin = int64_t(rp.cacheBegin);
+        if (cache_bytes) *cache_bytes = int64_t(rp.cacheBytes);
+        if (batch_bytes) *batch_bytes = int64_t(rp.batchBytes);
+        nb = int(rp.batches.size());
+        for (int i = 0; i < nb && i < cap; i++) { batches[2 * i] = int64_t(rp.batches[size_t(i)].first); batches[2 * i + 1] = int64_t(rp.batches[size_t(i)].second); }
+    });
+    return rc == 0 ? nb : -1;
+}
+
 int swdrv_last_rescored(swdrv* d) { return d ? d->lastRescored : 0; }
 
 int32_t swdrv_reference_length(swdrv* d, int64_t id) { return d->driver->getReferenceLength(id); }

@@ -445,36 +445,21 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
             HIPCHECK(hipMemcpyAsync(g.d_lengths + g.localBegin[p], db_->lengths() + r.begin, r.size() * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
         }
         HIPCHECK(hipStreamSynchronize(g.stream));
-        // Residency decision (GpuWorkingSet, cudasw4.cuh:317-392,1020-1026).  The limit covers everything this GPU holds:
-        // the per-subject metadata and result arrays allocated above (24 bytes per subject), the scratch of multi-stripe
-        // queries, and the chars — resident when they fit, otherwise three staging buffers of one batch each plus as
-        // much of the shard as still fits next to them (the reference: "N out of M DB batches will be cached").
         size_t freeMem = 0, totalMem = 0;
         HIPCHECK(hipMemGetInfo(&freeMem, &totalMem));
-        const size_t meta = n * 24 + 8;
-        size_t limit = std::min(memory_.maxGpuMem > meta ? memory_.maxGpuMem - meta : 0, freeMem);
-        const size_t safety = size_t(256) << 20;
-        if (limit > safety) limit -= safety;  // cudasw4.cuh:1020-1026: a limit below the margin is taken as it is
-        const size_t fixed = std::min({memory_.maxTempBytes, size_t(1) << 30, limit / 4});  // scratch of multi-stripe queries
-        const size_t avail = limit - fixed;
+        const ResidencyPlan rp = plan_residency(g.localOffsets, g.maxLen, memory_, freeMem, Gpu::kSlots, !(noHybrid && noHybrid[0] == '1'));
+        g.cacheBegin = rp.cacheBegin;
+        g.cacheBytes = rp.cacheBytes;
         g.batches.clear();
-        g.cacheBegin = 0;
-        g.cacheBytes = g.localChars;
-        if (g.numLocal && g.localChars + 64 > avail) {
-            // staging takes at most half of what is there, a batch is never smaller than the longest subject
-            const uint64_t minBatch = std::max<uint64_t>(uint64_t(g.maxLen) + 4, std::min<uint64_t>(memory_.maxBatchBytes, uint64_t(1) << 20));
-            const uint64_t batchBytes = std::max<uint64_t>(std::min<uint64_t>(memory_.maxBatchBytes, avail / (2 * Gpu::kSlots)), minBatch);
-            const uint64_t staging = uint64_t(Gpu::kSlots) * (batchBytes + 64);
-            const uint64_t budget = avail > staging + 64 ? avail - staging - 64 : 0;
-            // the cached suffix: the longest subjects, as many as fit; a sliver below one batch is not worth a launch
-            size_t cb = size_t(std::lower_bound(g.localOffsets.begin(), g.localOffsets.end(), g.localChars > budget ? g.localChars - budget : 0) - g.localOffsets.begin());
-            if ((noHybrid && noHybrid[0] == '1') || g.localChars - g.localOffsets[cb] < batchBytes) cb = g.numLocal;
-            g.cacheBegin = cb;
-            g.cacheBytes = g.localChars - g.localOffsets[cb];
-            planBatches(g, batchBytes);
-            g.batchChecked.assign(g.batches.size(), false);
-            anyStreamed = true;
+        for (const auto& be : rp.batches) {
+            Batch bt;
+            bt.lbegin = be.first; bt.lend = be.second;
+            bt.bytes = g.localOffsets[be.second] - g.localOffsets[be.first];
+            bt.maxLen = db_->length(size_t(g.toGlobal(int64_t(be.second - 1))));
+            g.batches.push_back(bt);
         }
+        g.batchChecked.assign(g.batches.size(), false);
+        if (!g.batches.empty()) anyStreamed = true;
         if (verbose_) {
             std::cout << "gpu " << g.device << ": " << g.numLocal << " sequences, " << g.localChars << " chars, ";
             if (g.cacheBegin == 0) std::cout << "resident\n";
@@ -532,27 +517,51 @@ void SearchDriver::registerStreamedRanges() {
     }
 }
 
-// Batches of the streamed part of a shard (computeDbCopyPlan, cudasw4.cuh:1177-1277): consecutive shard-local subjects
-// below cacheBegin, up to batchBytes / maxBatchSequences each; a batch may span adjacent length partitions (its scan is
-// then several launches).
-void SearchDriver::planBatches(Gpu& g, uint64_t batchBytes) {
-    const size_t maxSeq = std::max<size_t>(1, memory_.maxBatchSequences);
-    const uint64_t maxBytes = std::max<uint64_t>(batchBytes, uint64_t(g.maxLen) + 4);
-    const auto end = g.localOffsets.begin() + long(g.cacheBegin) + 1;
+// Residency decision (GpuWorkingSet, cudasw4.cuh:317-392,1020-1026).  The limit covers everything a GPU holds: the
+// per-subject metadata and result arrays (24 bytes per subject), the scratch of multi-stripe queries, and the chars —
+// resident when they fit, otherwise three staging buffers of one batch each plus as much of the shard as still fits next
+// to them (the reference: "N out of M DB batches will be cached").  The streamed part is cut into batches like
+// computeDbCopyPlan (cudasw4.cuh:1177-1277): consecutive subjects up to batchBytes / maxBatchSequences each; a batch may
+// span adjacent length partitions (its scan is then several launches).
+ResidencyPlan plan_residency(const std::vector<uint64_t>& localOffsets, int32_t maxLen, const MemoryConfig& memory,
+                             size_t freeMem, int stagingSlots, bool allowCache) {
+    ResidencyPlan rp;
+    const size_t numLocal = localOffsets.empty() ? 0 : localOffsets.size() - 1;
+    const uint64_t localChars = numLocal ? localOffsets[numLocal] : 0;
+    const size_t n = std::max<size_t>(numLocal, 1);
+    const size_t meta = n * 24 + 8;
+    size_t limit = std::min(memory.maxGpuMem > meta ? memory.maxGpuMem - meta : 0, freeMem);
+    const size_t safety = size_t(256) << 20;
+    if (limit > safety) limit -= safety;  // cudasw4.cuh:1020-1026: a limit below the margin is taken as it is
+    const size_t fixed = std::min({memory.maxTempBytes, size_t(1) << 30, limit / 4});  // scratch of multi-stripe queries
+    const size_t avail = limit - fixed;
+    rp.cacheBegin = 0;
+    rp.cacheBytes = localChars;
+    if (!numLocal || localChars + 64 <= avail) return rp;
+    // staging takes at most half of what is there, a batch is never smaller than the longest subject
+    const uint64_t minBatch = std::max<uint64_t>(uint64_t(maxLen) + 4, std::min<uint64_t>(memory.maxBatchBytes, uint64_t(1) << 20));
+    const uint64_t batchBytes = std::max<uint64_t>(std::min<uint64_t>(memory.maxBatchBytes, avail / (2 * uint64_t(stagingSlots))), minBatch);
+    const uint64_t staging = uint64_t(stagingSlots) * (batchBytes + 64);
+    const uint64_t budget = avail > staging + 64 ? avail - staging - 64 : 0;
+    // the cached suffix: the longest subjects, as many as fit; a sliver below one batch is not worth a launch
+    size_t cb = size_t(std::lower_bound(localOffsets.begin(), localOffsets.end(), localChars > budget ? localChars - budget : 0) - localOffsets.begin());
+    if (!allowCache || localChars - localOffsets[cb] < batchBytes) cb = numLocal;
+    rp.cacheBegin = cb;
+    rp.cacheBytes = localChars - localOffsets[cb];
+    rp.batchBytes = batchBytes;
+    const size_t maxSeq = std::max<size_t>(1, memory.maxBatchSequences);
+    const auto end = localOffsets.begin() + long(cb) + 1;
     size_t cur = 0;
-    while (cur < g.cacheBegin) {
-        // largest e with offsets[e] - offsets[cur] <= maxBytes and e - cur <= maxSeq
-        const uint64_t target = g.localOffsets[cur] + maxBytes;
-        size_t e = size_t(std::upper_bound(g.localOffsets.begin() + long(cur), end, target) - g.localOffsets.begin()) - 1;
+    while (cur < cb) {
+        // largest e with offsets[e] - offsets[cur] <= batchBytes and e - cur <= maxSeq
+        const uint64_t target = localOffsets[cur] + batchBytes;
+        size_t e = size_t(std::upper_bound(localOffsets.begin() + long(cur), end, target) - localOffsets.begin()) - 1;
         e = std::min(e, cur + maxSeq);
-        e = std::min(std::max(e, cur + 1), g.cacheBegin);
-        Batch b;
-        b.lbegin = cur; b.lend = e;
-        b.bytes = g.localOffsets[e] - g.localOffsets[cur];
-        b.maxLen = db_->length(size_t(g.toGlobal(int64_t(e - 1))));
-        g.batches.push_back(b);
+        e = std::min(std::max(e, cur + 1), cb);
+        rp.batches.emplace_back(cur, e);
         cur = e;
     }
+    return rp;
 }
 
 // the chars that stay in device memory: the whole shard, or its cached suffix

@@ -15,6 +15,7 @@
 #include <memory>
 #include <string>
 #include <string_view>
+#include <utility>
 #include <vector>
 
 #include "db_format.hpp"
@@ -89,6 +90,21 @@ std::vector<LaunchRun> plan_launch_runs(const KernelTypeConfig& kt, const size_t
     }
     return runs;
 }
+
+// Residency of one GPU's shard (GpuWorkingSet + assignBatchesToGpuMem + computeDbCopyPlan, cudasw4.cuh:317-392,1087-1144,
+// 1177-1277): what stays in device memory and how the rest is cut into streamed batches.  Pure host logic (no GPU call);
+// the driver calls it in setDatabase, the CPU tests through swdrv_plan_residency.
+struct ResidencyPlan {
+    size_t cacheBegin = 0;      // shard-local subjects [cacheBegin, n) keep their chars in device memory (0: resident)
+    uint64_t cacheBytes = 0;
+    uint64_t batchBytes = 0;    // size limit of a streamed batch (0 when nothing is streamed)
+    std::vector<std::pair<size_t, size_t>> batches;  // [begin, end) of every streamed batch, ascending
+};
+// localOffsets[n + 1]: byte offsets of the shard's subjects (ascending length); maxLen: its longest subject;
+// freeMem: what the device reports free after the per-subject metadata and result arrays (24 bytes per subject) are
+// allocated; allowCache = false: all-or-nothing residency (CUDASW4_AMD_NO_HYBRID=1)
+ResidencyPlan plan_residency(const std::vector<uint64_t>& localOffsets, int32_t maxLen, const MemoryConfig& memory,
+                             size_t freeMem, int stagingSlots, bool allowCache);
 
 // One timed launch (HIP events on the stream the kernel ran on), for bench.py's roofline
 struct KernelEvent {
@@ -176,7 +192,6 @@ private:
     void scanStreamed(Gpu& g);
     void enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot);
     void finishOnGpu(Gpu& g, int slot);
-    void planBatches(Gpu& g, uint64_t batchBytes);
     void registerStreamedRanges();
     void unregisterRanges();
     template <class F> void forEachGpu(F&& fn);

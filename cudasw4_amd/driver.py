@@ -19,7 +19,7 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_record_kernel_events", "swdrv_take_kernel_events", "swdrv_shard_info", "swdrv_last_scores",
            "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges", "swdrv_matrix25",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
-           "swdrv_cached_chars", "swdrv_streamed_bytes"]
+           "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency"]
 
 
 class DriverError(RuntimeError):
@@ -60,6 +60,8 @@ def _load():
     L.swdrv_cached_chars.argtypes = [vp, ctypes.c_int]
     L.swdrv_streamed_bytes.restype = ctypes.c_int64
     L.swdrv_streamed_bytes.argtypes = [vp]
+    L.swdrv_plan_residency.argtypes = [vp, sz, i32, sz, sz, sz, sz, sz, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), vp, ctypes.c_int]
     L.swdrv_reference_length.restype = i32
     L.swdrv_reference_length.argtypes = [vp, ctypes.c_int64]
     L.swdrv_reference_header.argtypes = [vp, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int]
@@ -175,6 +177,24 @@ def shard_ranges(offsets, sorted_lengths, world):
     _check(lib.swdrv_shard_ranges(l.ctypes.data, o.ctypes.data, len(l), world, out.ctypes.data))
     out = out.reshape(world, 36, 2)
     return [[(int(b), int(e)) for b, e in out[r]] for r in range(world)]
+
+
+def plan_residency(local_offsets, max_len, max_gpu_mem=0, max_batch_bytes=0, max_batch_sequences=0, max_temp_bytes=0,
+                   free_mem=288 << 30, allow_cache=True):
+    """The C++ driver's residency decision for one GPU's shard (plan_residency; no GPU needed) -> dict: cache_begin (the
+    subjects from there on stay in device memory), cache_bytes, batch_bytes, batches = [(begin, end), ...] of the rest."""
+    o = np.ascontiguousarray(local_offsets, dtype=np.uint64)
+    n = len(o) - 1
+    cap = max(n, 1)
+    out = np.zeros(2 * cap, dtype=np.int64)
+    cb, cby, bb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    nb = lib.swdrv_plan_residency(o.ctypes.data, n, int(max_len), max_gpu_mem, max_batch_bytes, max_batch_sequences,
+                                  max_temp_bytes, free_mem, int(allow_cache), ctypes.byref(cb), ctypes.byref(cby),
+                                  ctypes.byref(bb), out.ctypes.data, cap)
+    if nb < 0:
+        raise DriverError(lib.swdrv_last_error().decode())
+    return {"cache_begin": cb.value, "cache_bytes": cby.value, "batch_bytes": bb.value,
+            "batches": [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(nb)]}
 
 
 class Driver:

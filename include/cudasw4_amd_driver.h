@@ -99,6 +99,16 @@ int swdrv_plan_runs(const int32_t* sorted_lengths, size_t n, int kind_single, in
  * begin / end of the subject range of `rank` in `partition`. */
 int swdrv_shard_ranges(const int32_t* sorted_lengths, const uint64_t* offsets, size_t n, int world, int64_t* out);
 
+/* The residency decision of one GPU's shard (no GPU needed; GpuWorkingSet + assignBatchesToGpuMem + computeDbCopyPlan,
+ * cudasw4.cuh:317-392,1087-1144,1177-1277): local_offsets[n + 1] = byte offsets of the shard's subjects in ascending
+ * length, max_len its longest subject, free_mem what the device has free, the limits as in swdrv_create (0 = default).
+ * -> *cache_begin: subjects [cache_begin, n) keep their chars in device memory (0: the shard is resident), *cache_bytes
+ * their bytes, *batch_bytes the batch size of the streamed rest, batches[2 i], [2 i + 1] = begin / end of streamed batch
+ * i; returns the number of batches (may exceed cap), -1 on error.  allow_cache = 0: all-or-nothing residency. */
+int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_len, size_t max_gpu_mem, size_t max_batch_bytes,
+                         size_t max_batch_sequences, size_t max_temp_bytes, size_t free_mem, int allow_cache,
+                         int64_t* cache_begin, int64_t* cache_bytes, int64_t* batch_bytes, int64_t* batches, int cap);
+
 /* header / length of a subject by global id (getReferenceHeader / getReferenceLength) */
 int32_t swdrv_reference_length(swdrv* d, int64_t id);
 int swdrv_reference_header(swdrv* d, int64_t id, char* buf, int cap);

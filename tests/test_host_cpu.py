@@ -392,3 +392,51 @@ def test_parallel_blocks_helper(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I", inc, src, "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_residency_plan_hybrid_and_batches():
+    """The residency decision of a GPU's shard (plan_residency; GpuWorkingSet / assignBatchesToGpuMem / computeDbCopyPlan,
+    cudasw4.cuh:317-392,1087-1144,1177-1277) without a GPU: resident when the chars fit, otherwise the longest subjects
+    cached and the rest cut into batches that cover it exactly; the limit is respected; degenerate limits still work."""
+    from cudasw4_amd import driver, synthdb
+    lengths = synthdb.sprot_like_lengths(40000, seed=5, max_len=12000).astype(np.int64)
+    padded = (lengths + 3) // 4 * 4
+    off = np.concatenate([[0], np.cumsum(padded)]).astype(np.uint64)
+    n, chars, max_len = len(lengths), int(off[-1]), int(lengths[-1])
+    meta = 24 * n + 8
+    # fits: resident, nothing streamed
+    r = driver.plan_residency(off, max_len)
+    assert r["cache_begin"] == 0 and r["cache_bytes"] == chars and r["batches"] == []
+    # does not fit: hybrid
+    for frac in (0.25, 0.5, 0.7):
+        batch = 1 << 20
+        limit = int((frac * chars + 3 * (batch + 64) + 64) / 0.75) + meta
+        r = driver.plan_residency(off, max_len, max_gpu_mem=limit, max_batch_bytes=batch)
+        cb = r["cache_begin"]
+        assert 0 < cb < n and r["cache_bytes"] == chars - int(off[cb])
+        assert abs(r["cache_bytes"] - frac * chars) < 0.02 * chars + max_len + 8      # what the budget allows, to a subject
+        assert r["batch_bytes"] == batch
+        b = r["batches"]
+        assert b[0][0] == 0 and b[-1][1] == cb and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+        assert all(int(off[e] - off[s]) <= batch for s, e in b) and all(e > s for s, e in b)
+        # everything the limit pays for: metadata, scratch quarter, staging, cache
+        used = meta + (limit - meta) // 4 + 3 * (batch + 64) + r["cache_bytes"]
+        assert used <= limit
+        # without the cache the same limit streams everything
+        r0 = driver.plan_residency(off, max_len, max_gpu_mem=limit, max_batch_bytes=batch, allow_cache=False)
+        assert r0["cache_begin"] == n and r0["cache_bytes"] == 0 and r0["batches"][-1][1] == n
+    # a limit of one byte: everything streamed, a batch still holds the longest subject; batch sequence limit honoured
+    r = driver.plan_residency(off, max_len, max_gpu_mem=1, max_batch_bytes=6000, max_batch_sequences=7)
+    assert r["cache_begin"] == n and r["batch_bytes"] >= max_len + 4
+    assert all(e - s <= 7 for s, e in r["batches"]) and r["batches"][-1][1] == n
+    assert all(int(off[e] - off[s]) <= r["batch_bytes"] for s, e in r["batches"])
+    # the 256 MiB safety margin (cudasw4.cuh:1020-1026) applies only to limits above it
+    big = driver.plan_residency(off, max_len, max_gpu_mem=(300 << 20) + meta, max_batch_bytes=1 << 20)
+    small = driver.plan_residency(off, max_len, max_gpu_mem=(200 << 20) + meta, max_batch_bytes=1 << 20)
+    assert small["cache_bytes"] == chars and big["cache_bytes"] == chars   # 23 MB of chars fit both
+    # the device's free memory caps the limit
+    r = driver.plan_residency(off, max_len, free_mem=chars // 2, max_batch_bytes=1 << 20)
+    assert 0 < r["cache_begin"] <= n and r["cache_bytes"] < chars // 2
+    # an empty shard
+    r = driver.plan_residency(np.zeros(1, dtype=np.uint64), 0, max_gpu_mem=1)
+    assert r["cache_begin"] == 0 and r["batches"] == []
