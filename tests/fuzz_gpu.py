@@ -109,12 +109,26 @@ def main(argv=None):
         else:
             letters = bytes(LETTERS21[c] for c in q)
             devs = [[0], [0, 0], [0, 0, 0]][int(r.integers(0, 3))]
-            kw = {}
-            if r.integers(0, 2):
-                kw = dict(max_gpu_mem=1, max_batch_bytes=int(r.choice([2000, 20000, 300000])))
+            kw, mode = {}, "resident"
+            pick = int(r.integers(0, 3))
+            if pick == 1:
+                kw, mode = dict(max_gpu_mem=1, max_batch_bytes=int(r.choice([2000, 20000, 300000]))), "streamed"
+            elif pick == 2:
+                # hybrid residency: a limit that leaves room for a random part of a shard next to the staging buffers
+                batch = int(r.choice([2000, 20000, 300000]))
+                shard = max(1, int(offsets[-1]) // len(devs))
+                kw = dict(max_gpu_mem=int((float(r.uniform(0.1, 0.9)) * shard + 3 * (batch + 64) + 64) / 0.75) + 24 * n + 8,
+                          max_batch_bytes=batch)
+                mode = "hybrid"
             d = driver.Driver(devices=devs, num_top=min(10, n), kinds=kinds, **kw)
             d.db_from_arrays(chars, offsets, lens)
-            rr = d.scan(letters)
+            if r.integers(0, 3) == 0:
+                # two queries in flight (submit / collect): the second one's results are the ones checked
+                other = bytes(LETTERS21[c] for c in r.integers(0, 20, int(r.integers(1, 400))))
+                rr = d.scan_many([other, letters])[1]
+                mode += " pipelined"
+            else:
+                rr = d.scan(letters)
             ids, sc = d.all_scores()
             got = np.empty_like(sc)
             got[ids] = sc
@@ -127,7 +141,7 @@ def main(argv=None):
                 print("FAIL overflow statistic", rr["num_overflows"], rr["num_rescored"], want_ovf, desc)
                 sys.exit(1)
             d.close()
-            desc += " devs %d %s" % (len(devs), "streamed" if kw else "resident")
+            desc += " devs %d %s" % (len(devs), mode)
         es, ei = O.topk(expect, min(10, n))
         ok = (got == expect).all() and list(top[0]) == es.tolist() and list(top[1]) == ei.tolist()
         print(("ok   " if ok else "FAIL ") + desc, flush=True)
