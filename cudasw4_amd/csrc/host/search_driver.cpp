@@ -125,6 +125,7 @@ struct SearchDriver::Gpu {
     int8_t* d_staging[kSlots] = {nullptr, nullptr, nullptr};
     size_t stagingCap = 0;
     int8_t* h_pinned[kSlots] = {nullptr, nullptr, nullptr};
+    int8_t* h_pad = nullptr;  // pinned: 64 padding letters (the bytes behind a staged batch)
     size_t pinnedCap = 0;
     hipEvent_t copied[kSlots] = {nullptr, nullptr, nullptr}, scanned[kSlots] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> batchEv;  // 2 per batch of the last streamed scan (intervals for tests / tuning)
@@ -258,6 +259,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), matrix_.dim));
         HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
+        HIPCHECK(hipHostMalloc(&g->h_pad, 64));
+        std::memset(g->h_pad, kOtherCode, 64);
         for (auto& e : g->forkEvent) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&g->join2Event, hipEventDisableTiming));
         HIPCHECK(hipEventCreate(&g->scanStartEv));
@@ -304,6 +307,7 @@ SearchDriver::~SearchDriver() {
             for (int a = 0; a < Gpu::kAux; a++)
                 if (g.auxDone[i][a]) (void)hipEventDestroy(g.auxDone[i][a]);
         }
+        (void)hipHostFree(g.h_pad);
         for (hipEvent_t e : g.batchEv) (void)hipEventDestroy(e);
         if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
         if (g.recordRefEv) (void)hipEventDestroy(g.recordRefEv);
@@ -801,7 +805,10 @@ void SearchDriver::scanStreamed(Gpu& g) {
             }
         });
         if (!dbRegistered_) HIPCHECK(hipMemcpyAsync(dst, g.h_pinned[slot], b.bytes, hipMemcpyHostToDevice, g.copyStream));
-        HIPCHECK(hipMemsetAsync(dst + b.bytes, kOtherCode, 64, g.copyStream));
+        // the 64 padding bytes behind the batch come by DMA from a pinned block of padding letters, not from
+        // hipMemsetAsync: a memset is a KERNEL, and on the copy stream it would wait for a free workgroup slot — which the
+        // persistent grid of the batch that is computing only frees at its tail — with every later copy queued behind it
+        HIPCHECK(hipMemcpyAsync(dst + b.bytes, g.h_pad, 64, hipMemcpyHostToDevice, g.copyStream));
         HIPCHECK(hipEventRecord(g.copied[slot], g.copyStream));
         g.streamedBytes += b.bytes;
     };
