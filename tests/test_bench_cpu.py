@@ -160,3 +160,65 @@ def test_roofline_accounting_of_sequential_and_overlapping_launches(monkeypatch)
     # a configuration without a counter entry reports null, never a borrowed number
     _, valu3, _ = b.roofline_objects(args, "peak", "float", ev2, {"resident": True, "cached_chars": batch, "chars": batch})
     assert valu3["frac"] is None and "peak:float:resident" in valu3["counters_note"]
+
+
+def test_counter_tool_builds_the_entries_bench_reads(tmp_path, monkeypatch):
+    """tools/rocprof_summary.py counters (run by tools/collect_profiles.sh on the GPU box) on a hand-made rocprofv3
+    database: instructions per cell pair = SQ_INSTS_VALU x 64 / (cells / 2); traffic per subject byte = (2 x FETCH_SIZE +
+    WRITE_SIZE) KB / the subject bytes of the line's kernel table; one entry per workload / configuration / residency with
+    its own source; the figure of the larger launches is kept when a streamed run of the same kernel comes later; and
+    bench.py's lookups find what the tool wrote."""
+    import importlib.util
+    import json
+    import shutil
+    import sqlite3
+    root = tmp_path / "repo"
+    (root / "tools").mkdir(parents=True)
+    (root / "profiles").mkdir()
+    for rel in ("cudasw4_amd/csrc/sw_dp_kernel.hpp", "cudasw4_amd/csrc/sw_launch.hpp", "cudasw4_amd/csrc/sw_api.hip", "cudasw4_amd/csrc/Makefile"):
+        (root / rel).parent.mkdir(parents=True, exist_ok=True)
+        shutil.copy(os.path.join(ROOT, rel), root / rel)
+    shutil.copy(os.path.join(ROOT, "tools", "rocprof_summary.py"), root / "tools" / "rocprof_summary.py")
+    spec = importlib.util.spec_from_file_location("rs", str(root / "tools" / "rocprof_summary.py"))
+    rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rs)
+
+    name = "void swk::sw_scan_kernel<0, 43, 16, true, true>(swk::ScanParams)"
+
+    def mk(path, rows):
+        db = sqlite3.connect(str(path))
+        db.execute("create table counters_collection(kernel_name text, counter_name text, value real, duration real)")
+        db.executemany("insert into counters_collection values (?,?,?,?)", rows)
+        db.commit()
+
+    def run(tag, residency, launches, chars_total, fetch_kb, write_kb, insts):
+        mk(tmp_path / (tag + "_f.db"), [(name, "FETCH_SIZE", fetch_kb / launches, 1.0)] * launches)
+        mk(tmp_path / (tag + "_w.db"), [(name, "WRITE_SIZE", write_kb / launches, 1.0)] * launches)
+        mk(tmp_path / (tag + "_v.db"), [(name, "SQ_INSTS_VALU", insts / launches, 1.0)] * launches)
+        line = {"dtype": "f16x2", "config": {"workload": "peak: allqueries.fasta (20 queries, 41752 residues) vs x", "kernel": "half2", "residency": residency},
+                "kernels": [{"kernel": "sw_scan_kernel<0, 43, 16, true, *>", "launches": launches, "total_ms": 1.0, "chars": chars_total,
+                             "cells": 5478.0 * chars_total, "nstripes": [8]}]}
+        (tmp_path / (tag + ".log")).write_text("noise\n" + json.dumps(line) + "\n")
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            rs.counters(str(tmp_path / (tag + ".log")), str(tmp_path / (tag + "_f.db")), str(tmp_path / (tag + "_w.db")),
+                        str(tmp_path / (tag + "_v.db")), "profiles/%s_pmc.txt" % tag, "abc1234")
+
+    chars = 512_000_000
+    cells = 5478.0 * chars
+    run("res", "resident", 1, chars, fetch_kb=7.4e6, write_kb=16.8e6, insts=6.3 * (cells / 2) / 64)
+    run("hyb", "hybrid", 4, chars, fetch_kb=7.5e6, write_kb=17.0e6, insts=6.4 * (cells / 2) / 64)
+    kc = json.load(open(root / "profiles" / "kernel_counters.json"))
+    assert abs(kc["valu_instr_per_unit"]["peak:half2:resident"]["value"] - 6.3) < 1e-3
+    assert abs(kc["valu_instr_per_unit"]["peak:half2:hybrid"]["value"] - 6.4) < 1e-3
+    assert kc["valu_instr_per_unit"]["peak:half2:hybrid"]["source"] == "profiles/hyb_pmc.txt"
+    t = kc["traffic_bytes_per_char"]["peak|sw_scan_kernel<0, 43, 16, true,"]
+    assert t["chars_per_launch"] == chars and t["source"] == "profiles/res_pmc.txt" and t["nstripes"] == [8]   # the resident figure stays
+    assert abs(t["value"] - (2 * 7.4e6 + 16.8e6) * 1024 / chars) < 1e-3
+    # bench.py reads exactly these keys
+    b = load_bench()
+    monkeypatch.setattr(b, "load_counters", lambda: (kc, None))
+    ev = [fake_event(0, 43, 16, 8, 0.0, 250.0, chars, qlen=5478)]
+    roof, valu, _ = b.roofline_objects(b.parse_args(["--steps", "1"]), "peak", "half2", ev, {"resident": True, "cached_chars": chars, "chars": chars})
+    assert roof["traffic"] == int(t["value"] * chars) and valu["instr_per_cell_pair"] == kc["valu_instr_per_unit"]["peak:half2:resident"]["value"]
+    assert 0 < valu["frac"] <= 1
