@@ -167,6 +167,35 @@ def test_align_cli_tsv_and_plain(tmp_path):
     assert "Result 1. Score: %d. Length: 128. Header H. referenceId 1" % exp[19] in p.stdout
 
 
+def test_align_cli_hybrid_residency_and_pipelined_queries(monkeypatch):
+    """`align --maxGpuMem` below the DB size: the verbose output says how much of the shard stays cached in device memory
+    (the reference prints "N out of M DB batches will be cached in gpu memory", cudasw4.cuh:1044-1046), the results are
+    the golden ones — also with the next query submitted before the current one is collected (CUDASW4_AMD_PIPELINE=1),
+    whose output keeps the reference's order and format."""
+    from cudasw4_amd import driver
+    g = O.golden("ref_scores.json")
+    headers, seqs = O.read_fasta(FASTA)
+    outputs = []
+    for pipe in ("0", "1"):
+        monkeypatch.setenv("CUDASW4_AMD_PIPELINE", pipe)
+        p = subprocess.run([driver.ALIGN, "--query", FASTA, "--db", GOLDEN_DB, "--top", "2", "--verbose",
+                            "--maxGpuMem", "40683", "--maxBatchBytes", "3000"], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        m = [l for l in p.stdout.splitlines() if "chars cached in gpu memory" in l]
+        assert len(m) == 1, p.stdout[:2000]
+        cached, streamed = int(m[0].split(" chars cached")[0].split()[-1]), int(m[0].split(" streamed in ")[0].split()[-1])
+        assert 0 < cached < 41780 and cached + streamed == 41780
+        for qi in range(20):
+            es, ei = expected_top(g["allvsall"][qi], 2)
+            assert "Query %d, header%s, length %d, num overflows %d" % (
+                qi, headers[qi], len(seqs[qi]), sum(1 for x in g["allvsall"][qi] if x >= 2048)) in p.stdout
+            assert "Result 0. Score: %d. Length: %d. Header %s. referenceId %d" % (es[0], len(seqs[ei[0]]), headers[ei[0]], ei[0]) in p.stdout
+        order = [int(l.split()[2]) for l in p.stdout.splitlines() if l.startswith("Processing query ") and "file" not in l]
+        assert order == list(range(20))
+        outputs.append([l for l in p.stdout.splitlines() if l.startswith("Result ") or l.startswith("Query ")])
+    assert outputs[0] == outputs[1]
+
+
 def test_align_interactive_mode(tmp_path):
     """main.cu:336-424: 's <sequence>' (multi-line until an empty line), 'f <file>', 'exit'."""
     from cudasw4_amd import driver
