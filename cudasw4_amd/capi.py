@@ -64,6 +64,8 @@ def _load():
     L.sw_topk.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp, vp, sz, vp]
     L.sw_plan_query.argtypes = [ctypes.c_int, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.sw_check_letter_codes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    L.sw_plan_launch.argtypes = [vp, ctypes.c_int, ctypes.c_int, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                 ctypes.POINTER(i32), ctypes.POINTER(i32)]
     return L
 
 
@@ -139,6 +141,17 @@ class Context:
         check(lib.sw_rescore_overflow_stat(self.handle, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths,
                                            max_subject_len, gop, gex, scores, ids, id_offset, temp, temp_bytes,
                                            packed_limit, true_count, stream))
+
+    def plan_launch(self, kind, part_id, n, max_subject_len):
+        """-> (kind computed in, rows per lane, query stripes, lanes per group) of the launch sw_scan_partition
+        (part_id >= 0) or sw_rescore_overflow (part_id = -1) would make for the current query."""
+        k, r, s, l = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        check(lib.sw_plan_launch(self.handle, kind, part_id, n, max_subject_len, ctypes.byref(k), ctypes.byref(r),
+                                 ctypes.byref(s), ctypes.byref(l)))
+        return k.value, r.value, s.value, l.value
+
+    def check_letter_codes(self, chars, n, bad_flag, stream=0):
+        check(lib.sw_check_letter_codes(self.handle, chars, n, bad_flag, stream))
 
     def topk(self, scores, ids, n, k, out_scores, out_ids, temp, temp_bytes, stream=0):
         check(lib.sw_topk(self.handle, scores, ids, n, k, out_scores, out_ids, temp, temp_bytes, stream))

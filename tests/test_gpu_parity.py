@@ -587,3 +587,57 @@ def test_int32_kind_native_and_in_fp32_lanes(native, monkeypatch):
         got, res, _ = scan_all_scores(search, capi, db, qs[qi], kernel_types=kt)
         np.testing.assert_array_equal(got, expect, err_msg="native %s query %d" % (native, qi))
     assert expect.max() > 10000
+
+
+def test_letter_code_guard_and_launch_plan_introspection(monkeypatch):
+    """The two auxiliary entry points of the C ABI.  sw_check_letter_codes: flags a byte outside 0..20 wherever it sits
+    (aligned body, ragged head and tail, negative bytes), passes clean arrays of any size and alignment.
+    sw_plan_launch: names the instantiation the next scan would launch — stripes x rows x lanes cover the query, short
+    queries get 8-lane groups, the long partitions the wave-wide shape when they hold few subjects, and an int32 request
+    is served in fp32 lanes unless the score bound (or CUDASW4_AMD_I32_NATIVE) forbids it."""
+    torch, capi, search = gpu_modules()
+    ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    rng = np.random.default_rng(3)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for n in (1, 3, 15, 16, 17, 31, 64, 100, 4097, 1 << 20):
+        for shift in (0, 1, 5, 15):
+            host = rng.integers(0, 21, n + shift).astype(np.int8)
+            dev = torch.from_numpy(host).cuda()
+            flag.zero_()
+            ctx.check_letter_codes(dev.data_ptr() + shift, n, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert int(flag.item()) == 0, (n, shift)
+            for pos, bad in ((0, 21), (n - 1, 127), (n // 2, -1), (min(n - 1, 17), -128), (n - 1, 32)):
+                h2 = host.copy()
+                h2[shift + pos] = bad
+                d2 = torch.from_numpy(h2).cuda()
+                flag.zero_()
+                ctx.check_letter_codes(d2.data_ptr() + shift, n, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                assert int(flag.item()) == 1, (n, shift, pos, bad)
+    ctx.check_letter_codes(0, 0, flag.data_ptr())   # nothing to check
+
+    def plan(qlen, kind, part, n, maxlen):
+        ctx.set_query(rng.integers(0, 20, qlen).astype(np.int8), torch.cuda.current_stream().cuda_stream)
+        return ctx.plan_launch(kind, part, n, maxlen)
+
+    for qlen in (1, 48, 144, 256, 257, 375, 768, 769, 850, 5478, 20000):
+        for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
+            k, rows, ns, lanes = plan(qlen, kind, 20, 100000, 512)
+            assert rows * lanes * ns >= qlen and rows >= 1 and ns >= 1 and lanes in (8, 16)
+            assert k == (capi.KIND_F32 if kind == capi.KIND_I32 else kind)           # 512 x 11 + 2^22 < 2^24
+            packed = kind in (capi.KIND_F16X2, capi.KIND_I16X2)
+            assert lanes == (8 if qlen <= (256 if packed else 240) else 16), (qlen, kind, lanes)
+            assert (rows, ns) == capi.plan_query(k, qlen) or lanes == 8
+    assert plan(5478, capi.KIND_F32, 35, 19, 35213)[3] == 64          # a few giants: wave-wide groups
+    assert plan(5478, capi.KIND_F16X2, 34, 400, 8000)[3] == 64 and plan(5478, capi.KIND_F16X2, 34, 600, 8000)[3] == 16
+    assert plan(5478, capi.KIND_F32, -1, 1000, 700)[3] == 16 and plan(5478, capi.KIND_F32, -1, 1000, 1500)[3] == 64   # re-score
+    assert plan(20000, capi.KIND_I32, 35, 10, 2_000_000)[0] == capi.KIND_F32      # 20000 x 11 + 2^22 < 2^24: exact in fp32
+    assert plan(2_000_000, capi.KIND_I32, 35, 10, 2_000_000)[0] == capi.KIND_I32  # 2 * 10^6 x 11 is not: the int32 kernels
+    assert plan(1000, capi.KIND_I32, 35, 10, 2_000_000)[0] == capi.KIND_F32
+    ctx.close()
+    monkeypatch.setenv("CUDASW4_AMD_I32_NATIVE", "1")
+    ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    ctx.set_query(rng.integers(0, 20, 300).astype(np.int8), torch.cuda.current_stream().cuda_stream)
+    assert ctx.plan_launch(capi.KIND_I32, 20, 1000, 512)[0] == capi.KIND_I32
+    ctx.close()
