@@ -428,15 +428,17 @@ def measure(env, args, workload, want_cpu):
     info = drv.shard_info(0)
 
     merged = [None] * len(queries)
+    pipelined = os.environ["BENCH_PIPELINE"] == "1" if "BENCH_PIPELINE" in os.environ else world > 1
 
     def one_step():
         """20 scans through the C++ driver (each returns this rank's top-K on the host), then ONE exchange of the
         per-rank lists — K (score, id) pairs per query and rank — and the host-side merge on rank 0."""
         mine = np.full((len(queries), max(K, 1), 2), -1, dtype=np.int64)
-        # One query at a time, like the reference (main.cu:217-260).  BENCH_PIPELINE=1: the driver takes the next query
-        # while the current one's top-K is still on its way back (Driver.scan_many, SearchDriver::submit / collect) —
-        # measured: +0.4 % on a 125 000-subject shard, +-0.1 % on the 10^6 x 512 DB, -0.8 % on the Swiss-Prot-like DB
-        results = drv.scan_many(query_letters) if os.environ.get("BENCH_PIPELINE") == "1" else [drv.scan(q) for q in query_letters]
+        # One query at a time, like the reference (main.cu:217-260), on one GPU; with several ranks — small shards, where
+        # the fixed work per query weighs more — the driver takes the next query while the current one's top-K is still
+        # on its way back (Driver.scan_many, SearchDriver::submit / collect).  Measured on one GPU: +0.45 % on a
+        # 125 000-subject shard, +-0.1 % on the 10^6 x 512 DB, -0.1 ... -0.6 % on the Swiss-Prot-like DB.  BENCH_PIPELINE=0|1 forces it.
+        results = drv.scan_many(query_letters) if pipelined else [drv.scan(q) for q in query_letters]
         for qi, r in enumerate(results):
             n = len(r["scores"])
             mine[qi, :n, 0] = r["scores"]
@@ -553,6 +555,7 @@ def measure(env, args, workload, want_cpu):
                                    "gop -11 gex -1, top %d, C++ host driver" % (args.workload, sum_q, what, kernel_name, K),
                        "db_subjects": total_subjects, "db_residues": int(total_residues), "queries": len(queries),
                        "kernel": kernel_name, "host": "libcudasw4_host.so (SearchDriver)",
+                       "queries_in_flight": 2 if pipelined else 1,
                        "resident": info["resident"], "residency": residency_of(info),
                        "cached_chars": info.get("cached_chars"), "shard_chars": info["chars"],
                        "parallelism": "db-shard x%d (%s), one top-K gather per step + host merge" % (world, "one DB sharded" if strong else "one DB per rank")},
