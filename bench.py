@@ -73,6 +73,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="peak workload: skip the Swiss-Prot-like secondary measurement")
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="peak workload on one GPU: skip the peak-benchmark sweep (runpeakbenchmark.sh: 6 lengths x 4 kernel types)")
+    ap.add_argument("--sweep-steps", type=int, default=2, help="timed passes per cell of the peak sweep (after one verified warm-up pass)")
+    ap.add_argument("--no-families", action="store_true",
+                    help="sprot-like workload: independent random residues only (the round-1..3 stand-in) instead of the DB with "
+                         "seeded protein families of the queries")
     ap.add_argument("--cpu-sample-subjects", type=int, default=None)
     ap.add_argument("--db-prefix", default=os.environ.get("CUDASW4_SPROT_PREFIX"),
                     help="sprot-like workload (and the default run's secondary leg): a real DB made by `makedb` (e.g. "
@@ -141,6 +147,9 @@ def kinds_for(args):
 
 
 # ------------------------------------------------------------------------------------------------- CPU baseline
+_CPU_THREADS = {}  # calibrated once per process: every CPU leg of a line uses the same team size
+
+
 def cpu_baseline(queries, chars, offsets, lengths, what):
     """Oracle's SIMD scans (kind 'port') on the host cores over a bounded sample of the same workload: all 20 queries
     x the sample DB.  The thread count is picked by a short calibration (containers often cap CPU time below the
@@ -150,8 +159,8 @@ def cpu_baseline(queries, chars, offsets, lengths, what):
     m = O.blosum21(62)
     ncal = min(len(lengths), 6000)
     cal = (chars[:int(offsets[ncal])], offsets[:ncal + 1], lengths[:ncal])
-    best_nt, best_rate = 1, 0.0
-    nt = O.max_threads()
+    best_nt, best_rate = _CPU_THREADS.get("n", 1), 0.0
+    nt = 0 if "n" in _CPU_THREADS else O.max_threads()
     while nt >= 1:
         O.scan(queries[9], *cal, m21=m, simd=True, nthreads=nt)  # warm-up of this team size
         t0 = time.perf_counter()
@@ -160,6 +169,7 @@ def cpu_baseline(queries, chars, offsets, lengths, what):
         if rate > best_rate:
             best_nt, best_rate = nt, rate
         nt //= 2
+    _CPU_THREADS["n"] = best_nt
     cells = float(sum(len(q) for q in queries)) * float(lengths.astype(np.int64).sum())
     rates, scores = {}, None
     for name, kw in (("striped", dict(striped=True)), ("interseq", dict(simd=True))):
@@ -185,7 +195,8 @@ def cpu_baseline(queries, chars, offsets, lengths, what):
            "striped_gcups": round(rates["striped"][0], 3), "interseq_gcups": round(rates["interseq"][0], 3),
            "scalar_1core_gcups": round(scalar_rate, 4), "cpu_model": model,
            "sample": "20 queries x %s; oracle ports with int16 lanes (gcc, AVX-512 or AVX2 build picked by cpuid): Farrar "
-                     "striped SW %.1f s, inter-sequence SIMD %.1f s; %d of %d hardware threads (best of a calibration sweep)"
+                     "striped SW %.1f s, inter-sequence SIMD %.1f s; %d of %d hardware threads (best of ONE calibration sweep per "
+                     "line: every CPU leg of this line uses the same team size)"
                      % (what, rates["striped"][1], rates["interseq"][1], best_nt, O.max_threads())}
     return obj, scores
 
@@ -234,6 +245,8 @@ def roofline_objects(args, workload, kernel_name, events, info):
     * the DP kernels' own rate (`kernel_gcups`) = cells / the measure of the UNION of all launch intervals: launches
       overlap (long subjects on the auxiliary streams, consecutive batches on two work streams), a sequence of batches
       does not — neither the sum nor the longest launch of a scan is the time the kernels took."""
+    all_events = events
+    events = [e for e in all_events if not e.get("rescore")]  # the re-score launches count as busy time, not as cells
     if not events:
         return None, None, []
     groups = {}
@@ -264,7 +277,7 @@ def roofline_objects(args, workload, kernel_name, events, info):
                 t["value"], t["source"], int(avg_chars))
         else:
             tnote = "no PMC traffic figure for %s *> with these stripes" % key
-    busy_ms = union_ms([(e["t0_ms"], e["t1_ms"]) for e in events])
+    busy_ms = union_ms([(e["t0_ms"], e["t1_ms"]) for e in all_events])
     roof = {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": 8000.0, "unit": "GB/s",
             "frac": round(hbm_gbs / 8000.0, 6), "traffic": traffic, "kernel": kname,
             "avg_launch_ms": round(avg_ms, 4), "launches": len(ev), "algorithmic_bytes_per_launch": int(bytes_per_launch),
@@ -355,7 +368,11 @@ def run_rank(args):
         sec = measure(env, a2, "sprot-like", want_cpu=not args.no_cpu_baseline and world == 1)
         if rank == 0:
             out["sprot_like"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "data", "verified", "verified_how",
-                                                      "config", "roofline", "valu_roofline", "cpu_baseline") if k in sec}
+                                                      "config", "roofline", "valu_roofline", "overflow_load", "cpu_baseline") if k in sec}
+    if args.workload == "peak" and world == 1 and not args.no_sweep and not args.no_secondary:
+        sweep = peak_sweep(env, args)
+        if rank == 0:
+            out["peak_sweep"] = sweep
     if distributed and world > 1 and args.scaling == "strong" and args.workload == "peak" and not args.no_secondary:
         # next to the strong-scaling headline (ONE DB sharded over the ranks): the same benchmark with one full DB per
         # rank, so that a multi-GPU run shows both what sharding a 532 MB DB eight ways costs and what the GPUs do when
@@ -371,6 +388,58 @@ def run_rank(args):
         sys.stdout.flush()
     if distributed:
         dist.destroy_process_group()
+
+
+def peak_sweep(env, args):
+    """The reference's peak protocol (runpeakbenchmark.sh:26-83) under the same clock as the headline: allqueries.fasta
+    against `--pseudodb 1000000 L` for L in {128, 256, 512, 768, 1024, 2048} x {half2, dpxs16} and L <= 1024 x {dpxs32,
+    float}, resident, through the C++ driver.  Per cell: ONE warm-up pass in which every score of every query is checked
+    against the reference's golden score (tests/golden/ref_scores.json), then --sweep-steps timed passes bracketed by
+    device synchronisation (top-K inside, like the headline).  The headline's own cell (half2, 512) is measured again
+    here with the sweep's few steps."""
+    torch = env.torch
+    from cudasw4_amd import driver
+    _, query_letters = driver.read_sequences(os.path.join(ROOT, "tests", "golden", "allqueries.fasta"))
+    sum_q = sum(len(q) for q in query_letters)
+    golden_all = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_scores.json")))["pseudo"]
+    num = args.db_size or 1_000_000
+    K = max(args.top, 0)
+    table, ok_all, t_begin = {}, True, time.perf_counter()
+    import copy
+    for kname, lengths in (("half2", (128, 256, 512, 768, 1024, 2048)), ("dpxs16", (128, 256, 512, 768, 1024, 2048)),
+                           ("dpxs32", (128, 256, 512, 768, 1024)), ("float", (128, 256, 512, 768, 1024))):
+        a = copy.copy(args)
+        a.kernel, a.workload = kname, "peak"
+        _, kinds = kinds_for(a)
+        row = {}
+        for L in lengths:
+            golden = golden_all.get(str(L))
+            drv = driver.Driver(devices=[env.local_rank], num_top=K, matrix=62, kinds=kinds)
+            drv.pseudo_db(num, L)
+            drv.upload()
+            ok = golden is not None
+            for qi, q in enumerate(query_letters):  # warm-up pass == verification pass
+                drv.scan(q)
+                sc, _ids = drv.last_scores(0)
+                ok = ok and len(sc) == num and int(sc.min()) == int(sc.max()) == int(golden[qi])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(args.sweep_steps, 1)):
+                for q in query_letters:
+                    drv.scan(q)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            drv.close()
+            row[str(L)] = round(float(sum_q) * num * L * max(args.sweep_steps, 1) / 1e9 / dt, 1)
+            ok_all = ok_all and bool(ok)
+        table[kname] = row
+    return {"unit": "GCUPS", "protocol": "runpeakbenchmark.sh:26-83: allqueries.fasta x pseudo DB %d x L, resident, blosum62, gop -11 gex -1, "
+                                        "top %d, C++ host driver; per cell 1 verified warm-up pass + %d timed passes" % (num, K, max(args.sweep_steps, 1)),
+            "gcups": table, "verified": ok_all,
+            "verified_how": "in every cell all %d scores of each of the 20 queries equal the reference's golden score" % num,
+            "dpxs32_note": "int32 results computed in fp32 lanes (exact below 2^24, bound checked per launch)"
+                           if os.environ.get("CUDASW4_AMD_I32_NATIVE") != "1" else "native int32 kernels",
+            "seconds": round(time.perf_counter() - t_begin, 1)}
 
 
 def measure(env, args, workload, want_cpu):
@@ -415,10 +484,11 @@ def measure(env, args, workload, want_cpu):
             label = "DB %s" % args.db_prefix
         else:
             num = args.db_size or synthdb.SPROT_SEQUENCES
-            host_db = synthdb.sprot_like(num)
+            host_db = synthdb.sprot_like(num, families=not args.no_families)
             drv.set_shard(rank, world, 0) if strong else drv.set_shard(0, 1, rank * num)
             drv.db_from_arrays(*host_db)
-            label = "Swiss-Prot-like synthetic DB"
+            label = "Swiss-Prot-like synthetic DB (Swiss-Prot composition%s)" % (
+                "" if args.no_families else ", seeded families of the 20 queries: mutated copies, fragments, domains in foreign flanks")
         total_residues = float(host_db[2].astype(np.int64).sum()) * (1 if strong else world)
         total_subjects = num * (1 if strong else world)
         what = "%s (%d sequences, %d residues, %s, max %d)%s" % (
@@ -428,6 +498,7 @@ def measure(env, args, workload, want_cpu):
     info = drv.shard_info(0)
 
     merged = [None] * len(queries)
+    load = {"num_overflows": 0, "num_rescored": 0}  # of the last step: summed over its 20 queries (this rank's shard)
     pipelined = os.environ["BENCH_PIPELINE"] == "1" if "BENCH_PIPELINE" in os.environ else world > 1
 
     def one_step():
@@ -439,6 +510,8 @@ def measure(env, args, workload, want_cpu):
         # on its way back (Driver.scan_many, SearchDriver::submit / collect).  Measured on one GPU: +0.45 % on a
         # 125 000-subject shard, +-0.1 % on the 10^6 x 512 DB, -0.1 ... -0.6 % on the Swiss-Prot-like DB.  BENCH_PIPELINE=0|1 forces it.
         results = drv.scan_many(query_letters) if pipelined else [drv.scan(q) for q in query_letters]
+        load["num_overflows"] = sum(r["num_overflows"] for r in results)
+        load["num_rescored"] = sum(r["num_rescored"] for r in results)
         for qi, r in enumerate(results):
             n = len(r["scores"])
             mine[qi, :n, 0] = r["scores"]
@@ -547,7 +620,7 @@ def measure(env, args, workload, want_cpu):
         out = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong" if (strong and distributed) else "weak", "vs_baseline": None,
+            "scaling": "single" if world == 1 else ("strong" if strong else "weak"), "vs_baseline": None,
             "dtype": DTYPE_BY_KIND[kinds[0]] + (" (int32 results computed in fp32 lanes: exact below 2^24, bound checked per launch)"
                                                 if kinds[0] == 2 and os.environ.get("CUDASW4_AMD_I32_NATIVE") != "1" else ""),
             "data": data, "verified": verified, "verified_how": verify_note,
@@ -560,6 +633,13 @@ def measure(env, args, workload, want_cpu):
                        "cached_chars": info.get("cached_chars"), "shard_chars": info["chars"],
                        "parallelism": "db-shard x%d (%s), one top-K gather per step + host merge" % (world, "one DB sharded" if strong else "one DB per rank")},
             "roofline": roof, "valu_roofline": valu,
+            # what real data loads a scan with (half2_kernels.cuh:1087-1109, cudasw4.cuh:2134-2172), per step = one pass of
+            # the 20 queries over rank 0's shard: subjects whose exact score reached the packed kind's limit (the
+            # reference's "num overflows"), subjects the packed kernels flagged and a 32-bit kind re-scored (a few more:
+            # the column-offset frame flags early), and the time of the re-score launches (HIP events, inside the timed region)
+            "overflow_load": {"num_overflows": load["num_overflows"], "num_rescored": load["num_rescored"],
+                              "rescore_launches_per_step": sum(1 for e in events if e.get("rescore")) // max(args.steps, 1),
+                              "rescore_ms_per_step": round(sum(e["ms"] for e in events if e.get("rescore")) / max(args.steps, 1), 3)},
         }
         if args.kernel_table:
             out["kernels"] = ktable

@@ -183,10 +183,10 @@ int swdrv_take_kernel_events(swdrv* d, double* out, int cap) {
         const auto ev = d->driver->takeKernelEvents();
         n = int(ev.size());
         for (int i = 0; i < n && i < cap; i++) {
-            double* o = out + size_t(i) * 14;
+            double* o = out + size_t(i) * 15;
             const KernelEvent& e = ev[size_t(i)];
             o[0] = e.gpu; o[1] = e.kind; o[2] = e.part_id; o[3] = e.qlen; o[4] = double(e.subjects); o[5] = e.cells; o[6] = e.chars; o[7] = e.ms;
-            o[8] = e.t0_ms; o[9] = e.t1_ms; o[10] = e.eff_kind; o[11] = e.rows; o[12] = e.nstripes; o[13] = e.lanes;
+            o[8] = e.t0_ms; o[9] = e.t1_ms; o[10] = e.eff_kind; o[11] = e.rows; o[12] = e.nstripes; o[13] = e.lanes; o[14] = e.rescore;
         }
     });
     return rc == 0 ? n : -1;
@@ -273,7 +273,7 @@ int swdrv_shard_ranges(const int32_t* sorted_lengths, const uint64_t* offsets, s
 
 int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_len, size_t max_gpu_mem, size_t max_batch_bytes,
                          size_t max_batch_sequences, size_t max_temp_bytes, size_t free_mem, int allow_cache, int64_t* cache_begin,
-                         int64_t* cache_bytes, int64_t* batch_bytes, int64_t* batches, int cap) {
+                         int64_t* cache_bytes, int64_t* batch_bytes, int64_t* batches, int cap, int64_t* temp_per_stream) {
     int nb = -1;
     const int rc = guarded([&] {
         if (!local_offsets) throw std::runtime_error("null offsets");
@@ -287,6 +287,7 @@ int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_le
         if (cache_begin) *cache_begin = int64_t(rp.cacheBegin);
         if (cache_bytes) *cache_bytes = int64_t(rp.cacheBytes);
         if (batch_bytes) *batch_bytes = int64_t(rp.batchBytes);
+        if (temp_per_stream) *temp_per_stream = int64_t(std::min<size_t>(rp.tempPerStream, size_t(INT64_MAX)));
         nb = int(rp.batches.size());
         for (int i = 0; i < nb && i < cap; i++) { batches[2 * i] = int64_t(rp.batches[size_t(i)].first); batches[2 * i + 1] = int64_t(rp.batches[size_t(i)].second); }
     });

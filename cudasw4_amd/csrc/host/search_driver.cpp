@@ -84,6 +84,7 @@ struct TimedLaunch {
     int32_t eff_kind = 0, rows = 0, nstripes = 0, lanes = 0;
     int32_t qlen = 0;
     size_t lbegin = 0, lend = 0;
+    bool rescore = false;
 };
 
 struct SearchDriver::Gpu {
@@ -159,6 +160,8 @@ struct SearchDriver::Gpu {
     bool twoWorkStreams = true;   // CUDASW4_AMD_ONE_WORK_STREAM=1: every batch of a streamed scan on the work stream (A/B measurements)
     void* d_temp[kAux + 2] = {nullptr, nullptr, nullptr, nullptr};  // work stream, auxiliary streams, stream2
     size_t tempBytes[kAux + 2] = {0, 0, 0, 0};
+    size_t tempCap = SIZE_MAX;  // plan_residency: what each of them may grow to inside the memory limit
+    static_assert(kAux + 2 == kTempStreams, "plan_residency budgets the scratch of this many streams");
     void* d_topkTemp = nullptr;
     size_t topkTempBytes = 0;
     float* d_topS = nullptr;
@@ -250,6 +253,13 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
     std::string why;
     if (!kernels_.valid(&why)) throw std::runtime_error("Invalid kernel type configuration: " + why);
     if (deviceIds.empty()) throw std::runtime_error("No GPU found");
+    std::string order = "WCAB";  // creation order of the streams of a GPU (below)
+    if (const char* e = std::getenv("CUDASW4_AMD_STREAM_ORDER")) {
+        std::string sorted = e;
+        std::sort(sorted.begin(), sorted.end());
+        if (sorted != "ABCW") throw std::runtime_error("CUDASW4_AMD_STREAM_ORDER must be a permutation of WCAB");
+        order = e;
+    }
     for (int dev : deviceIds) {
         auto g = std::make_unique<Gpu>();
         g->index = int(gpus_.size());
@@ -257,8 +267,22 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         g->use();
         SWCHECK(sw_ctx_create(dev, &g->ctx));
         SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), matrix_.dim));
-        HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-        HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
+        // The auxiliary streams carry the few long subjects that must overlap the bulk launch.  The runtime multiplexes
+        // streams of one priority onto GPU_MAX_HW_QUEUES (4) hardware queues, and two streams that share a queue
+        // serialise (measured: the giant-subject launch in front of the bulk launch, 167 instead of 106 ms for a
+        // 5478-residue query on the Swiss-Prot-like DB).  High-priority streams come from a queue pool of their own, so
+        // they never share a hardware queue with the work stream — and the giants get their workgroups first.
+        // Since round 4 a resident scan needs ONE of them (the giants; partition 34 runs inside the bulk grid,
+        // plan_launch_runs), so the two auxiliary streams can no longer end up serialised behind each other either.
+        // CUDASW4_AMD_STREAM_ORDER permutes the creation order (letters W work, C copy, A / B auxiliary) for the test
+        // that shows the scan rate no longer depends on it.
+        int prioLow = 0, prioHigh = 0;
+        HIPCHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
+        for (char c : order) {
+            if (c == 'W') HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+            else if (c == 'C') HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
+            else HIPCHECK(hipStreamCreateWithPriority(&g->aux[c - 'A'], hipStreamNonBlocking, prioHigh));
+        }
         HIPCHECK(hipHostMalloc(&g->h_pad, 64));
         std::memset(g->h_pad, kOtherCode, 64);
         for (auto& e : g->forkEvent) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -266,17 +290,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         HIPCHECK(hipEventCreate(&g->scanStartEv));
         HIPCHECK(hipEventCreate(&g->recordRefEv));
         for (auto& r : g->res) HIPCHECK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
-        // The auxiliary streams carry the few long subjects that must overlap the bulk launch.  The runtime multiplexes
-        // streams of one priority onto GPU_MAX_HW_QUEUES (4) hardware queues, and two streams that share a queue
-        // serialise (measured: the giant-subject launch in front of the bulk launch, 167 instead of 106 ms for a
-        // 5478-residue query on the Swiss-Prot-like DB).  High-priority streams come from a queue pool of their own, so
-        // they never share a hardware queue with the work stream — and the giants get their workgroups first.
-        int prioLow = 0, prioHigh = 0;
-        HIPCHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-        for (int i = 0; i < Gpu::kAux; i++) {
-            HIPCHECK(hipStreamCreateWithPriority(&g->aux[i], hipStreamNonBlocking, prioHigh));
-            HIPCHECK(hipEventCreateWithFlags(&g->joinEvent[i], hipEventDisableTiming));
-        }
+        for (int i = 0; i < Gpu::kAux; i++) HIPCHECK(hipEventCreateWithFlags(&g->joinEvent[i], hipEventDisableTiming));
         for (int i = 0; i < Gpu::kSlots; i++) {
             HIPCHECK(hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&g->scanned[i], hipEventDisableTiming));
@@ -454,6 +468,7 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
         const ResidencyPlan rp = plan_residency(g.localOffsets, g.maxLen, memory_, freeMem, Gpu::kSlots, !(noHybrid && noHybrid[0] == '1'));
         g.cacheBegin = rp.cacheBegin;
         g.cacheBytes = rp.cacheBytes;
+        g.tempCap = rp.tempPerStream;
         g.batches.clear();
         for (const auto& be : rp.batches) {
             Batch bt;
@@ -512,6 +527,27 @@ void SearchDriver::registerStreamedRanges() {
             }
             registered_.push_back(r);
         }
+        // HIP rejects a copy whose source starts inside a registered object and runs past its end: every piece the scans
+        // will copy (streamed batches, and the cached part's one-time upload) must lie wholly inside ONE registration or
+        // wholly outside all of them.  Holds by construction today (batches are cut from the streamed prefix, the merge
+        // only closes gaps); checked so that a change to the piece or merge boundaries falls back to pinned staging
+        // instead of failing uploads with hipErrorInvalidValue.
+        auto consistent = [&](const int8_t* src, uint64_t bytes, bool mustBeInside) {
+            bool inside = false;
+            for (const auto& r : registered_) {
+                const int8_t* rb = r.first;
+                const int8_t* re = r.first + r.second;
+                if (src >= rb && src + bytes <= re) { inside = true; continue; }
+                if (src < re && src + bytes > rb) return false;  // straddles the edge of a registration
+            }
+            return inside || !mustBeInside;
+        };
+        for (auto& gp : gpus_) {
+            if (!ok) break;
+            for (const Batch& b : gp->batches)
+                for_each_piece(*gp, *db_, b.lbegin, b.lend, [&](const int8_t* src, uint64_t bytes, uint64_t) { ok = ok && (!bytes || consistent(src, bytes, true)); });
+            for_each_piece(*gp, *db_, gp->cacheBegin, gp->numLocal, [&](const int8_t* src, uint64_t bytes, uint64_t) { ok = ok && (!bytes || consistent(src, bytes, false)); });
+        }
         if (!ok) unregisterRanges();
         dbRegistered_ = ok;
     }
@@ -537,11 +573,26 @@ ResidencyPlan plan_residency(const std::vector<uint64_t>& localOffsets, int32_t 
     size_t limit = std::min(memory.maxGpuMem > meta ? memory.maxGpuMem - meta : 0, freeMem);
     const size_t safety = size_t(256) << 20;
     if (limit > safety) limit -= safety;  // cudasw4.cuh:1020-1026: a limit below the margin is taken as it is
-    const size_t fixed = std::min({memory.maxTempBytes, size_t(1) << 30, limit / 4});  // scratch of multi-stripe queries
+    // scratch of multi-stripe queries: ONE budget for all streams that can hold a scratch buffer at the same time (work
+    // stream, second work stream, auxiliary streams).  A resident shard with memory to spare keeps --maxTempBytes per
+    // buffer; a shard under a binding limit splits the budget (a quarter of the limit, at most 1 GiB) evenly, so that
+    // cached chars + staging + every scratch buffer stay inside the limit (a smaller scratch only lowers the number of
+    // workgroups a multi-stripe launch keeps in flight, sw_api.hip: scan_common).
+    const size_t allTemp = memory.maxTempBytes > SIZE_MAX / size_t(kTempStreams) ? SIZE_MAX : memory.maxTempBytes * size_t(kTempStreams);
+    const size_t fixed = std::min({allTemp, size_t(1) << 30, limit / 4});
     const size_t avail = limit - fixed;
     rp.cacheBegin = 0;
     rp.cacheBytes = localChars;
-    if (!numLocal || localChars + 64 <= avail) return rp;
+    rp.tempPerStream = memory.maxTempBytes;
+    if (!numLocal || localChars + 64 <= avail) {
+        // resident: the buffers may grow to --maxTempBytes each only while that still fits next to the chars
+        const size_t spare = avail - size_t(localChars ? localChars + 64 : 0) + fixed;
+        rp.tempPerStream = std::min(memory.maxTempBytes, std::max(spare / size_t(kTempStreams), std::min(memory.maxTempBytes, size_t(256) << 20)));
+        return rp;
+    }
+    // never below 256 MiB (or --maxTempBytes): limits under 4.3 GiB may be exceeded by the difference, like the reference
+    // takes a limit below its safety margin as it is (cudasw4.cuh:1020-1026)
+    rp.tempPerStream = std::max(fixed / size_t(kTempStreams), std::min(memory.maxTempBytes, size_t(256) << 20));
     // staging takes at most half of what is there, a batch is never smaller than the longest subject
     const uint64_t minBatch = std::max<uint64_t>(uint64_t(maxLen) + 4, std::min<uint64_t>(memory.maxBatchBytes, uint64_t(1) << 20));
     const uint64_t batchBytes = std::max<uint64_t>(std::min<uint64_t>(memory.maxBatchBytes, avail / (2 * uint64_t(stagingSlots))), minBatch);
@@ -654,13 +705,13 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         const LaunchRun& r = runs[ri];
         const int32_t n = int32_t(r.end - r.begin);
         const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, r.maxlen);
-        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, mem.maxTempBytes);
+        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
         TimedLaunch t;
         const bool record = recordMode == 1 || (recordMode == 2 && tslot == workTemp);
         if (record) {
             if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
             else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
-            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end;
+            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = false;
             SWCHECK(sw_plan_launch(g.ctx, int(r.kind), r.part_id, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
             HIPCHECK(hipEventRecord(t.ev0, stream));
         }
@@ -679,12 +730,25 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         const LaunchRun& r = runs[ri];
         const int32_t n = int32_t(r.end - r.begin);
         const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, n, r.maxlen);
-        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, mem.maxTempBytes);
+        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
+        TimedLaunch t;
+        const bool record = recordMode == 1 || (recordMode == 2 && tslot == workTemp);
+        if (record) {
+            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
+            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
+            t.kind = int(kt.overflowType); t.part_id = -1; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = true;
+            SWCHECK(sw_plan_launch(g.ctx, int(kt.overflowType), -1, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
+            HIPCHECK(hipEventRecord(t.ev0, stream));
+        }
         SWCHECK(sw_rescore_overflow_stat(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[ri], n,
                                          chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
                                          int64_t(lbegin), temp, g.tempBytes[tslot],
                                          r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16,
                                          g.d_ovfCount, stream));
+        if (record) {
+            HIPCHECK(hipEventRecord(t.ev1, stream));
+            g.timed.push_back(t);
+        }
     };
     int auxNext = 0;
     bool auxBusy[GpuT::kAux] = {};
@@ -944,6 +1008,8 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
         for (bool& u : g.slotUsed) u = false;
         g.firstBatchStaged = false;
         g.slotBase = 0;
+        // the letter-code checks this scan enqueued never reported back: check those batches again
+        g.batchChecked.assign(g.batchChecked.size(), false);
         rs.used = false;
         throw;
     }
@@ -961,7 +1027,10 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot) {
     g.use();
     HIPCHECK(hipEventSynchronize(rs.done));
     rs.used = false;
-    if (rs.h_ovf[rs.ncounters]) {
+    // A streamed batch is checked by the FIRST scan that uses it; with two queries in flight the second one was enqueued
+    // before the first one's flag came back and carries no check of its own: a flag raised by any earlier query
+    // (g.badCodes) condemns its scores as well.
+    if (rs.h_ovf[rs.ncounters] || g.badCodes) {
         g.badCodes = true;
         throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
     }
@@ -1084,8 +1153,9 @@ std::vector<KernelEvent> SearchDriver::takeKernelEvents() {
             e.gpu = g.index; e.kind = t.kind; e.part_id = t.part_id; e.qlen = t.qlen;
             e.eff_kind = t.eff_kind; e.rows = t.rows; e.nstripes = t.nstripes; e.lanes = t.lanes;
             e.subjects = int64_t(t.lend - t.lbegin);
-            e.cells = double(t.qlen) * double(g.resPrefix[t.lend] - g.resPrefix[t.lbegin]);
-            e.chars = double(g.localOffsets[t.lend] - g.localOffsets[t.lbegin]);
+            e.rescore = t.rescore ? 1 : 0;
+            e.cells = t.rescore ? 0.0 : double(t.qlen) * double(g.resPrefix[t.lend] - g.resPrefix[t.lbegin]);
+            e.chars = t.rescore ? 0.0 : double(g.localOffsets[t.lend] - g.localOffsets[t.lbegin]);
             HIPCHECK(hipEventElapsedTime(&e.ms, t.ev0, t.ev1));
             e.t0_ms = e.t1_ms = 0.f;
             if (g.recordRefValid) {

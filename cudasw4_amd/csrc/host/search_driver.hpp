@@ -67,26 +67,45 @@ struct LaunchRun {
     int32_t maxlen;
 };
 
+// Partition 34 (1281..8000 residues) joins the bulk launch when it alone could not run on wave-wide groups anyway: from
+// this many subjects up the library gives it the 16-lane shape (sw_api.hip: lanes_for_partition), i.e. the very kernel
+// the partitions below it run on.
+constexpr size_t kLongPartitionMergeMin = 512;
+
 // Partition walk of runAlignmentKernels (cudasw4.cuh:1742-2103) over the positions [begin, end) of a subject list
 // whose partition p occupies [partBegin[p], partBegin[p+1]): largest partition first, adjacent partitions of equal
-// kind merged into one launch (the kernels take any subject length; partitions 34/35 keep launches of their own
-// because they may use the wave-wide group shape).  maxLenOf(pos) = true length of the subject at pos.
+// kind merged into one launch (the kernels take any subject length).  Partition 35 (> 8000) always keeps a launch of
+// its own (few giant subjects: wave-wide groups, a side stream); partition 34 keeps one while it holds fewer than
+// kLongPartitionMergeMin subjects of the range (wave-wide groups) and otherwise MERGES with the partitions below it when
+// the kinds agree: one grid takes the long subjects first instead of two grids sharing the CUs, and one side stream
+// less has to find a hardware queue of its own (round 3: which streams shared a queue depended on the order they were
+// created in, 10.0 ... 11.15 TCUPS on the Swiss-Prot-like DB).  A merged run reports part_id 33.
+// maxLenOf(pos) = true length of the subject at pos.
 // The ONE planner: the Python mirror (cudasw4_amd/search.py) calls it through swdrv_plan_runs.
 template <class MaxLenOf>
 std::vector<LaunchRun> plan_launch_runs(const KernelTypeConfig& kt, const size_t* partBegin, size_t begin, size_t end,
                                         MaxLenOf&& maxLenOf) {
     std::vector<LaunchRun> runs;
+    constexpr int kSmallLong = kNumLengthPartitions - 2, kLargeLong = kNumLengthPartitions - 1;
+    auto shape_of = [&](int p, size_t count) {  // 2: giants, 1: few long subjects, 0: bulk
+        if (p == kLargeLong) return 2;
+        if (p == kSmallLong && count < kLongPartitionMergeMin) return 1;
+        return 0;
+    };
+    int lastShape = -1;
     for (int p = kNumLengthPartitions - 1; p >= 0; p--) {
         const size_t b = begin > partBegin[p] ? begin : partBegin[p];
         const size_t e = end < partBegin[p + 1] ? end : partBegin[p + 1];
         if (e <= b) continue;
         const KernelType kind = kt.for_partition(p);
-        const bool sameShape = !runs.empty() && (runs.back().part_id >= kNumLengthPartitions - 2) == (p >= kNumLengthPartitions - 2);
-        if (!runs.empty() && runs.back().kind == kind && runs.back().begin == e && sameShape) {
+        const int shape = shape_of(p, e - b);
+        if (!runs.empty() && runs.back().kind == kind && runs.back().begin == e && shape == 0 && lastShape == 0) {
             runs.back().begin = b;
         } else {
-            runs.push_back(LaunchRun{kind, p, b, e, maxLenOf(e - 1)});
+            const int pid = (p == kSmallLong && shape == 0) ? kSmallLong - 1 : p;
+            runs.push_back(LaunchRun{kind, pid, b, e, maxLenOf(e - 1)});
         }
+        lastShape = shape;
     }
     return runs;
 }
@@ -94,9 +113,11 @@ std::vector<LaunchRun> plan_launch_runs(const KernelTypeConfig& kt, const size_t
 // Residency of one GPU's shard (GpuWorkingSet + assignBatchesToGpuMem + computeDbCopyPlan, cudasw4.cuh:317-392,1087-1144,
 // 1177-1277): what stays in device memory and how the rest is cut into streamed batches.  Pure host logic (no GPU call);
 // the driver calls it in setDatabase, the CPU tests through swdrv_plan_residency.
+constexpr int kTempStreams = 4;  // streams of a GPU that can hold a stripe-border scratch at a time: work, second work, 2 auxiliary
 struct ResidencyPlan {
     size_t cacheBegin = 0;      // shard-local subjects [cacheBegin, n) keep their chars in device memory (0: resident)
     uint64_t cacheBytes = 0;
+    size_t tempPerStream = 0;   // cap of each stream's scratch buffer (<= --maxTempBytes; kTempStreams of them fit the limit)
     uint64_t batchBytes = 0;    // size limit of a streamed batch (0 when nothing is streamed)
     std::vector<std::pair<size_t, size_t>> batches;  // [begin, end) of every streamed batch, ascending
 };
@@ -120,6 +141,10 @@ struct KernelEvent {
     // the kernel instantiation the library chose (sw_plan_launch): arithmetic kind actually computed in, rows per lane,
     // query stripes, lanes per alignment group
     int eff_kind, rows, nstripes, lanes;
+    // 1: an overflow re-score launch (cudasw4.cuh:2134-2172) over the list of the run [subjects: the run's, an upper
+    // bound of the list; cells / chars: 0 — the list's length is only known on the device; the query's totals are in
+    // ScanResult::stats.numRescored]
+    int rescore;
 };
 
 class SearchDriver {

@@ -96,8 +96,9 @@ struct Profile {
 constexpr uint32_t kWorkSlots = 4096;
 // Longest query that runs on 8-lane groups.  Tuned on RAGGED subjects (tools/ragged_query_sweep.py, Swiss-Prot-like DB
 // through the C++ driver): the packed kinds gain 2.4 ... 7.3 % up to 256 residues (R = 32: still three waves per SIMD)
-// and nothing consistent above (272: -1 %, 288: +1.5 %, 304: -3 %); the 32-bit kinds gain 4 ... 14 % up to 256 and lose
-// from 272 on.  (Round 2 tuned on the peak DB, whose identical subjects hid the LDS bank conflicts of the second group
+// and nothing consistent above (272: -1 %, 288: +1.5 %, 304: -3 %); the 32-bit kinds gain 4 ... 14 % up to 256 (R = 32:
+// the last height at which their single-stripe kernels keep three waves per SIMD without spills) and lose from 272 on,
+// so both limits are 256 (the 32-bit limit stood at 240 until round 4, below what the sweep supports).  (Round 2 tuned on the peak DB, whose identical subjects hid the LDS bank conflicts of the second group
 // of a DPP row — fixed since, Geometry / dp_step: laneStep — and chose 288 / 240: +14 % at 144 residues there.)
 #ifndef SW_LANES8_MAX_QUERY_PACKED
 #define SW_LANES8_MAX_QUERY_PACKED 256
@@ -106,7 +107,7 @@ constexpr uint32_t kWorkSlots = 4096;
 #define SW_LANES8_MAX_SUBJECT 192
 #endif
 #ifndef SW_LANES8_MAX_QUERY_SCALAR
-#define SW_LANES8_MAX_QUERY_SCALAR 240
+#define SW_LANES8_MAX_QUERY_SCALAR 256
 #endif
 
 struct sw_ctx {

@@ -345,8 +345,9 @@ struct Geometry {
     static constexpr int NW = (kPacked && !kWide) ? (R + 1) / 2 : R;
     using C = Chunks<NW>;
     static constexpr int NCH = C::kCount;
-    // chunk k of lane l at k*kChunkRowBytes + l*16; 8-lane groups keep the 16 slots of a DPP row (slots 8..15 unused:
-    // the second group of a row reads the first one's slots, in a later LDS cycle) so that the letter arithmetic is the same
+    // chunk k of lane l at k*kChunkRowBytes + l*16; 8-lane groups keep the 16 slots of a DPP row: the first group of a row
+    // reads slots 0..7, the second one slots 8..15 (dp_step: laneStep), which the profile builder fills with a copy —
+    // sharing slots 0..7 made the two groups meet in the same banks with different letter rows
     static constexpr int kChunkRowBytes = (LANES <= 16 ? 16 : LANES) * 16;
     static constexpr int kRowBytes = NCH * kChunkRowBytes;
     static constexpr int kTileBytes = kLetters * kRowBytes;

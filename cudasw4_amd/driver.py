@@ -61,7 +61,8 @@ def _load():
     L.swdrv_streamed_bytes.restype = ctypes.c_int64
     L.swdrv_streamed_bytes.argtypes = [vp]
     L.swdrv_plan_residency.argtypes = [vp, sz, i32, sz, sz, sz, sz, sz, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
-                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), vp, ctypes.c_int]
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), vp, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_int64)]
     L.swdrv_reference_length.restype = i32
     L.swdrv_reference_length.argtypes = [vp, ctypes.c_int64]
     L.swdrv_reference_header.argtypes = [vp, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int]
@@ -182,18 +183,19 @@ def shard_ranges(offsets, sorted_lengths, world):
 def plan_residency(local_offsets, max_len, max_gpu_mem=0, max_batch_bytes=0, max_batch_sequences=0, max_temp_bytes=0,
                    free_mem=288 << 30, allow_cache=True):
     """The C++ driver's residency decision for one GPU's shard (plan_residency; no GPU needed) -> dict: cache_begin (the
-    subjects from there on stay in device memory), cache_bytes, batch_bytes, batches = [(begin, end), ...] of the rest."""
+    subjects from there on stay in device memory), cache_bytes, batch_bytes, batches = [(begin, end), ...] of the rest,
+    temp_per_stream (cap of each of the 4 stripe-border scratch buffers)."""
     o = np.ascontiguousarray(local_offsets, dtype=np.uint64)
     n = len(o) - 1
     cap = max(n, 1)
     out = np.zeros(2 * cap, dtype=np.int64)
-    cb, cby, bb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    cb, cby, bb, tps = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     nb = lib.swdrv_plan_residency(o.ctypes.data, n, int(max_len), max_gpu_mem, max_batch_bytes, max_batch_sequences,
                                   max_temp_bytes, free_mem, int(allow_cache), ctypes.byref(cb), ctypes.byref(cby),
-                                  ctypes.byref(bb), out.ctypes.data, cap)
+                                  ctypes.byref(bb), out.ctypes.data, cap, ctypes.byref(tps))
     if nb < 0:
         raise DriverError(lib.swdrv_last_error().decode())
-    return {"cache_begin": cb.value, "cache_bytes": cby.value, "batch_bytes": bb.value,
+    return {"cache_begin": cb.value, "cache_bytes": cby.value, "batch_bytes": bb.value, "temp_per_stream": tps.value,
             "batches": [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(nb)]}
 
 
@@ -250,11 +252,11 @@ class Driver:
 
     def take_kernel_events(self):
         """-> list of dicts (gpu, kind, part_id, qlen, subjects, cells, chars, ms, t0_ms, t1_ms, eff_kind, rows,
-        nstripes, lanes), HIP-event timed launches; t0/t1: begin and end on the device clock since recording was
+        nstripes, lanes, rescore), HIP-event timed launches; t0/t1: begin and end on the device clock since recording was
         switched on; the last four name the kernel instantiation."""
         cap = 16384
         while True:
-            buf = np.zeros(cap * 14, dtype=np.float64)
+            buf = np.zeros(cap * 15, dtype=np.float64)
             n = lib.swdrv_take_kernel_events(self.handle, buf.ctypes.data, cap)
             if n < 0:
                 raise DriverError(lib.swdrv_last_error().decode())
@@ -262,9 +264,9 @@ class Driver:
                 break
             raise DriverError("more than %d kernel events between two takes" % cap)
         keys = ("gpu", "kind", "part_id", "qlen", "subjects", "cells", "chars", "ms", "t0_ms", "t1_ms", "eff_kind", "rows",
-                "nstripes", "lanes")
+                "nstripes", "lanes", "rescore")
         floats = ("cells", "chars", "ms", "t0_ms", "t1_ms")
-        return [dict(zip(keys, (float(v) if k in floats else int(v) for k, v in zip(keys, buf[14 * i:14 * i + 14]))))
+        return [dict(zip(keys, (float(v) if k in floats else int(v) for k, v in zip(keys, buf[15 * i:15 * i + 15]))))
                 for i in range(n)]
 
     def shard_info(self, gpu=0):

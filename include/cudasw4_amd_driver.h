@@ -68,11 +68,12 @@ int swdrv_scan_collect(swdrv* d, int32_t* scores, int64_t* ids, int cap, int* nr
 int swdrv_in_flight(swdrv* d);
 
 /* ---- measurement / verification hooks (bench.py, tests) ----
- * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 14 doubles per launch
+ * Kernel events: HIP events around every DP launch on the stream it runs on.  take: 15 doubles per launch
  * (gpu index, kind, part_id, query length, subjects, cells, padded subject bytes, milliseconds, begin ms, end ms — these
  * two on the device clock since recording was switched on: launches on different streams overlap, the union of the
  * intervals is the time the DP kernels kept the GPU busy — and the kernel instantiation: kind computed in, rows per lane,
- * query stripes, lanes per group); returns the number of launches recorded since the last call
+ * query stripes, lanes per group; last: 1 for an overflow re-score launch, whose cells / bytes are 0 — the length of
+ * its list is only known on the device); returns the number of launches recorded since the last call
  * (may exceed cap), -1 on error. */
 int swdrv_record_kernel_events(swdrv* d, int on);
 int swdrv_take_kernel_events(swdrv* d, double* out, int cap);
@@ -104,10 +105,14 @@ int swdrv_shard_ranges(const int32_t* sorted_lengths, const uint64_t* offsets, s
  * length, max_len its longest subject, free_mem what the device has free, the limits as in swdrv_create (0 = default).
  * -> *cache_begin: subjects [cache_begin, n) keep their chars in device memory (0: the shard is resident), *cache_bytes
  * their bytes, *batch_bytes the batch size of the streamed rest, batches[2 i], [2 i + 1] = begin / end of streamed batch
- * i; returns the number of batches (may exceed cap), -1 on error.  allow_cache = 0: all-or-nothing residency. */
+ * i; *temp_per_stream (may be NULL): what each of the 4 stripe-border scratch buffers of a GPU (work, second work, two
+ * auxiliary streams) may grow to, so that cached chars + 3 staging buffers + 4 scratch buffers + 24 bytes per subject fit
+ * the limit (from 4.3 GiB up; below that the 256 MiB floor per buffer wins); returns the number of batches (may exceed
+ * cap), -1 on error.  allow_cache = 0: all-or-nothing residency. */
 int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_len, size_t max_gpu_mem, size_t max_batch_bytes,
                          size_t max_batch_sequences, size_t max_temp_bytes, size_t free_mem, int allow_cache,
-                         int64_t* cache_begin, int64_t* cache_bytes, int64_t* batch_bytes, int64_t* batches, int cap);
+                         int64_t* cache_begin, int64_t* cache_bytes, int64_t* batch_bytes, int64_t* batches, int cap,
+                         int64_t* temp_per_stream);
 
 /* header / length of a subject by global id (getReferenceHeader / getReferenceLength) */
 int32_t swdrv_reference_length(swdrv* d, int64_t id);

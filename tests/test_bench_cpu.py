@@ -1,6 +1,7 @@
 """CPU: bench.py's launcher logic, the one launch planner / shard cutter shared by the C++ driver and the Python
 mirror, and the synthetic DB generator.  No GPU, no compute calls."""
 import importlib.util
+import json
 import os
 import subprocess
 import sys
@@ -47,32 +48,45 @@ def test_bench_counters_are_tied_to_the_kernel_sources():
 
 
 def reference_walk(lengths, kinds):
-    """The partition walk restated independently (cudasw4.cuh:1742-2103 + merging of equal kinds)."""
+    """The partition walk restated independently (cudasw4.cuh:1742-2103 + merging of equal kinds): partition 35 always
+    alone; partition 34 alone while it holds fewer than 512 subjects (wave-wide groups), else part of the bulk."""
     bounds = O.partition_boundaries()
     ends = np.searchsorted(lengths, bounds, side="right")
     begins = np.concatenate([[0], ends[:-1]])
-    runs = []
+    runs, last_bulk = [], False
     for p in range(35, -1, -1):
         b, e = int(begins[p]), int(ends[p])
         if e <= b:
             continue
         kind = kinds[0] if p < 34 else kinds[1] if p == 34 else kinds[2]
-        if runs and runs[-1]["kind"] == kind and runs[-1]["begin"] == e and (runs[-1]["part_id"] >= 34) == (p >= 34):
+        bulk = p < 34 or (p == 34 and e - b >= 512)
+        if runs and runs[-1]["kind"] == kind and runs[-1]["begin"] == e and bulk and last_bulk:
             runs[-1]["begin"] = b
         else:
-            runs.append({"kind": kind, "part_id": p, "begin": b, "end": e, "maxlen": int(lengths[e - 1])})
+            runs.append({"kind": kind, "part_id": 33 if (p == 34 and bulk) else p, "begin": b, "end": e, "maxlen": int(lengths[e - 1])})
+        last_bulk = bulk
     return runs
 
 
 def test_one_planner_for_both_host_drivers():
     from cudasw4_amd import driver, search
     rng = np.random.default_rng(0)
-    for trial in range(20):
-        n = int(rng.integers(1, 400))
+    merged = 0
+    for trial in range(24):
+        n = int(rng.integers(1, 400)) if trial < 16 else int(rng.integers(3000, 9000))
         lengths = np.sort(rng.choice([3, 48, 49, 64, 65, 200, 256, 257, 512, 700, 1280, 1281, 5000, 8000, 8001, 20000], n)).astype(np.int32)
         for kinds in ((0, 0, 3), (1, 1, 2), (2, 1, 2), (3, 0, 3)):
             got = driver.plan_runs(lengths, *kinds)
             assert got == reference_walk(lengths, kinds), (trial, kinds)
+            merged += any(r["part_id"] == 33 and r["maxlen"] > 1280 for r in got)
+    assert merged > 0  # partition 34 joined the bulk launch somewhere
+    # a large partition 34 of the bulk's kind: ONE bulk run + the giants
+    lengths = np.sort(np.concatenate([np.full(5000, 300), np.full(600, 2000), np.full(3, 9000)])).astype(np.int32)
+    got = driver.plan_runs(lengths, 1, 1, 2)
+    assert [(r["part_id"], r["begin"], r["end"], r["maxlen"]) for r in got] == [(35, 5600, 5603, 9000), (33, 0, 5600, 2000)]
+    # other kind for partition 34: a run of its own on the bulk shape (reported as 33); a small one: wave-wide groups (34)
+    assert [r["part_id"] for r in driver.plan_runs(lengths, 2, 1, 2)] == [35, 33, 15]
+    assert [r["part_id"] for r in driver.plan_runs(lengths[:5100], 1, 1, 2)] == [34, 15]
     assert driver.plan_runs(np.zeros(0, np.int32), 0, 0, 3) == []
     # the Python mirror's merged plan IS the C++ planner's
     import inspect
@@ -111,6 +125,50 @@ def test_synthetic_sprot_like_db_layout():
     a = synthdb.sprot_like(2000)
     b = synthdb.sprot_like(2000)
     assert all((x == y).all() for x, y in zip(a, b))
+
+
+def test_sprot_like_db_carries_families_of_the_queries():
+    """The Swiss-Prot stand-in holds what a real Swiss-Prot holds for these queries: the proteins
+    themselves and seeded relatives — so scans see hits far above the noise floor, packed overflows and re-scores —
+    while sequence count, length histogram, sort order and layout stay those of the background."""
+    from cudasw4_amd import synthdb
+    n = 40000
+    chars, offsets, lengths, fam = synthdb.sprot_like(n, return_family_ids=True)
+    plain = synthdb.sprot_like(n, families=False)
+    assert (lengths == plain[2]).all() and (offsets == plain[1]).all() and len(chars) == len(plain[0])
+    assert (np.diff(lengths) >= 0).all() and chars.min() >= 0 and chars.max() <= 20
+    ends = offsets[:-1].astype(np.int64) + lengths
+    assert all((chars[int(e):int(o)] == 20).all() for e, o in list(zip(ends, offsets[1:]))[::997])
+    assert 100 < len(fam) < n // 20 and (np.diff(fam) > 0).all()
+    # only family slots differ from the background
+    changed = np.nonzero([not np.array_equal(chars[int(offsets[i]):int(offsets[i + 1])], plain[0][int(offsets[i]):int(offsets[i + 1])])
+                          for i in fam])[0]
+    assert len(changed) == len(fam)
+    untouched = np.setdiff1d(np.arange(0, n, 53), fam)
+    assert all(np.array_equal(chars[int(offsets[i]):int(offsets[i + 1])], plain[0][int(offsets[i]):int(offsets[i + 1])]) for i in untouched)
+    # composition of the background: Swiss-Prot's, not uniform
+    freq = np.bincount(plain[0][plain[0] < 20], minlength=20) / float((plain[0] < 20).sum())
+    assert abs(freq[10] - 0.0965) < 0.003 and abs(freq[17] - 0.011) < 0.002     # L and W
+    # the queries find themselves (self score, Appendix B of SURVEY.md) and relatives above the packed limits
+    _, qs = O.load_queries()
+    from cudasw4_amd import search
+    sub = search.build_shard(chars, offsets, lengths, [(int(i), int(i) + 1) for i in fam])[:3]
+    golden = json.load(open(os.path.join(O.GOLDEN_DIR, "ref_scores.json")))
+    self_scores = [golden["allvsall"][i][i] for i in range(20)] if "allvsall" in golden else None
+    over_f16 = 0
+    for qi in (4, 9, 16):
+        sc = O.scan(qs[qi], *sub, simd=True)
+        if self_scores:
+            assert int(sc.max()) == self_scores[qi]
+        over_f16 += int((sc >= 2048).sum())
+        assert (sc >= 1000).sum() >= (2 if qi < 10 else 1)   # long proteins are rare: a long query may only find itself
+    assert over_f16 >= 10
+    q16 = O.scan(qs[16], *sub, simd=True)
+    assert int(q16.max()) >= 25000                                              # an int16 overflow as well
+    # small DBs get proportionally small families, and the generator is deterministic
+    small = synthdb.sprot_like(2000, return_family_ids=True)
+    assert 20 <= len(small[3]) <= 200
+    assert all((x == y).all() for x, y in zip(synthdb.sprot_like(n, return_family_ids=True), (chars, offsets, lengths, fam)))
 
 
 def test_union_of_launch_intervals():

@@ -626,7 +626,7 @@ def test_letter_code_guard_and_launch_plan_introspection(monkeypatch):
             assert rows * lanes * ns >= qlen and rows >= 1 and ns >= 1 and lanes in (8, 16)
             assert k == (capi.KIND_F32 if kind == capi.KIND_I32 else kind)           # 512 x 11 + 2^22 < 2^24
             packed = kind in (capi.KIND_F16X2, capi.KIND_I16X2)
-            assert lanes == (8 if qlen <= (256 if packed else 240) else 16), (qlen, kind, lanes)
+            assert lanes == (8 if qlen <= 256 else 16), (qlen, kind, lanes)
             assert (rows, ns) == capi.plan_query(k, qlen) or lanes == 8
     assert plan(5478, capi.KIND_F32, 35, 19, 35213)[3] == 64          # a few giants: wave-wide groups
     assert plan(5478, capi.KIND_F16X2, 34, 400, 8000)[3] == 64 and plan(5478, capi.KIND_F16X2, 34, 600, 8000)[3] == 16

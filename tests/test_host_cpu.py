@@ -440,3 +440,31 @@ def test_residency_plan_hybrid_and_batches():
     # an empty shard
     r = driver.plan_residency(np.zeros(1, dtype=np.uint64), 0, max_gpu_mem=1)
     assert r["cache_begin"] == 0 and r["batches"] == []
+
+
+def test_residency_plan_budgets_the_scratch_of_every_stream():
+    """the limit must cover the stripe-border scratch of EVERY stream that can hold one (work, second work, two
+    auxiliary streams — all live in a hybrid scan), not one buffer: cached chars + 3 staging buffers + 4 scratch buffers at
+    their cap + the per-subject arrays + the safety margin stay inside --maxGpuMem (from 4.3 GiB up, where the quarter of the
+    limit covers the 256 MiB floor per buffer)."""
+    from cudasw4_amd import driver
+    n = 200000
+    lengths = np.full(n, 400, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    off = (off * 2000).astype(np.uint64)   # 160 GB of chars: far above every limit below
+    meta = 24 * n + 8
+    for limit_gb, max_temp in ((5, 0), (6, 0), (16, 0), (16, 64 << 20), (64, 0)):
+        limit = (limit_gb << 30) + meta
+        r = driver.plan_residency(off, 800000, max_gpu_mem=limit, max_batch_bytes=128 << 20, max_temp_bytes=max_temp)
+        assert r["cache_begin"] > 0 and r["batches"]
+        tps = r["temp_per_stream"]
+        assert tps >= min(max_temp or (4 << 30), 256 << 20) and tps <= (max_temp or (4 << 30))
+        used = meta + (256 << 20) + r["cache_bytes"] + 64 + 3 * (r["batch_bytes"] + 64) + 4 * tps
+        assert used <= limit, (limit_gb, max_temp, used - limit)
+    # resident with memory to spare: every buffer may grow to --maxTempBytes
+    small = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    assert driver.plan_residency(small, 400)["temp_per_stream"] == 4 << 30
+    assert driver.plan_residency(small, 400, max_temp_bytes=1 << 20)["temp_per_stream"] == 1 << 20
+    # resident, but barely: the buffers share what is left (never below the floor)
+    tight = driver.plan_residency(small, 400, max_gpu_mem=int(small[-1]) + (2 << 30) + meta)
+    assert tight["cache_begin"] == 0 and (256 << 20) <= tight["temp_per_stream"] <= (2 << 30) // 4 + (1 << 20)

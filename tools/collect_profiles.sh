@@ -39,7 +39,9 @@ if has traffic && has valu; then
 python3 tools/rocprof_summary.py counters $RAW/pmc_SQ_INSTS_VALU.log $RAW/pmc_FETCH_SIZE/bench_results.db $RAW/pmc_WRITE_SIZE/bench_results.db \
     $RAW/pmc_SQ_INSTS_VALU/bench_results.db "profiles/${TAG}_${NAME}_pmc.txt (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE)" $COMMIT \
     > $OUT/${TAG}_${NAME}_counters.json 2>&1
-cp profiles/kernel_counters.json $OUT/kernel_counters.json
+[ -n "${KERNEL_COUNTERS_OUT:-}" ] || cp profiles/kernel_counters.json $OUT/kernel_counters.json
 fi
 rm -rf $RAW
 ls -la $OUT
+# the counters entry of this configuration must exist when its passes were asked for
+if has traffic && has valu; then grep -q '"key"' $OUT/${TAG}_${NAME}_counters.json || exit 1; fi

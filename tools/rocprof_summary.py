@@ -97,7 +97,9 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
     insts = sum(v for (v,) in db.execute(
         "select value from counters_collection where counter_name = 'SQ_INSTS_VALU' and kernel_name like '%sw_scan_kernel%'"))
     ipu = insts * 64.0 / (cells / (2 if packed else 1))
-    out_path = os.path.join(root, "profiles", "kernel_counters.json")
+    # KERNEL_COUNTERS_OUT: where the file is built (tools/collect_all_profiles.sh builds it under gpurun_out/ and only
+    # replaces the tracked profiles/kernel_counters.json once every expected entry is there)
+    out_path = os.environ.get("KERNEL_COUNTERS_OUT") or os.path.join(root, "profiles", "kernel_counters.json")
     try:
         cur = json.load(open(out_path))
     except (OSError, ValueError):
