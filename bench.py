@@ -60,10 +60,14 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["peak", "sprot-like"], default="peak")
+    ap.add_argument("--workload", choices=["peak", "sprot-like", "uniref50-like"], default="peak")
+    ap.add_argument("--queries", default=None, help="comma-separated indices into allqueries.fasta (default: all 20)")
+    ap.add_argument("--shards-per-gpu", type=int, default=1,
+                    help="in-process shards per rank, all on this rank's GPU (one worker thread, context and stream set each): the "
+                         "shape of an N-GPU node on one device")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: shard ONE DB over the ranks (strong, default) or give every rank its own DB (weak)")
-    ap.add_argument("--db-size", type=int, default=None, help="subjects of the DB (peak: 1000000, sprot-like: 570000)")
+    ap.add_argument("--db-size", type=int, default=None, help="subjects of the DB (peak: 1000000, sprot-like: 570000, uniref50-like: 60000000)")
     ap.add_argument("--db-length", type=int, default=512, help="peak: pseudo-DB subject length")
     ap.add_argument("--kernel", choices=sorted(KIND_BY_NAME) + ["dpx"], default=None,
                     help="kernel configuration (peak default: half2; sprot-like default: dpx = DPXs16/DPXs16/DPXs32/DPXs32)")
@@ -137,7 +141,7 @@ def load_counters():
 
 
 def kinds_for(args):
-    name = args.kernel or ("half2" if args.workload == "peak" else "dpx")
+    name = args.kernel or ("dpx" if args.workload == "sprot-like" else "half2")
     if name == "dpx":
         return name, (1, 1, 2, 2)
     k = KIND_BY_NAME[name]
@@ -157,14 +161,15 @@ def cpu_baseline(queries, chars, offsets, lengths, what):
     scores[query][subject] of the sample) — the scores double as the checker of the GPU results."""
     import oracle_lib as O
     m = O.blosum21(62)
+    qmid = queries[len(queries) // 2]
     ncal = min(len(lengths), 6000)
     cal = (chars[:int(offsets[ncal])], offsets[:ncal + 1], lengths[:ncal])
     best_nt, best_rate = _CPU_THREADS.get("n", 1), 0.0
     nt = 0 if "n" in _CPU_THREADS else O.max_threads()
     while nt >= 1:
-        O.scan(queries[9], *cal, m21=m, simd=True, nthreads=nt)  # warm-up of this team size
+        O.scan(qmid, *cal, m21=m, simd=True, nthreads=nt)  # warm-up of this team size
         t0 = time.perf_counter()
-        O.scan(queries[9], *cal, m21=m, simd=True, nthreads=nt)
+        O.scan(qmid, *cal, m21=m, simd=True, nthreads=nt)
         rate = 1.0 / (time.perf_counter() - t0)
         if rate > best_rate:
             best_nt, best_rate = nt, rate
@@ -182,8 +187,8 @@ def cpu_baseline(queries, chars, offsets, lengths, what):
     # the reference's own scalar int32 DP (cudasw4.cuh:2331-2392 restated), one core, a few hundred subjects
     ns = min(300, len(lengths))
     t0 = time.perf_counter()
-    O.scan(queries[9], chars[:int(offsets[ns])], offsets[:ns + 1], lengths[:ns], m21=m, nthreads=1)
-    scalar_rate = len(queries[9]) * float(lengths[:ns].astype(np.int64).sum()) / 1e9 / (time.perf_counter() - t0)
+    O.scan(qmid, chars[:int(offsets[ns])], offsets[:ns + 1], lengths[:ns], m21=m, nthreads=1)
+    scalar_rate = len(qmid) * float(lengths[:ns].astype(np.int64).sum()) / 1e9 / (time.perf_counter() - t0)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -194,10 +199,10 @@ def cpu_baseline(queries, chars, offsets, lengths, what):
     obj = {"value": round(rates[best][0], 3), "unit": "GCUPS", "cores": best_nt, "kind": "port", "algorithm": best,
            "striped_gcups": round(rates["striped"][0], 3), "interseq_gcups": round(rates["interseq"][0], 3),
            "scalar_1core_gcups": round(scalar_rate, 4), "cpu_model": model,
-           "sample": "20 queries x %s; oracle ports with int16 lanes (gcc, AVX-512 or AVX2 build picked by cpuid): Farrar "
+           "sample": "%d queries x %s; oracle ports with int16 lanes (gcc, AVX-512 or AVX2 build picked by cpuid): Farrar "
                      "striped SW %.1f s, inter-sequence SIMD %.1f s; %d of %d hardware threads (best of ONE calibration sweep per "
                      "line: every CPU leg of this line uses the same team size)"
-                     % (what, rates["striped"][1], rates["interseq"][1], best_nt, O.max_threads())}
+                     % (len(queries), what, rates["striped"][1], rates["interseq"][1], best_nt, O.max_threads())}
     return obj, scores
 
 
@@ -353,9 +358,17 @@ def run_rank(args):
         else:
             dist.init_process_group(backend)
 
+    # one process per GPU: this rank's threads (the driver's launches, its staging copies of streamed shards) run on the
+    # NUMA node the GPU hangs off — on a two-socket box half of the GPUs sit behind the other socket
+    from cudasw4_amd import driver as _driver
+    numa_node = _driver.device_numa_node(local_rank)
+    numa_bound = os.environ.get("BENCH_NO_NUMA_BIND") != "1" and _driver.bind_to_numa_node(numa_node)
+    sys.stderr.write("bench.py: rank %d of %d on GPU %d, NUMA node %d%s\n" % (rank, world, local_rank, numa_node, " (threads bound to it)" if numa_bound else ""))
+
     class Env:
         pass
     env = Env()
+    env.numa_node, env.numa_bound = numa_node, bool(numa_bound)
     env.torch, env.dist, env.world, env.rank, env.local_rank = torch, dist, world, rank, local_rank
     env.distributed, env.backend, env.comm_dev = distributed, backend, comm_dev
     out = measure(env, args, args.workload, want_cpu=not args.no_cpu_baseline and world == 1)
@@ -452,13 +465,16 @@ def measure(env, args, workload, want_cpu):
     from cudasw4_amd import capi, driver, search, synthdb
 
     _, query_letters = driver.read_sequences(os.path.join(ROOT, "tests", "golden", "allqueries.fasta"))
+    if args.queries:
+        query_letters = [query_letters[int(i)] for i in args.queries.split(",")]
     queries = [driver.encode(q) for q in query_letters]
     sum_q = sum(len(q) for q in queries)
     kernel_name, kinds = kinds_for(args)
     strong = args.scaling == "strong" or not distributed
     K = max(args.top, 0)
 
-    drv = driver.Driver(devices=[local_rank], num_top=K, matrix=62, kinds=kinds, max_gpu_mem=parse_size(args.max_gpu_mem),
+    nshards = max(1, args.shards_per_gpu)
+    drv = driver.Driver(devices=[local_rank] * nshards, num_top=K, matrix=62, kinds=kinds, max_gpu_mem=parse_size(args.max_gpu_mem),
                         max_batch_bytes=parse_size(args.max_batch_bytes))
     host_db = None
     data = "synthetic"
@@ -482,6 +498,14 @@ def measure(env, args, workload, want_cpu):
             drv.open_db(args.db_prefix, prefetch=True)
             data = "real"
             label = "DB %s" % args.db_prefix
+        elif args.workload == "uniref50-like":
+            num = args.db_size or synthdb.UNIREF50_SEQUENCES
+            t_gen = time.perf_counter()
+            host_db = synthdb.uniref50_like(num, torch_device=torch.device("cuda", local_rank))
+            drv.set_shard(rank, world, 0) if strong else drv.set_shard(0, 1, rank * num)
+            drv.db_from_arrays(*host_db)
+            label = "UniRef50-sized synthetic DB (Swiss-Prot length histogram and composition, independent residues; generated and loaded in %.0f s)" % (
+                time.perf_counter() - t_gen)
         else:
             num = args.db_size or synthdb.SPROT_SEQUENCES
             host_db = synthdb.sprot_like(num, families=not args.no_families)
@@ -540,6 +564,7 @@ def measure(env, args, workload, want_cpu):
     for _ in range(args.warmup):
         one_step()
     barrier()
+    h2d_before = drv.streamed_bytes()
     drv.record_kernel_events(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -548,6 +573,7 @@ def measure(env, args, workload, want_cpu):
     dt = time.perf_counter() - t0
     drv.record_kernel_events(False)
     events = drv.take_kernel_events()
+    h2d_per_step = (drv.streamed_bytes() - h2d_before) // max(args.steps, 1)
 
     t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
     if distributed:
@@ -564,10 +590,10 @@ def measure(env, args, workload, want_cpu):
             if golden is None:
                 ok, verify_note = None, "no golden scores for pseudo-DB length %d" % args.db_length
             else:
-                nloc = info["subjects"]
+                nloc = sum(drv.shard_info(g)["subjects"] for g in range(nshards))
                 for qi, q in enumerate(query_letters):
                     drv.scan(q)
-                    sc, ids = drv.last_scores(0)
+                    ids, sc = drv.all_scores()
                     ok = ok and len(sc) == nloc and int(sc.min()) == int(sc.max()) == int(golden[qi])
                     if rank == 0 and K > 0:
                         kk = min(K, total_subjects)
@@ -577,10 +603,20 @@ def measure(env, args, workload, want_cpu):
                         ok = ok and merged[qi][0].tolist() == [int(golden[qi])] * kk and merged[qi][1].tolist() == want_ids
                 verify_note = "all %d scores of every query equal the reference's golden score; merged top-%d scores and ids as expected" % (nloc, K)
         else:
+            def top_of_all(sc, ids, k):
+                """score desc, id asc — without sorting 6e7 entries: everything at or above the k-th largest score"""
+                if k <= 0 or len(sc) == 0:
+                    return np.zeros(0, np.int32), np.zeros(0, np.int64)
+                kk = min(k, len(sc))
+                thr = np.partition(sc, len(sc) - kk)[len(sc) - kk]
+                cand = np.nonzero(sc >= thr)[0]
+                return search.merge_topk([(sc[cand], ids[cand])], kk)
+            big = num > 5_000_000
             gpu_scores = []
-            for q in query_letters:
+            for q in (query_letters if not big else []):
                 drv.scan(q)
-                gpu_scores.append(drv.last_scores(0))
+                ids_all, sc_all = drv.all_scores()
+                gpu_scores.append((sc_all, ids_all))
             if want_cpu:
                 # the CPU leg scores a seeded sample of the DB (plus the longest subjects): timing AND checker
                 chars, offsets, lengths = host_db
@@ -591,12 +627,20 @@ def measure(env, args, workload, want_cpu):
                 cpu_obj, cpu_scores = cpu_baseline(queries, sub[0], sub[1], sub[2],
                                                    "%d sampled subjects (%d residues, incl. the 4 longest) of the same DB" % (len(pick), int(sub[2].astype(np.int64).sum())))
                 for qi in range(len(queries)):
-                    sc, ids = gpu_scores[qi]
-                    order = np.argsort(ids)
-                    ok = ok and (sc[order][pick] == cpu_scores[qi]).all()
-                    top = search.merge_topk([(sc, ids)], K) if K > 0 else None
+                    if big:     # one query's scores at a time (12 bytes per subject on the host)
+                        drv.scan(query_letters[qi])
+                        ids, sc = drv.all_scores()
+                    else:
+                        sc, ids = gpu_scores[qi]
+                    by_id = np.empty(num, dtype=np.int32)
+                    by_id[ids] = sc     # world == 1: this rank's shards cover every id
+                    ok = ok and len(sc) == num and (by_id[pick] == cpu_scores[qi]).all()
+                    top = top_of_all(sc, ids, K) if K > 0 else None
                     ok = ok and (K == 0 or (merged[qi][0].tolist() == top[0].tolist() and merged[qi][1].tolist() == top[1].tolist()))
-                verify_note = "every score of %d sampled subjects x 20 queries equals the CPU oracle; top-%d equals the top of all scores" % (len(pick), K)
+                verify_note = "every score of %d sampled subjects x %d queries equals the CPU oracle; top-%d equals the top of all %d scores" % (
+                    len(pick), len(queries), K, num)
+            elif big:
+                ok, verify_note = None, "not verified: a DB of this size is checked against the CPU leg only (drop --no-cpu-baseline)"
             else:
                 # no CPU leg: an independent arithmetic path — all scores again with the int32 kernels only
                 d2 = driver.Driver(devices=[local_rank], num_top=0, matrix=62, kinds=(2, 1, 2, 2))
@@ -606,7 +650,8 @@ def measure(env, args, workload, want_cpu):
                 for qi, q in enumerate(query_letters):
                     d2.scan(q)
                     sc2, ids2 = d2.last_scores(0)
-                    ok = ok and (sc2 == gpu_scores[qi][0]).all() and (ids2 == gpu_scores[qi][1]).all()
+                    o1 = np.argsort(gpu_scores[qi][1], kind="stable")
+                    ok = ok and (sc2 == gpu_scores[qi][0][o1]).all() and (ids2 == gpu_scores[qi][1][o1]).all()
                 d2.close()
                 verify_note = "all scores of every query equal between the %s and the int32 kernel configuration" % kernel_name
         if ok is not None and distributed:
@@ -624,13 +669,15 @@ def measure(env, args, workload, want_cpu):
             "dtype": DTYPE_BY_KIND[kinds[0]] + (" (int32 results computed in fp32 lanes: exact below 2^24, bound checked per launch)"
                                                 if kinds[0] == 2 and os.environ.get("CUDASW4_AMD_I32_NATIVE") != "1" else ""),
             "data": data, "verified": verified, "verified_how": verify_note,
-            "config": {"workload": "%s: allqueries.fasta (20 queries, %d residues) vs %s, %s kernel configuration, blosum62, "
-                                   "gop -11 gex -1, top %d, C++ host driver" % (args.workload, sum_q, what, kernel_name, K),
+            "config": {"workload": "%s: allqueries.fasta (%d queries, %d residues) vs %s, %s kernel configuration, blosum62, "
+                                   "gop -11 gex -1, top %d, C++ host driver" % (args.workload, len(queries), sum_q, what, kernel_name, K),
                        "db_subjects": total_subjects, "db_residues": int(total_residues), "queries": len(queries),
                        "kernel": kernel_name, "host": "libcudasw4_host.so (SearchDriver)",
                        "queries_in_flight": 2 if pipelined else 1,
+                       "numa_node_rank0": env.numa_node, "numa_bound": env.numa_bound,
                        "resident": info["resident"], "residency": residency_of(info),
                        "cached_chars": info.get("cached_chars"), "shard_chars": info["chars"],
+                       "shards_on_this_gpu": nshards, "h2d_subject_bytes_per_step": int(h2d_per_step),
                        "parallelism": "db-shard x%d (%s), one top-K gather per step + host merge" % (world, "one DB sharded" if strong else "one DB per rank")},
             "roofline": roof, "valu_roofline": valu,
             # what real data loads a scan with (half2_kernels.cuh:1087-1109, cudasw4.cuh:2134-2172), per step = one pass of

@@ -126,12 +126,20 @@ int main(int argc, char** argv) {
             for (int x : deviceIds) std::cout << " " << x;
             std::cout << "\n";
         }
+        if (deviceIds.size() == 1) {
+            // one GPU: this thread issues everything (with several, every GPU has a worker thread on its own node): run it
+            // on the CPUs next to the GPU (CUDASW4_AMD_NO_NUMA_BIND=1: leave the affinity alone)
+            const char* no = std::getenv("CUDASW4_AMD_NO_NUMA_BIND");
+            const int node = numa_node_of_device(deviceIds[0]);
+            if (!(no && no[0] == '1') && bind_thread_to_numa_node(node) && options.verbose)
+                std::cout << "GPU " << deviceIds[0] << " is on NUMA node " << node << ": host threads bound to it\n";
+        }
         std::ofstream outputfile(options.outputfile);
         if (!outputfile) throw std::runtime_error("Cannot open file " + options.outputfile);
         if (options.outputMode == ProgramOptions::OutputMode::TSV) printTSVHeader(outputfile);
 
         SearchDriver driver(deviceIds, options.numTopOutputs, options.matrix, options.kernels, options.memory, options.verbose,
-                            options.gop, options.gex);
+                            options.effectiveGop(), options.effectiveGex());
         if (!options.usePseudoDB) {
             if (options.verbose) std::cout << "Reading Database: \n";
             Stopwatch t;

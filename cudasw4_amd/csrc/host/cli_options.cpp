@@ -27,6 +27,7 @@ void printOptions(const ProgramOptions& o) {
     std::cout << "numTopOutputs: " << o.numTopOutputs << "\n";
     std::cout << "gop: " << o.gop << "\n";
     std::cout << "gex: " << o.gex << "\n";
+    if (o.refCompat) std::cout << "refCompat: gap scores applied are " << o.effectiveGop() << " / " << o.effectiveGex() << " like the reference binary's\n";
     std::cout << "maxBatchBytes: " << o.memory.maxBatchBytes << "\n";
     std::cout << "maxBatchSequences: " << o.memory.maxBatchSequences << "\n";
     std::cout << "maxTempBytes: " << o.memory.maxTempBytes << "\n";
@@ -91,6 +92,7 @@ bool parseArgs(int argc, char** argv, ProgramOptions& o) {
             gotDB = true;
         }
         else if (arg == "--dpx") gotDPX = true;
+        else if (arg == "--refCompat") o.refCompat = true;
         else if (arg == "--tsv") o.outputMode = ProgramOptions::OutputMode::TSV;
         else if (arg == "--of") o.outputfile = value(i);
         else std::cout << "Unexpected arg " << arg << "\n";
@@ -100,6 +102,7 @@ bool parseArgs(int argc, char** argv, ProgramOptions& o) {
     const SubstitutionMatrix& m = substitution_matrix(o.matrix);
     if (!gotGop) o.gop = m.default_gop;
     if (!gotGex) o.gex = m.default_gex;
+    if (const char* e = std::getenv("CUDASW4_AMD_REF_COMPAT")) o.refCompat = o.refCompat || e[0] == '1';
     if (gotDPX) {
         o.kernels.singlePassType = KernelType::DPXs16;
         o.kernels.manyPassType_small = KernelType::DPXs16;
@@ -132,6 +135,7 @@ void printHelp(char** argv) {
     std::cout << "      --maxBatchSequences val : Process DB in batches of at most val sequences. Default val = " << d.memory.maxBatchSequences << "\n\n";
     std::cout << "   Misc\n";
     std::cout << "      --dpx : Use the packed int16 / int32 kernels (the reference's DPX kernels).\n";
+    std::cout << "      --refCompat : Apply gap scores -11 / -1 whatever --gop, --gex and --mat say, like the reference binary does.\n";
     std::cout << "      --of : Result output file. Parent directory must exist. Default: console output (/dev/stdout)\n";
     std::cout << "      --tsv : Print results as tab-separated values instead of plain text. \n";
     std::cout << "      --verbose : More console output. Shows timings. \n";

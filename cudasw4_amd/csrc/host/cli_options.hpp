@@ -24,6 +24,14 @@ struct ProgramOptions {
     int numTopOutputs = 10;
     int gop = -11;
     int gex = -1;
+    // --refCompat (or CUDASW4_AMD_REF_COMPAT=1): score exactly like the reference BINARY.  There --gop / --gex and the
+    // per-matrix default gap scores are parsed and printed (options.cpp:179-194) but never reach the kernels
+    // (cudasw4.cuh:539-550: the setters have no call site), which always run gop -11 / gex -1 — so the same inputs give the
+    // reference's output for every --mat.  The reference's other quirk, the fp16 overflow check that is off for partitions
+    // 0-12, is NOT reproduced: it returns inexact scores.
+    bool refCompat = false;
+    int effectiveGop() const { return refCompat ? -11 : gop; }
+    int effectiveGex() const { return refCompat ? -1 : gex; }
     int pseudoDBLength = 0;
     int pseudoDBSize = 0;
     MatrixId matrix = MatrixId::Blosum62;

@@ -296,6 +296,22 @@ int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_le
 
 int swdrv_last_rescored(swdrv* d) { return d ? d->lastRescored : 0; }
 
+int swdrv_numa_node(swdrv* d, int gpu) {
+    int node = -1;
+    (void)guarded([&] { node = d->driver->numaNode(gpu); });
+    return node;
+}
+
+int swdrv_device_of(swdrv* d, int gpu) {
+    int dev = -1;
+    (void)guarded([&] { dev = d->driver->deviceOf(gpu); });
+    return dev;
+}
+
+int swdrv_device_numa_node(int device) { return numa_node_of_device(device); }
+
+int swdrv_bind_to_numa_node(int node) { return bind_thread_to_numa_node(node) ? 0 : -1; }
+
 int32_t swdrv_reference_length(swdrv* d, int64_t id) { return d->driver->getReferenceLength(id); }
 
 int swdrv_reference_header(swdrv* d, int64_t id, char* buf, int cap) {

@@ -3,11 +3,16 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <sched.h>
+
+#include <cctype>
+
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <iostream>
 #include <mutex>
@@ -38,6 +43,65 @@ double now_seconds() {
 bool is_packed(KernelType t) { return t == KernelType::Half2 || t == KernelType::DPXs16; }
 
 }  // namespace
+
+// NUMA node of a HIP device: the numa_node attribute of its PCI function (-1: unknown, or the box has a single node)
+int numa_node_of_device(int device) {
+    char bus[64] = {};
+    if (hipDeviceGetPCIBusId(bus, int(sizeof(bus)) - 1, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    std::string id(bus);
+    for (char& c : id) c = char(std::tolower(static_cast<unsigned char>(c)));
+    std::ifstream f("/sys/bus/pci/devices/" + id + "/numa_node");
+    int node = -1;
+    if (!(f >> node)) return -1;
+    return node;
+}
+
+namespace {
+
+// "0-63,128-191" -> cpu numbers
+std::vector<int> parse_cpulist(const std::string& text) {
+    std::vector<int> cpus;
+    size_t i = 0;
+    while (i < text.size()) {
+        size_t j = text.find(',', i);
+        if (j == std::string::npos) j = text.size();
+        const std::string part = text.substr(i, j - i);
+        const size_t dash = part.find('-');
+        try {
+            const int a = std::stoi(part.substr(0, dash));
+            const int b = dash == std::string::npos ? a : std::stoi(part.substr(dash + 1));
+            for (int c = a; c <= b && c < CPU_SETSIZE; c++) cpus.push_back(c);
+        } catch (...) {}
+        i = j + 1;
+    }
+    return cpus;
+}
+
+}  // namespace
+
+std::vector<int> cpus_of_numa_node(int node) {
+    if (node < 0) return {};
+    std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+    std::string text;
+    if (!std::getline(f, text)) return {};
+    return parse_cpulist(text);
+}
+
+// The calling thread (and the threads it creates from now on) runs on the CPUs of `node`, restricted to the CPUs the
+// process may use at all (a container's cpuset); false: unknown node, or nothing of it is allowed — affinity unchanged.
+bool bind_thread_to_numa_node(int node) {
+    const std::vector<int> cpus = cpus_of_numa_node(node);
+    if (cpus.empty()) return false;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    CPU_ZERO(&want);
+    int n = 0;
+    for (int c : cpus)
+        if (CPU_ISSET(c, &allowed)) { CPU_SET(c, &want); n++; }
+    if (n == 0) return false;
+    return sched_setaffinity(0, sizeof(want), &want) == 0;
+}
 
 const char* to_string(KernelType t) {
     switch (t) {
@@ -90,6 +154,7 @@ struct TimedLaunch {
 struct SearchDriver::Gpu {
     int index = 0;   // position in gpus_
     int device = 0;
+    int numaNode = -1;  // of the device's PCI function; the GPU's worker thread (and the staging copies it starts) run there
     sw_ctx* ctx = nullptr;
     // stream: the work stream (resident scans, every other batch of a streamed scan, top-K, copy-back); stream2: the
     // batches in between, so that the first workgroups of a batch fill the CUs the last round of the batch before
@@ -152,6 +217,13 @@ struct SearchDriver::Gpu {
     hipEvent_t auxDone[kSlots][kAux] = {};
     bool auxPending[kSlots][kAux] = {};
     bool auxUsed[kAux] = {false, false};  // this scan put work on the stream: joined before the top-K
+    // Start handshake (include/cudasw4_amd.h: sw_set_start_signal): every side launch adds 1 to *startSignal when its
+    // workgroups are resident; the bulk launch of the batch waits on the work stream for the count of side launches
+    // enqueued so far.  Without it the persistent bulk grid, once dispatched, holds every workgroup slot to its end and a
+    // side launch that loses the race for the first slots runs BEHIND it (tools/ubench/side_launch_probe.hip: 8 of 8).
+    uint32_t* startSignal = nullptr;   // signal memory (hipMallocSignalMemory)
+    uint32_t sideLaunches = 0;         // enqueued since the signal was last zeroed
+    bool handshake = true;             // CUDASW4_AMD_NO_HANDSHAKE=1 turns it off (A/B measurements)
     bool stream2Used = false;
     bool firstBatchStaged = false;  // staging buffer slotBase already holds the first batch of the next streamed scan
     size_t slotBase = 0;            // staging buffer of the first batch of the next streamed scan
@@ -209,8 +281,12 @@ struct SearchDriver::Worker {
     bool pending = false, busy = false, stop = false;
     std::exception_ptr err;
 
-    Worker() {
-        th = std::thread([this] {
+    explicit Worker(int numaNode) {
+        th = std::thread([this, numaNode] {
+            // per-GPU host thread on the GPU's NUMA node: its pinned staging copies and its launches stay off the other
+            // socket's memory and interconnect (CUDASW4_AMD_NO_NUMA_BIND=1: leave the affinity alone)
+            const char* no = std::getenv("CUDASW4_AMD_NO_NUMA_BIND");
+            if (!(no && no[0] == '1')) (void)bind_thread_to_numa_node(numaNode);
             std::unique_lock<std::mutex> lk(m);
             for (;;) {
                 cv.wait(lk, [this] { return pending || stop; });
@@ -264,6 +340,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         auto g = std::make_unique<Gpu>();
         g->index = int(gpus_.size());
         g->device = dev;
+        g->numaNode = numa_node_of_device(dev);
         g->use();
         SWCHECK(sw_ctx_create(dev, &g->ctx));
         SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), matrix_.dim));
@@ -296,6 +373,21 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             HIPCHECK(hipEventCreateWithFlags(&g->scanned[i], hipEventDisableTiming));
             for (int a = 0; a < Gpu::kAux; a++) HIPCHECK(hipEventCreateWithFlags(&g->auxDone[i][a], hipEventDisableTiming));
         }
+        {
+            int canWait = 0;
+            (void)hipDeviceGetAttribute(&canWait, hipDeviceAttributeCanUseStreamWaitValue, dev);
+            const char* no = std::getenv("CUDASW4_AMD_NO_HANDSHAKE");
+            g->handshake = canWait != 0 && !(no && no[0] == '1');
+            if (g->handshake) {
+                if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g->startSignal), 8, hipMallocSignalMemory) != hipSuccess) {
+                    (void)hipGetLastError();
+                    g->startSignal = nullptr;
+                    g->handshake = false;
+                } else {
+                    *g->startSignal = 0;
+                }
+            }
+        }
         if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
         g->ovfCountCap = 1 + Gpu::kOvfLists;
@@ -303,7 +395,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         gpus_.push_back(std::move(g));
     }
     if (gpus_.size() > 1)
-        for (size_t i = 0; i < gpus_.size(); i++) workers_.push_back(std::make_unique<Worker>());
+        for (size_t i = 0; i < gpus_.size(); i++) workers_.push_back(std::make_unique<Worker>(gpus_[i]->numaNode));
 }
 
 SearchDriver::~SearchDriver() {
@@ -322,6 +414,7 @@ SearchDriver::~SearchDriver() {
                 if (g.auxDone[i][a]) (void)hipEventDestroy(g.auxDone[i][a]);
         }
         (void)hipHostFree(g.h_pad);
+        if (g.startSignal) (void)hipFree(g.startSignal);
         for (hipEvent_t e : g.batchEv) (void)hipEventDestroy(e);
         if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
         if (g.recordRefEv) (void)hipEventDestroy(g.recordRefEv);
@@ -753,14 +846,22 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     int auxNext = 0;
     bool auxBusy[GpuT::kAux] = {};
     std::vector<int> streamOf(runs.size(), -1);  // auxiliary stream of a run, -1: work stream
+    bool anySide = false;
     for (size_t i = 0; i < runs.size(); i++) {
         if (i == mainIdx || (shareLast && ovfList[i] == GpuT::kOvfLists - 1)) continue;
         const int a = auxNext++ % GpuT::kAux;
         if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], fork, 0));
         auxBusy[a] = true;
         streamOf[i] = a;
+        if (g.handshake) {
+            SWCHECK(sw_set_start_signal(g.ctx, g.startSignal));
+            g.sideLaunches++;
+            anySide = true;
+        }
         launch(i, g.aux[a], a + 1);
     }
+    // the bulk launch goes in only after the side launches hold their workgroup slots
+    if (anySide) HIPCHECK(hipStreamWaitValue32(work, g.startSignal, g.sideLaunches, hipStreamWaitValueGte, 0xffffffffu));
     for (size_t i = 0; i < runs.size(); i++)
         if (streamOf[i] < 0) launch(i, work, workTemp);
     for (size_t i = 0; i < runs.size(); i++) {
@@ -1010,6 +1111,9 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
         g.slotBase = 0;
         // the letter-code checks this scan enqueued never reported back: check those batches again
         g.batchChecked.assign(g.batchChecked.size(), false);
+        // a side launch may have been counted but never enqueued: nothing is in flight now, start the count afresh
+        if (g.startSignal) *g.startSignal = 0;
+        g.sideLaunches = 0;
         rs.used = false;
         throw;
     }
@@ -1171,6 +1275,8 @@ std::vector<KernelEvent> SearchDriver::takeKernelEvents() {
 }
 
 size_t SearchDriver::numLocal(int gpu) const { return gpus_.at(size_t(gpu))->numLocal; }
+int SearchDriver::numaNode(int gpu) const { return gpus_.at(size_t(gpu))->numaNode; }
+int SearchDriver::deviceOf(int gpu) const { return gpus_.at(size_t(gpu))->device; }
 uint64_t SearchDriver::localResidues(int gpu) const { return gpus_.at(size_t(gpu))->localResidues; }
 uint64_t SearchDriver::localChars(int gpu) const { return gpus_.at(size_t(gpu))->localChars; }
 bool SearchDriver::isResident(int gpu) const {

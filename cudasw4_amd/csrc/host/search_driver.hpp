@@ -147,6 +147,12 @@ struct KernelEvent {
     int rescore;
 };
 
+// CPUs of a NUMA node (/sys/devices/system/node/nodeN/cpulist; empty: unknown) and binding of the calling thread to them —
+// what a one-process-per-GPU caller (bench.py ranks, `align` on one GPU) does with SearchDriver::numaNode()
+int numa_node_of_device(int device);  // from the PCI function of HIP device `device` (-1: unknown)
+std::vector<int> cpus_of_numa_node(int node);
+bool bind_thread_to_numa_node(int node);
+
 class SearchDriver {
 public:
     SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matrix, KernelTypeConfig kernels, MemoryConfig memory,
@@ -191,6 +197,8 @@ public:
     void recordKernelEvents(int mode);
     std::vector<KernelEvent> takeKernelEvents();      // elapsed times of the launches recorded so far (synchronises)
     size_t numLocal(int gpu) const;                   // subjects of this GPU's shard
+    int numaNode(int gpu) const;                      // NUMA node of the GPU's PCI function (-1: unknown); its worker thread runs there
+    int deviceOf(int gpu) const;                      // HIP device ordinal of the driver's gpu-th GPU
     uint64_t localResidues(int gpu) const;            // true residues of this GPU's shard
     uint64_t localChars(int gpu) const;               // padded subject bytes of this GPU's shard
     bool isResident(int gpu) const;                   // the whole shard's chars are kept in device memory

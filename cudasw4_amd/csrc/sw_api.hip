@@ -116,8 +116,9 @@ struct sw_ctx {
     int8_t* d_matrix = nullptr;  // (dim + 1) x 21: one row per query letter + the padding row, 21 subject letters
     int dim = swk::kLetters;     // what sw_set_matrix was given: query codes are 0..dim-1
     uint32_t* d_zeros = nullptr; // per kind 64 bytes of its zero pattern (first-stripe border): [kind * 16 words]
-    uint32_t* d_work = nullptr;  // kWorkSlots batch counters (dynamic batch distribution), one per launch in flight
+    uint32_t* d_work = nullptr;  // kWorkSlots pairs (batch counter of the dynamic batch distribution, started workgroups), one per launch in flight
     uint32_t work_next = 0;
+    uint32_t* start_signal = nullptr;  // sw_set_start_signal: one-shot, consumed by the next scan / re-score launch
     int grid_mult = 4;           // persistent workgroups per CU (CUDASW4_AMD_GRID_MULT overrides, for experiments)
     bool have_matrix = false;
     int8_t* d_query = nullptr;
@@ -249,6 +250,10 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
                 int32_t* ovf_pos, int32_t* ovf_count, int ovf_check, void* temp, size_t temp_bytes,
                 hipStream_t stream, int32_t* stat_count = nullptr, int32_t stat_limit = 0) {
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    // one-shot: whatever happens to this call, the pending start signal belongs to it (an error or an empty launch
+    // cancels it: nothing will fire, the caller must not wait)
+    uint32_t* const start_signal = ctx->start_signal;
+    ctx->start_signal = nullptr;
     const swk::KindLaunch* kl = kind_launch(kind);
     if (!kl) return fail(SW_ERR_INVALID, "unknown kind");
     if (n < 0 || max_subject_len < 0) return fail(SW_ERR_INVALID, "negative count or length");
@@ -346,8 +351,12 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     }
     // batches are handed out through an atomic counter (longest subjects first): workgroups that start late
     // because another launch still holds the CUs simply take fewer batches
-    p.work_counter = ctx->d_work + (ctx->work_next++ % kWorkSlots);
-    SW_HIP(hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream));
+    p.work_counter = ctx->d_work + 2 * (ctx->work_next++ % kWorkSlots);
+    SW_HIP(hipMemsetAsync(p.work_counter, 0, 2 * sizeof(uint32_t), stream));
+    // start handshake (sw_set_start_signal): the signal fires once `quorum` workgroups are resident — all of a small
+    // launch, the first 64 of a larger one (its remaining workgroups are next in its queue when the waiter is released)
+    p.start_signal = start_signal;
+    p.start_quorum = (uint32_t)std::min(grid, 64);
     SW_HIP(kl->scan(pl.rows, lanes, multi, offs, grid, stream, p));
     return SW_OK;
 }
@@ -387,7 +396,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_CHECK_BOUNDS")) ctx->check_bounds = e[0] == '1';
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_work, kWorkSlots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_work, 2 * kWorkSlots * sizeof(uint32_t));
     if (e == hipSuccess) {
         uint32_t z[64] = {};
         for (int i = 0; i < 16; i++) z[SW_KIND_I16X2 * 16 + i] = swk::Arith<swk::I16X2>::kZero;
@@ -528,6 +537,12 @@ int sw_check_letter_codes(sw_ctx* ctx, const int8_t* chars, size_t n, int32_t* b
     const int grid = (int)std::min<size_t>(want, (size_t)std::max(1, ctx->num_cus) * 16);
     hipLaunchKernelGGL(check_codes_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), chars, n, bad_flag);
     SW_HIP(hipGetLastError());
+    return SW_OK;
+}
+
+int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    ctx->start_signal = signal;
     return SW_OK;
 }
 

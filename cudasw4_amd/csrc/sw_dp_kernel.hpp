@@ -386,6 +386,11 @@ struct ScanParams {
     u32 wrap_last;             // OFFS: encode_gap(-a*((R-1) % P + 1))
     int32_t* stat_count;       // optional (re-score launches): += subjects whose exact score is >= stat_limit, i.e. the
     int32_t stat_limit;        // reference's notion of an overflow (half2_kernels.cuh:1087-1109), for the printed statistic
+    // Start handshake (side launches that must run BESIDE a grid that fills the GPU): every workgroup counts itself in
+    // work_counter[1] when it becomes resident, and the one that completes start_quorum adds 1 to *start_signal (system
+    // scope; signal memory a stream can wait on: hipStreamWaitValue32).  nullptr: no handshake.
+    u32* start_signal;
+    u32 start_quorum;
 };
 
 typedef u32 u32x3 __attribute__((ext_vector_type(3)));
@@ -814,6 +819,11 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     // 8-lane groups: the two groups of a DPP row use the two halves of the row's 16 profile slots (dp_step: laneStep)
     const int slot = LANES == 8 ? (tid & 15) : lane;
     const u32 laneStep = (A::kPacked ? 0x00100010u : 16u) * ((LANES == 8 && (tid & 15) == 8) ? 9u : 1u);
+    if (p.start_signal && tid == 0) {
+        // this workgroup holds its registers and LDS now: whoever the caller ordered behind the signal cannot take them
+        if (atomicAdd(p.work_counter + 1, 1u) + 1u == p.start_quorum)
+            __hip_atomic_fetch_add(p.start_signal, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const int n = p.count_ptr ? *p.count_ptr : p.n;
     constexpr int kSubjPerBatch = kGroups * A::kSubjects;
     const int nbatches = (n + kSubjPerBatch - 1) / kSubjPerBatch;

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcudasw4_host.so")
+# CUDASW4_AMD_HOST_LIB: another build of the same C ABI (tests/host/fake_gpu: the real driver on a two-device fake runtime)
+LIB_PATH = os.environ.get("CUDASW4_AMD_HOST_LIB") or os.path.join(_HERE, "lib", "libcudasw4_host.so")
 MAKEDB = os.path.join(_HERE, "lib", "makedb")
 ALIGN = os.path.join(_HERE, "lib", "align")
 
@@ -19,7 +20,8 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_record_kernel_events", "swdrv_take_kernel_events", "swdrv_shard_info", "swdrv_last_scores",
            "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges", "swdrv_matrix25",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
-           "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency"]
+           "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency", "swdrv_numa_node", "swdrv_device_of",
+           "swdrv_bind_to_numa_node", "swdrv_device_numa_node"]
 
 
 class DriverError(RuntimeError):
@@ -87,6 +89,10 @@ def _load():
     L.swdrv_shard_ranges.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.swdrv_matrix25.argtypes = [ctypes.c_int, vp]
     L.swdrv_last_rescored.argtypes = [vp]
+    L.swdrv_numa_node.argtypes = [vp, ctypes.c_int]
+    L.swdrv_device_of.argtypes = [vp, ctypes.c_int]
+    L.swdrv_bind_to_numa_node.argtypes = [ctypes.c_int]
+    L.swdrv_device_numa_node.argtypes = [ctypes.c_int]
     L.swdrv_encode25.argtypes = [ctypes.c_char_p, vp, sz]
     return L
 
@@ -150,6 +156,16 @@ def read_sequences(path):
     finally:
         lib.swdrv_reader_close(h)
     return headers, seqs
+
+
+def device_numa_node(device):
+    """NUMA node of HIP device `device` (its PCI function's numa_node attribute; -1: unknown)."""
+    return int(lib.swdrv_device_numa_node(int(device)))
+
+
+def bind_to_numa_node(node):
+    """Run the calling thread (and the threads it starts) on the CPUs of `node` that the process may use -> True if bound."""
+    return lib.swdrv_bind_to_numa_node(int(node)) == 0
 
 
 def _check(rc):
@@ -275,6 +291,13 @@ class Driver:
         _check(lib.swdrv_shard_info(self.handle, gpu, ctypes.byref(n), ctypes.byref(r), ctypes.byref(c), ctypes.byref(res)))
         return {"subjects": n.value, "residues": r.value, "chars": c.value, "resident": bool(res.value),
                 "cached_chars": int(lib.swdrv_cached_chars(self.handle, gpu))}
+
+    def numa_node(self, gpu=0):
+        """NUMA node of the GPU's PCI function (-1: unknown)."""
+        return int(lib.swdrv_numa_node(self.handle, gpu))
+
+    def device_of(self, gpu=0):
+        return int(lib.swdrv_device_of(self.handle, gpu))
 
     def streamed_bytes(self):
         """Subject bytes copied host -> device by scans since the driver was created (all GPUs)."""

@@ -17,6 +17,7 @@ import numpy as np
 
 SPROT_SEQUENCES = 570_000      # UniProtKB/Swiss-Prot order of magnitude
 SPROT_MAX_LENGTH = 35_213      # titin
+UNIREF50_SEQUENCES = 60_000_000  # UniRef50 order of magnitude (rununiref50benchmark.sh: 12 GB gzipped FASTA): ~2.3e10 residues here
 
 # amino-acid composition of UniProtKB/Swiss-Prot (release statistics, per cent) in the code order of ConvertAA_20
 # (convert.cuh:32: A R N D C Q E G H I L K M F P S T W Y V)
@@ -232,4 +233,33 @@ def sprot_like(n=SPROT_SEQUENCES, seed=2024, max_len=SPROT_MAX_LENGTH, families=
         fam_pos = np.array(sorted(fam), dtype=np.int64)
     if return_family_ids:
         return chars, offsets, lengths, fam_pos
+    return chars, offsets, lengths
+
+
+def uniref50_like(n=UNIREF50_SEQUENCES, seed=50, max_len=SPROT_MAX_LENGTH, torch_device=None):
+    """A UniRef50-sized stand-in (BASELINE configs 4 and 5: rununiref50benchmark.sh / runtremblbenchmark.sh download 12 /
+    57 GB of FASTA): n sequences with the Swiss-Prot-like length histogram and composition, independent residues (UniRef50
+    is clustered at 50 % identity: close relatives are rare by construction).  ~385 residues per sequence: the default
+    6e7 sequences are 2.3e10 residues, 23 GB of chars.  torch_device: draw the residues on that GPU (numpy needs ~20 s
+    per 10^9 residues on one core) -> (chars, offsets, lengths) as numpy arrays in dbdata layout."""
+    lengths, offsets = _layout(sprot_like_lengths(n, seed, max_len))
+    total = int(offsets[-1])
+    if torch_device is None:
+        chars = _residues(np.random.default_rng(seed + 7), total, SPROT_COMPOSITION)
+    else:
+        import torch
+        p = np.asarray(SPROT_COMPOSITION, dtype=np.float64)
+        edges = np.round(np.cumsum(p / p.sum()) * 65536.0).astype(np.int64)
+        edges[-1] = 65536
+        lut = torch.from_numpy(np.repeat(np.arange(20, dtype=np.int8), np.diff(np.concatenate([[0], edges])))).to(torch_device)
+        gen = torch.Generator(device=torch_device)
+        gen.manual_seed(seed + 7)
+        chars = np.empty(total, dtype=np.int8)
+        step = 1 << 29
+        for b in range(0, total, step):
+            e = min(total, b + step)
+            draw = torch.randint(0, 65536, (e - b,), dtype=torch.int32, device=torch_device, generator=gen)
+            chars[b:e] = lut[draw.long()].cpu().numpy()
+            del draw
+    _pad_with_other(chars, offsets, lengths)
     return chars, offsets, lengths

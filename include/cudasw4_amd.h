@@ -155,6 +155,17 @@ int sw_rescore_overflow_stat(sw_ctx* ctx, int kind,
                              void* temp, size_t temp_bytes,
                              int32_t packed_limit, int32_t* true_overflow_count, void* stream);
 
+/* Start handshake for launches that must run BESIDE a launch that fills the GPU (the reference gets that overlap from
+ * its ten work streams, cudasw4.cuh:293,1745-1748; on this runtime a persistent grid that is dispatched first keeps every
+ * workgroup slot until its end, and a small launch on another stream — the few giant subjects of partition 35 — then
+ * runs BEHIND it instead of beside it, whichever stream was enqueued first).  One-shot: the NEXT sw_scan_partition /
+ * sw_rescore_overflow launch of this context adds 1 to *signal (system scope) as soon as its workgroups are resident
+ * (all of them up to 64; the first 64 of a larger launch).  `signal` must be signal memory
+ * (hipExtMallocWithFlags(..., hipMallocSignalMemory)); the caller orders the big launch behind it with
+ * hipStreamWaitValue32(stream, signal, expected, hipStreamWaitValueGte).  NULL cancels; so does a launch that fails or
+ * has n == 0 (nothing is enqueued, nothing will fire: do not wait for it). */
+int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
+
 /* Per-GPU top-K (cudasw4.cuh:1357-1401): the k best (score desc, id asc on ties) of n results.
  * out_scores/out_ids: DEVICE, k entries, padded with (-1, -1) when n < k.
  * temp: DEVICE scratch of sw_topk_temp_bytes(n, k). */

@@ -114,6 +114,14 @@ int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_le
                          int64_t* cache_begin, int64_t* cache_bytes, int64_t* batch_bytes, int64_t* batches, int cap,
                          int64_t* temp_per_stream);
 
+/* NUMA placement: the node of the gpu-th GPU's PCI function (-1: unknown) and its HIP device ordinal.  In-process
+ * multi-GPU drivers run each GPU's worker thread on that node themselves; a one-process-per-GPU caller binds its own
+ * thread with swdrv_bind_to_numa_node (0: bound; -1: unknown node or none of its CPUs allowed, affinity unchanged). */
+int swdrv_numa_node(swdrv* d, int gpu);
+int swdrv_device_of(swdrv* d, int gpu);
+int swdrv_device_numa_node(int device);   /* the same for a HIP device ordinal, before any driver exists */
+int swdrv_bind_to_numa_node(int node);
+
 /* header / length of a subject by global id (getReferenceHeader / getReferenceLength) */
 int32_t swdrv_reference_length(swdrv* d, int64_t id);
 int swdrv_reference_header(swdrv* d, int64_t id, char* buf, int cap);

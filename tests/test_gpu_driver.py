@@ -167,6 +167,44 @@ def test_align_cli_tsv_and_plain(tmp_path):
     assert "Result 1. Score: %d. Length: 128. Header H. referenceId 1" % exp[19] in p.stdout
 
 
+def test_align_ref_compat_switch(tmp_path):
+    """`align --refCompat`: the reference binary parses --gop / --gex and the per-matrix default gap
+    scores but always runs -11 / -1 (options.cpp:179-194 never reach the kernels, cudasw4.cuh:539-550), so for --mat
+    blosum45|50|80 this build's default output (per-matrix gaps applied) differs from the reference's.  With the switch
+    the output is the reference's: equal to the oracle at -11 / -1 on the selected matrix, whatever gap options are
+    given; without it the per-matrix defaults apply (and give other scores)."""
+    from cudasw4_amd import driver
+    headers, seqs = O.read_fasta(FASTA)
+    queries = [O.encode(q) for q in seqs]
+    chars, offsets, lengths = O.make_db(queries)
+
+    def run(extra):
+        of = str(tmp_path / "o.tsv")
+        p = subprocess.run([driver.ALIGN, "--query", FASTA, "--db", GOLDEN_DB, "--top", "20", "--tsv", "--of", of] + extra,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        rows = [l.split("\t") for l in open(of).read().splitlines()[1:]]
+        sc = np.zeros((20, 20), dtype=np.int64)
+        for r in rows:
+            sc[int(r[0]), int(r[7])] = int(r[4])
+        return sc, p.stdout
+
+    for mat in (45, 80):
+        want = np.array([O.scan(q, chars, offsets, lengths, m21=O.blosum21(mat), gop=-11, gex=-1, simd=True) for q in queries])
+        compat, out = run(["--mat", "blosum%d" % mat, "--refCompat"])
+        assert (compat == want).all() and "refCompat: gap scores applied are -11 / -1" in out
+        compat2, _ = run(["--mat", "blosum%d" % mat, "--refCompat", "--gop", "-5", "--gex", "-3"])
+        assert (compat2 == want).all()
+        native, out = run(["--mat", "blosum%d" % mat])
+        assert "refCompat" not in out and (native != want).any()
+    # the environment switch does the same
+    env = dict(os.environ, CUDASW4_AMD_REF_COMPAT="1")
+    of = str(tmp_path / "e.tsv")
+    p = subprocess.run([driver.ALIGN, "--query", FASTA, "--db", GOLDEN_DB, "--top", "1", "--tsv", "--of", of, "--mat", "blosum50"],
+                       capture_output=True, text=True, env=env)
+    assert p.returncode == 0 and "refCompat: gap scores applied are -11 / -1" in p.stdout
+
+
 def test_align_cli_hybrid_residency_and_pipelined_queries(monkeypatch):
     """`align --maxGpuMem` below the DB size: the verbose output says how much of the shard stays cached in device memory
     (the reference prints "N out of M DB batches will be cached in gpu memory", cudasw4.cuh:1044-1046), the results are

@@ -153,7 +153,7 @@ def test_cli_surface_without_gpu():
     for flag in ("--query", "--db", "--top", "--gop", "--gex", "--mat", "--maxGpuMem", "--maxTempBytes", "--maxBatchBytes",
                  "--maxBatchSequences", "--dpx", "--of", "--tsv", "--verbose", "--printLengthPartitions", "--interactive",
                  "--prefetchDBFile", "--uploadFull", "--pseudodb", "--singlePassType", "--manyPassType_small",
-                 "--manyPassType_large", "--overflowType"):
+                 "--manyPassType_large", "--overflowType", "--refCompat"):
         assert flag in out.stdout, flag
     out = subprocess.run([ALIGN, "--db", "x"], capture_output=True, text=True)
     assert "Query is missing" in out.stdout and out.returncode == 0
