@@ -64,6 +64,14 @@ QueryPlan plan_query(int kind, int32_t qlen, int lanes) {
     const int maxrows = swk::max_rows(kind, lanes);
     // fp32 multi-stripe kernels above 32 rows per lane lose the third wave per SIMD (their single-stripe kernels keep it up to 36)
     const int maxrows_multi = (kind == SW_KIND_F32 && lanes <= 16) ? std::min(maxrows, swk::kMaxRowsScalarMulti) : maxrows;
+    // packed kinds: a multi-stripe kernel above kWaves3MaxRowsPackedMulti rows per lane holds two waves per SIMD, which
+    // fill 93.5 % of the issue slots at best (three: 97+ %).  Measured on the peak DB, the same queries with 32-row stripes
+    // at three waves against 40..47-row stripes at two (tools/variant_bench2.sh): a step-row of the tall kernels costs
+    // 5 % more (fitted together with the per-step overhead below on ten queries of 1500..5478 residues).  CUDASW4_AMD_TWO_WAVE_PENALTY overrides the factor (1: the planner of rounds 1-3; tests use it to reach
+    // every compiled shape).
+    double two_wave_penalty = 1.05;
+    if (const char* e = getenv("CUDASW4_AMD_TWO_WAVE_PENALTY")) two_wave_penalty = std::max(1.0, atof(e));
+    const bool has_three_wave_multi = kl->packed && lanes <= 16 && swk::kWaves3MaxRowsPackedMulti > maxrows / 2;
     double best = 1e300;
     auto consider = [&](int ns) {
         const int64_t per_lane = (qlen + (int64_t)lanes * ns - 1) / ((int64_t)lanes * ns);
@@ -71,14 +79,21 @@ QueryPlan plan_query(int kind, int32_t qlen, int lanes) {
         r = std::max(r, swk::kRowsGranule);
         if (r > (ns > 1 ? maxrows_multi : maxrows)) return;
         if (ns > 1 && 2 * r <= maxrows) return;  // multi-stripe kernels exist for R > max/2 only
-        // per-step overhead in row equivalents: ~10 VALU ops single-stripe, ~20 with the stripe border
-        const double cost = ns * (r + (ns > 1 ? 2.5 : 1.2));
+        // per-step overhead in row equivalents: ~10 VALU ops single-stripe; with several stripes ~20 with the stripe border,
+        // plus the tile load and the two barriers of every stripe switch spread over the stripe's steps
+        double cost = ns * (r + (ns > 1 ? 3.0 : 1.2));
+        if (has_three_wave_multi && ns > 1 && r > swk::kWaves3MaxRowsPackedMulti) cost *= two_wave_penalty;
         if (cost < best - 1e-9) { best = cost; pl.rows = r; pl.nstripes = ns; }
     };
     if (qlen <= (int64_t)lanes * maxrows) consider(1);
     const int64_t stripe_multi = (int64_t)lanes * maxrows_multi;
     const int ns_m = std::max<int>(2, (int)((qlen + stripe_multi - 1) / stripe_multi));
-    for (int ns = ns_m; ns <= ns_m + 2; ns++) consider(ns);
+    int ns_hi = ns_m + 2;
+    if (has_three_wave_multi) {  // ... and the plans on three-wave stripes
+        const int64_t stripe3 = (int64_t)lanes * swk::kWaves3MaxRowsPackedMulti;
+        ns_hi = std::max<int>(ns_hi, (int)((qlen + stripe3 - 1) / stripe3) + 1);
+    }
+    for (int ns = ns_m; ns <= ns_hi; ns++) consider(ns);
     return pl;
 }
 
@@ -287,6 +302,10 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // one frame plus the pipeline skew must fit the room
     int64_t K = 1 << 21;
     while (K >= 4 * lanes && (int64_t)a * (K + 3 * lanes + 16) > room) K >>= 1;
+    // int16: the room would allow a period of 8192 columns, but the flag bound grows with the period (score + a * min(columns,
+    // K) + ...): with 8192 a 4000-residue protein was re-scored from 21 000 up instead of 25 000.  2048 columns cost 0.3 % in
+    // lowering steps (16 of every 2048 run the second loop body) and keep the early flags within 8 % of the limit.
+    if (kind == SW_KIND_I16X2) K = std::min<int64_t>(K, std::max<int64_t>(2048, 4 * lanes));
     if (!kind_packed(kind) && max_subject_len + 3 * lanes + 16 > K) K = 0;  // the 32-bit kernels do not lower their frame
     const bool offs = ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
     int rc = ensure_profile(ctx, kind, lanes, offs, offs ? a : 0, stream);

@@ -434,6 +434,21 @@ __device__ __forceinline__ void lds_read_words(u32 (&dst)[NW], const unsigned ch
 #ifndef SWK_WAVES3_MAX_R
 #define SWK_WAVES3_MAX_R 36
 #endif
+#ifndef SWK_WAVES3_MAX_R_MULTI
+// Packed MULTI-stripe kernels up to this many rows per lane are bound to 168 VGPRs as well (round 4).  With the stripe
+// border in LDS rings (Border<LANES>) their loops run without a single scratch access at that bound (tools/loop_spills.py;
+// what the code object reports as spills is set-up code), the 43 KB tile plus 8 KB of rings still fits three workgroups
+// per CU, and the third wave is worth +6 % at the same stripe height (850 / 1000-residue queries: 10.8 / 11.0 -> 11.5 /
+// 11.6 TCUPS) — enough for the planner to prefer 32-row stripes over 40..48-row ones for most long queries
+// (sw_api.hip: plan_query; peak benchmark 11.53 -> 11.67 TCUPS).  0: none.
+#define SWK_WAVES3_MAX_R_MULTI 32
+#endif
+#ifndef SWK_MULTI_SCALAR_LOOP
+// multi-stripe kernels: the quad counters in scalar registers too (wave-uniform by construction).  Rounds 1-3 kept them in
+// vector registers (the scalar form measured 1 % slower then); with the block loop of the LDS border rings the scalar
+// form is the faster one (11.39 -> 11.44 TCUPS) and frees registers
+#define SWK_MULTI_SCALAR_LOOP 1
+#endif
 #ifndef SWK_WAVES4_MAX_R
 #define SWK_WAVES4_MAX_R 22   // ... and up to this many to 128 VGPRs = four waves per SIMD (+1 % at R = 17..22, -0.4 % at 24)
 #endif
@@ -451,7 +466,7 @@ constexpr int frame_classes(bool packed, int R, int lanes, bool multi) {
     // packed kinds: 8 classes for the tall kernels (two waves per SIMD anyway: 0.125 instead of 0.25 wrap subtractions per
     // cell pair for 8 more registers, +0.8 % on the peak benchmark); the single-stripe kernels up to R = SWK_WAVES3_MAX_R and
     // everything below R = 25 four, which keeps those at three (or more) waves per SIMD.  32-bit kinds: four (register-bound by their occupancy).
-    const int want = packed ? ((R > SWK_WAVES3_MAX_R || (multi && R >= 25)) ? SWK_CLASSES_PACKED : SWK_CLASSES_PACKED_SMALL)
+    const int want = packed ? ((R > SWK_WAVES3_MAX_R || (multi && R >= 25 && R > SWK_WAVES3_MAX_R_MULTI)) ? SWK_CLASSES_PACKED : SWK_CLASSES_PACKED_SMALL)
                             : SWK_CLASSES_SCALAR;
     int P = want;
     while (P > 1 && 2 * P > R) P--;  // at least two rows per class, so that the running maximum still folds two rows per max3
@@ -564,14 +579,16 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
         // above) (sw_build_profile_kernel), which makes row 0 consistent.
         constexpr int kLastClass = (R - 1) % P;
         constexpr int Q = A::kWindow ? BYTE : 0;  // step within the quad == which letter byte feeds lane 0
-        const u32 bH = st.Zc[Q + kLastClass];  // the local-alignment boundary H = 0 as row 0's diagonal expects it
         u32 upH, F;
         if constexpr (MULTI) {
-            upH = prev_lane<LANES, false>(first ? bH : inH, st.Hlast, head);
-            // no select for F: in the first stripe lane 0 reads the zeros array (the kind's unraised zero pattern),
-            // which lies below every zero level — "no vertical gap" as well as any other value down there
+            // the stripe above's bottom row at this column; in the first stripe the IN ring holds the column's zero level as
+            // H (the local-alignment boundary row 0's diagonal expects: first_stripe_pair) and the kind's unraised zero
+            // pattern as F, which lies below every zero level — "no vertical gap" as well as any other value down there
+            (void)first;
+            upH = prev_lane<LANES, false>(inH, st.Hlast, head);
             F = prev_lane<LANES, false>(inF, st.Fout, head);
         } else {
+            const u32 bH = st.Zc[Q + kLastClass];  // the local-alignment boundary H = 0 as row 0's diagonal expects it
             upH = prev_lane<LANES, false>(bH, st.Hlast, head);
             // any F below the column's zero level is "no vertical gap": bound_ctrl zero fill (pattern 0 is below every
             // zero level of every kind, and the fp16 comparator of the int16 kind orders +0.0 below all its patterns)
@@ -757,15 +774,40 @@ __device__ __forceinline__ u32 group_max(u32 v) {
 // subjects per batch; LANES = 64: 4 groups), longest subjects first.  MULTI == the query needs more than
 // one stripe.
 // ------------------------------------------------------------------------------------------------
-// Stripe-border scratch of one group: [kJunk junk words][H/F interleaved: column j at words 2j (H) and 2j+1 (F)].
-// The last lane stores the four columns of a quad as ONE aligned 32-byte run (a full sector: no partial-line
-// write-backs); its quad q covers columns 4q-(LANES-1).., so the array starts 2*(LANES-1) words == 6 (mod 8) past a
-// 32-byte boundary.  The junk area holds the last lane's columns < 0 (2*(LANES-1) words right below the array) and
-// one 8-word slot per other lane (their stores are never read).
+// Stripe border of multi-stripe queries (the analogue of the reference's devTempHcol2 / devTempEcol2,
+// half2_kernels.cuh:335-338).  The bottom row of a stripe — one (H, F) pair = 8 bytes per subject column — goes from the
+// group's LAST lane to lane 0 of the same group one stripe later.  Round 4: through LDS rings and block transfers.
+//   * the last lane stores its pair into the group's OUT ring in LDS every step (one ds_write_b64; the other lanes hit a
+//     private dummy slot), lane 0 takes the previous stripe's pair from the group's IN ring (one ds_read_b64; the other
+//     lanes read along and ignore the value): no global access, no staging registers and no register copies in the step;
+//   * every kBlockCols = 2 * LANES steps the group moves one BLOCK: each lane copies 16 bytes of the OUT ring to the
+//     global scratch (a fully coalesced 16 * LANES-byte burst: whole lines, written once) and 16 bytes of the block after
+//     next from the scratch into a register, which it drops into the IN ring one block later.
+// (Rounds 1-3: every lane issued 2 x 16-byte loads and stores per four steps, only lane 0's / the last lane's addresses
+// walked the real array, the rest hit junk slots and the zeros array: 16 staging registers, ~3 register copies per step,
+// and write-backs of junk lines.)  The scratch is indexed by the PRODUCER's step ("position"): the last lane emits column
+// c at position c + LANES - 1, so the consumer's block b starts 8 * (LANES - 1) bytes into producer block b.
+#ifndef SWK_BORDER_PEND
+#define SWK_BORDER_PEND 1   // 1: the block after next is loaded one block ahead into 4 registers; 0: loaded where it is needed (exposed latency once per block)
+#endif
 template <int LANES>
-constexpr int border_junk_words() { return LANES == 8 ? 70 : LANES == 16 ? 166 : 646; }  // >= 10*(LANES-1), == 6 (mod 8)
+struct Border {
+    static constexpr int kBlockCols = 2 * LANES;                 // positions per block: 16 bytes per lane
+    static constexpr int kQuadsPerBlock = LANES / 2;
+    static constexpr int kBlockBytes = 8 * kBlockCols;
+    static constexpr int kBlockWords = 2 * kBlockCols;
+    // LDS per group: IN ring and OUT ring, one block each; per workgroup one set of dummy slots (the groups of a wave are
+    // served in separate LDS passes, so sharing them costs no conflicts; what they hold is never read)
+    static constexpr int kInBytes = kBlockBytes, kOutBytes = kBlockBytes, kDummyBytes = 8 * LANES + 32;
+    static constexpr int kGroupBytes = kInBytes + kOutBytes;
+    static constexpr int ring_bytes(int groups) { return groups * kGroupBytes + kDummyBytes; }
+    static_assert(kGroupBytes % 16 == 0, "rings are read and written 16 bytes at a time");
+    // blocks of the global array for subjects of up to `steps` steps: the partial last block, the tail block behind it,
+    // and one more that the consumer's look-ahead reads
+    static constexpr int blocks(int steps) { return (steps + kBlockCols - 1) / kBlockCols + 3; }
+};
 template <int LANES>
-constexpr int border_region_words(int lcap) { return (border_junk_words<LANES>() + 2 * lcap + 15) / 16 * 16; }  // per group, 64-byte granular
+constexpr int border_region_words(int lcap) { return Border<LANES>::blocks(lcap) * Border<LANES>::kBlockWords; }  // per group
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument).
 // Packed kinds: 1 (unconstrained) is best — forcing 3-4 waves spills the multi-stripe kernels (-3..4 %).
@@ -790,6 +832,7 @@ template <int KIND, int R, int LANES, bool MULTI>
 constexpr int min_waves() {
     // packed kinds: 2 waves/SIMD (256 VGPRs) for the tall kernels; up to SWK_WAVES3_MAX_R rows a third wave is asked for
     // (168 VGPRs): two waves cover each other's wait states only ~92 % of the time, three reach the issue peak
+    if (Arith<KIND>::kPacked && LANES <= 16 && MULTI && R <= SWK_WAVES3_MAX_R_MULTI) return 3;
     if (Arith<KIND>::kPacked) return (LANES <= 16 && !MULTI && R <= SWK_WAVES4_MAX_R) ? 4 : (LANES <= 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
     // int32 above 32 rows per lane: two waves per SIMD (the registers of the taller stripes; its add/max3 mix cannot
@@ -806,11 +849,12 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     using A = Arith<KIND>;
     using G = Geometry<KIND, R, LANES>;
     constexpr int kGroups = kThreads / LANES;
-    constexpr int kJunk = border_junk_words<LANES>();
+    using BD = Border<LANES>;
     constexpr int SHL1 = Shift<LANES>::kShl1;
     constexpr int kQuadsPerLetterBlock = LANES;  // a lane holds 4 letters: LANES quads per reload
     constexpr int P = OFFS ? frame_classes(A::kPacked, R, LANES, MULTI) : 1;  // row classes of the column-offset frame
     __shared__ __attribute__((aligned(16))) unsigned char lds[16 + G::kTileBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char rings[MULTI ? BD::ring_bytes(kGroups) : 16];
 
     const int tid = threadIdx.x;
     const int lane = tid & (LANES - 1);  // position in the alignment group
@@ -834,10 +878,10 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         __syncthreads();
     }
 
-    // Stripe-border spill of this group (layout: border_junk_words).  The loop is kept branch-free: EVERY lane loads
-    // and stores each quad, but only lane 0's load address and the last lane's store address walk the real array;
-    // the other lanes read the zeros array and write their junk slot.
-    u32* const borderHF = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroups + group) * (size_t)border_region_words<LANES>(p.lcap) + kJunk : nullptr;
+    // Stripe border of this group (Border<LANES>): its rings in LDS and its block array in the global scratch
+    unsigned char* const ringIn = rings + (MULTI ? group * BD::kGroupBytes : 0);
+    unsigned char* const ringOut = ringIn + BD::kInBytes;
+    u32* const gBorder = MULTI ? p.scratch + ((size_t)blockIdx.x * kGroups + group) * (size_t)border_region_words<LANES>(p.lcap) : nullptr;
 
     // OFFS: a lane starts every stripe "at column -lane": zero level a*(LANES - lane), +a per step
     const u32 apos = OFFS ? A::pos_word(p.gex_mag) : 0u;
@@ -890,7 +934,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         // letter-reload test and the frame-lowering segments into scalar control flow (the counter otherwise lives in a
         // VGPR, with a compare, an exec update and a masked branch per quad).  Single-stripe kernels: +0.5 %; the
         // multi-stripe kernels schedule worse with it (4 instructions fewer per quad, yet -1 %), so they keep the vector loop
-        if constexpr (!MULTI) nquads = __builtin_amdgcn_readfirstlane(nquads);
+        if constexpr (!MULTI || SWK_MULTI_SCALAR_LOOP) nquads = __builtin_amdgcn_readfirstlane(nquads);
         const int len0pad = (len0 + 3) & ~3, len1pad = (len1 + 3) & ~3;
 
         u32 maxv = OFFS ? 0u : A::kZero;  // OFFS tracks true scores (unbiased), the plain form the kind's own zero
@@ -933,18 +977,74 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             u32 nextB = A::kPacked ? fetch(s1, len1pad, 0) : 0u;
             u32 lettersA = 0, lettersB = 0;
 
-            // stripe border (MULTI only): lane 0 reads the previous stripe's bottom row four columns per quad, one quad
-            // ahead (2 x 16-byte loads of interleaved H/F); the last lane stores its own bottom row once per quad.
-            uint4 curH = make_uint4(A::kZero, A::kZero, A::kZero, A::kZero), curF = curH, bordA = curH, bordB = curH;
-            const int walkIn = (lane == 0 && !first) ? 8 : 0;  // words per quad the load address advances
-            const int walkOut = (lane == LANES - 1) ? 8 : 0;
-            const u32* inHF = (lane == 0 && !first) ? borderHF : p.zeros;
-            u32* outHF = (lane == LANES - 1) ? borderHF - 2 * (LANES - 1) : borderHF - kJunk + 8 * lane;
+            // Stripe border (MULTI only; Border<LANES>).  Lane 0 walks the IN ring, the last lane the OUT ring; the other
+            // lanes read the ring's first pair over and over and write into their dummy slots.
+            const bool last = stripe + 1 == p.nstripes;
+            const unsigned char* inPtr = ringIn;
+            unsigned char* outPtr = (lane == LANES - 1) ? ringOut : rings + kGroups * BD::kGroupBytes + 8 * lane;
+            const u32 walkIn = (lane == 0) ? 32u : 0u;   // bytes per quad
+            const u32 walkOut = (lane == LANES - 1) ? 32u : 0u;
+            uint4 pend = make_uint4(A::kZero, A::kZero, A::kZero, A::kZero);   // this lane's 16 bytes of the block after the current one
+            uint2 nxt = make_uint2(A::kZero, A::kZero);                          // the pair of the step to come
+            // consumer block b = positions b * kBlockCols + (LANES - 1) ...: 8 * (LANES - 1) bytes into producer block b
+            const u32* const gIn = MULTI ? gBorder + 2 * (LANES - 1) + 4 * lane : nullptr;
+            // What lane 0 takes in the FIRST stripe, where no stripe lies above: columns j, j + 1 -> (H, F, H, F) with H the
+            // local-alignment boundary in the column's frame — zero level a * (j mod K + LANES) raised to the class of the lane's
+            // last row, the frame row 0's diagonal term expects (OFFS; plain form: the kind's zero) — and F "no vertical gap"
+            auto first_stripe_pairs = [&](int j) -> uint4 {
+                if constexpr (OFFS) {
+                    constexpr int kLastClass = (R - 1) % P;
+                    const int K = 4 * rq;   // frame period (0: the frame is never lowered)
+                    const int j0 = K > 0 ? (j & (K - 1)) : j, j1 = K > 0 ? ((j + 1) & (K - 1)) : j + 1;
+                    return make_uint4(A::zero_at(p.gex_mag, j0 + LANES + kLastClass), A::kZero, A::zero_at(p.gex_mag, j1 + LANES + kLastClass), A::kZero);
+                } else {
+                    return make_uint4(A::kZero, A::kZero, A::kZero, A::kZero);
+                }
+            };
             if constexpr (MULTI) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                bordA = *reinterpret_cast<const uint4*>(inHF);
-                bordB = *reinterpret_cast<const uint4*>(inHF + 4);
+                if (!first) {
+                    const uint4 b0 = *reinterpret_cast<const uint4*>(gIn);
+#if SWK_BORDER_PEND
+                    pend = *reinterpret_cast<const uint4*>(gIn + BD::kBlockWords);
+#endif
+                    *reinterpret_cast<uint4*>(ringIn + 16 * lane) = b0;
+                } else {
+                    *reinterpret_cast<uint4*>(ringIn + 16 * lane) = first_stripe_pairs(2 * lane);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                nxt = *reinterpret_cast<const uint2*>(inPtr);
             }
+            // end of block `blk` (all of its steps are done): the OUT ring's first block goes to the scratch, the IN ring
+            // takes the next block, the load of the one after that is issued
+            auto block_end = [&](int blk) {
+                // every address is rebuilt here from the thread index (kept opaque, so that the compiler does not hoist a
+                // dozen loop-invariant address registers into a loop that runs at the register limit)
+                int t = tid;
+                asm volatile("" : "+v"(t));
+                const int ln = t & (LANES - 1), grp = t / LANES;
+                unsigned char* const rIn = rings + grp * BD::kGroupBytes + 16 * ln;
+                u32* const gb = p.scratch + ((size_t)blockIdx.x * kGroups + grp) * (size_t)border_region_words<LANES>(p.lcap) + 4 * ln;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (!last) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(rIn + BD::kInBytes);
+                    *reinterpret_cast<uint4*>(gb + (size_t)blk * BD::kBlockWords) = v;
+                }
+                outPtr -= walkOut * BD::kQuadsPerBlock;
+                inPtr -= walkIn * BD::kQuadsPerBlock;
+                if (first) {
+                    *reinterpret_cast<uint4*>(rIn) = first_stripe_pairs((blk + 1) * BD::kBlockCols + 2 * ln);
+                } else {
+#if SWK_BORDER_PEND
+                    *reinterpret_cast<uint4*>(rIn) = pend;
+                    pend = *reinterpret_cast<const uint4*>(gb + 2 * (LANES - 1) + (size_t)(blk + 2) * BD::kBlockWords);
+#else
+                    *reinterpret_cast<uint4*>(rIn) = *reinterpret_cast<const uint4*>(gb + 2 * (LANES - 1) + (size_t)(blk + 1) * BD::kBlockWords);
+#endif
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                nxt = *reinterpret_cast<const uint2*>(inPtr);   // what the last step prefetched was the old block's
+            };
 
             auto quad = [&](int q, auto lower_tag) {
                 constexpr bool LOWER = decltype(lower_tag)::value;
@@ -952,14 +1052,6 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     lettersA = nextA; lettersB = nextB;
                     nextA = fetch(s0, len0pad, q / kQuadsPerLetterBlock + 1);
                     if constexpr (A::kPacked) nextB = fetch(s1, len1pad, q / kQuadsPerLetterBlock + 1);
-                }
-                u32 bh0 = 0, bf0 = 0, bh1 = 0, bf1 = 0, bh2 = 0, bf2 = 0;
-                if constexpr (MULTI) {
-                    curH = make_uint4(bordA.x, bordA.z, bordB.x, bordB.z);
-                    curF = make_uint4(bordA.y, bordA.w, bordB.y, bordB.w);
-                    inHF += walkIn;  // prefetch the next quad (the array has slack past the last one)
-                    bordA = *reinterpret_cast<const uint4*>(inHF);
-                    bordB = *reinterpret_cast<const uint4*>(inHF + 4);
                 }
                 // OFFS on long subjects: the frame of column j is a*(j mod K + LANES), i.e. a lane lowers everything it
                 // holds by a*K right before it enters a column that is a multiple of K (lane l at step m*K + l).  The
@@ -977,18 +1069,32 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 #pragma unroll
                     for (int d = 0; d < P + 3; d++) st.maxv[d] = A::gap(st.maxv[d], gw);
                 };
+                // one step: lane 0's pair of the stripe above from the IN ring, the last lane's own pair into the OUT ring.
+                // The pair is requested ONE STEP AHEAD (nxt): the chain of a step starts with it (row 0's diagonal and F),
+                // and an LDS read issued at the top of the step would be waited for right there.
+                auto border_step = [&](auto byte_tag) {
+                    constexpr int BYTE = decltype(byte_tag)::value;
+                    const uint2 in = nxt;
+                    if constexpr (MULTI) {
+                        if constexpr (BYTE == 3) {
+                            inPtr += walkIn;
+                            nxt = *reinterpret_cast<const uint2*>(inPtr);   // first pair of the next quad (re-read after a block transfer)
+                        } else {
+                            nxt = *reinterpret_cast<const uint2*>(inPtr + 8 * (BYTE + 1));
+                        }
+                    }
+                    dp_step<KIND, R, LANES, BYTE, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, in.x, in.y, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
+                    if constexpr (MULTI) *reinterpret_cast<uint2*>(outPtr + 8 * BYTE) = make_uint2(st.Hlast, st.Fout);
+                };
                 if constexpr (LOWER) lower_frame(lower_lane + 0);
-                dp_step<KIND, R, LANES, 0, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.x, curF.x, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
-                if constexpr (MULTI) { bh0 = st.Hlast; bf0 = st.Fout; }
+                border_step(std::integral_constant<int, 0>{});
                 if constexpr (LOWER) lower_frame(lower_lane + 1);
-                dp_step<KIND, R, LANES, 1, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.y, curF.y, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
-                if constexpr (MULTI) { bh1 = st.Hlast; bf1 = st.Fout; *reinterpret_cast<uint4*>(outHF) = make_uint4(bh0, bf0, bh1, bf1); }
+                border_step(std::integral_constant<int, 1>{});
                 if constexpr (LOWER) lower_frame(lower_lane + 2);
-                dp_step<KIND, R, LANES, 2, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.z, curF.z, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
-                if constexpr (MULTI) { bh2 = st.Hlast; bf2 = st.Fout; }
+                border_step(std::integral_constant<int, 2>{});
                 if constexpr (LOWER) lower_frame(lower_lane + 3);
-                dp_step<KIND, R, LANES, 3, MULTI, OFFS, P>(st, lds, lettersA, lettersB, p.gop, p.gex, curH.w, curF.w, apos, first, p.wrap_class, p.wrap_last, head, laneStep);
-                if constexpr (MULTI) { *reinterpret_cast<uint4*>(outHF + 4) = make_uint4(bh2, bf2, st.Hlast, st.Fout); outHF += walkOut; }
+                border_step(std::integral_constant<int, 3>{});
+                if constexpr (MULTI) outPtr += walkOut;
                 lettersA = dpp<SHL1, true>(0u, lettersA);
                 if constexpr (A::kPacked) lettersB = dpp<SHL1, true>(0u, lettersB);
                 if constexpr (OFFS && A::kWindow) {  // the windows move on by four columns
@@ -1000,7 +1106,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             };
             // the quads in which lanes lower their frame (the first LANES/4 of every K/4 quads but the first) run a second
             // copy of the loop body, so that the others pay nothing for it
-            {
+            if constexpr (!MULTI) {
                 const int seg = (kLowers && rq > 0) ? rq : nquads;
                 for (int q0 = 0; q0 < nquads; q0 += seg) {
                     const int qend = min(nquads, q0 + seg);
@@ -1013,11 +1119,38 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     }
                     for (; q < qend; q++) quad(q, std::false_type{});
                 }
+            } else {
+                // multi-stripe: block by block (Border<LANES>: kQuadsPerBlock quads, then the block transfer); the lowering
+                // period K/4 is a multiple of the block and the LANES/4 lowering quads fit in one
+                static_assert(BD::kQuadsPerBlock >= LANES / 4, "the lowering quads of a period must lie in one block");
+                for (int q0 = 0; q0 < nquads; q0 += BD::kQuadsPerBlock) {
+                    const int qend = min(nquads, q0 + BD::kQuadsPerBlock);
+                    int q = q0;
+                    if constexpr (kLowers) {
+                        if (rq > 0 && q0 > 0 && (q0 & (rq - 1)) == 0) {
+                            const int qlow = min(qend, q0 + LANES / 4);
+                            for (; q < qlow; q++) quad(q, std::true_type{});
+                        }
+                    }
+                    for (; q < qend; q++) quad(q, std::false_type{});
+                    if (qend == q0 + BD::kQuadsPerBlock) block_end(q0 / BD::kQuadsPerBlock);
+                }
             }
             if constexpr (MULTI) {
-                // the last lane reached column 4*nquads-LANES; the next stripe reads up to 4*nquads-1: zero the rest
-                if (lane < LANES - 1)
-                    *reinterpret_cast<uint2*>(borderHF + 2 * (4 * nquads - (LANES - 1) + lane)) = make_uint2(A::kZero, A::kZero);
+                // The last lane has emitted positions 0 .. 4*nquads - 1; the next stripe's lane 0 reads positions up to
+                // 4*nquads + LANES - 2 (its columns up to 4*nquads - 1): LANES pairs of "no value" (the kind's unraised zero
+                // pattern) go behind the last emitted one — into the OUT ring where they fall into the partial block, straight
+                // to the scratch where they fall into the block behind it — and the partial block leaves the OUT ring.
+                if (!last) {
+                    const int done = nquads & ~(BD::kQuadsPerBlock - 1);           // quads in complete (flushed) blocks
+                    const int slot = 4 * (nquads - done) + lane;                     // this lane's "no value" pair: position 4 * done + slot
+                    u32* const g = gBorder + (size_t)(done / BD::kQuadsPerBlock) * BD::kBlockWords;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (slot < BD::kBlockCols) *reinterpret_cast<uint2*>(ringOut + 8 * slot) = make_uint2(A::kZero, A::kZero);
+                    else *reinterpret_cast<uint2*>(g + 2 * slot) = make_uint2(A::kZero, A::kZero);   // in the block behind: the flush below does not touch it
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    *reinterpret_cast<uint4*>(g + 4 * lane) = *reinterpret_cast<const uint4*>(ringOut + 16 * lane);
+                }
             }
             if constexpr (OFFS) {
                 if constexpr (A::kWindow) {

@@ -26,7 +26,9 @@ constexpr int kMaxRowsScalarMulti = SWK_MAX_ROWS_SCALAR_MULTI;
 #ifndef SWK_MAX_ROWS_I32
 #define SWK_MAX_ROWS_I32 48
 #endif
-constexpr int kMaxRowsI32 = SWK_MAX_ROWS_I32;  // int32 cannot co-issue, so like the packed kinds it trades the third wave for taller stripes (fewer stripes, less per-step overhead)
+constexpr int kMaxRowsI32 = SWK_MAX_ROWS_I32;
+// packed multi-stripe kernels up to this height keep three waves per SIMD (sw_dp_kernel.hpp: SWK_WAVES3_MAX_R_MULTI)
+constexpr int kWaves3MaxRowsPackedMulti = SWK_WAVES3_MAX_R_MULTI;  // int32 cannot co-issue, so like the packed kinds it trades the third wave for taller stripes (fewer stripes, less per-step overhead)
 // long-subject shape (64-lane groups)
 constexpr int kMaxRowsPackedLong = 16;  // stripe = 1024 query rows, 43 KB tile
 constexpr int kMaxRowsScalarLong = 8;   // stripe = 512 query rows, 43 KB tile

@@ -41,7 +41,7 @@ def test_version_and_plan_without_gpu(built):
         for q in (1, 63, 64, 65, 144, 512, 513, 5478, 40000):
             r, s = capi.plan_query(kind, q)
             assert 1 <= r <= 48 and 16 * r * s >= q > 16 * r * s - 16 * s   # padding below one row per lane and stripe
-            assert (q + 767) // 768 <= s <= (q + 767) // 768 + 2
+            assert (q + 767) // 768 <= s <= max((q + 767) // 768 + 2, (q + 511) // 512 + 1)
     for kind, rmax in ((capi.KIND_I32, 48), (capi.KIND_F32, 36)):
         for q in (1, 256, 257, 567, 5478):
             r, s = capi.plan_query(kind, q)
@@ -49,6 +49,27 @@ def test_version_and_plan_without_gpu(built):
     assert capi.plan_query(capi.KIND_I32, 657)[1] == 1 and capi.plan_query(capi.KIND_F32, 657)[1] == 2
     with pytest.raises(capi.SwError):
         capi.plan_query(7, 100)
+
+
+def test_planner_prefers_three_wave_stripes(built, monkeypatch):
+    """Packed multi-stripe kernels up to 32 rows per lane keep three waves per SIMD (sw_dp_kernel.hpp:
+    SWK_WAVES3_MAX_R_MULTI), and a step-row of the taller two-wave kernels is priced 4.5 % higher: the planner takes
+    32-row stripes unless the taller plan saves more than that in padding and per-step overhead (measured per query on the
+    peak DB, profiles/r04_results.md).  CUDASW4_AMD_TWO_WAVE_PENALTY=1 is the planner of rounds 1-3."""
+    from cudasw4_amd import capi
+    monkeypatch.delenv("CUDASW4_AMD_TWO_WAVE_PENALTY", raising=False)
+    want = {850: (27, 2), 1000: (32, 2), 1500: (47, 2), 2005: (32, 4), 2504: (32, 5), 3005: (47, 4), 3564: (32, 7),
+            4061: (32, 8), 4548: (32, 9), 4743: (30, 10), 5147: (27, 12), 5478: (29, 12)}
+    for kind in (capi.KIND_F16X2, capi.KIND_I16X2):
+        for q, plan in want.items():
+            assert capi.plan_query(kind, q) == plan, (q, capi.plan_query(kind, q))
+        for q in (100, 512, 729, 768):      # one stripe whenever the query fits one
+            assert capi.plan_query(kind, q)[1] == 1
+    assert capi.plan_query(capi.KIND_I32, 5478) == (43, 8)      # the 32-bit kinds are not affected
+    monkeypatch.setenv("CUDASW4_AMD_TWO_WAVE_PENALTY", "1")
+    old = {850: (27, 2), 2005: (42, 3), 2504: (40, 4), 4061: (43, 6), 5478: (43, 8)}
+    for q, plan in old.items():
+        assert capi.plan_query(capi.KIND_F16X2, q) == plan
 
 
 def test_no_cpu_fallback(built):

@@ -382,8 +382,11 @@ def test_every_compiled_tile_shape(monkeypatch):
     """Every (kind, rows-per-lane R, group shape, single/multi stripe) instantiation that the planner can pick:
     query lengths that land on each R for one and for several stripes, 16-lane groups (short subjects,
     partition 33), 64-lane groups (long subjects, partition 34 with a small n) and 8-lane groups (short queries;
-    forced on / off through the environment so that both shapes see every single-stripe R)."""
+    forced on / off through the environment so that both shapes see every single-stripe R).  The planner's preference
+    for three-wave stripes (round 4) is switched off here, so that the tall two-wave multi-stripe kernels are reached
+    too: the plans asserted below are those of the plain cost model."""
     torch, capi, search = gpu_modules()
+    monkeypatch.setenv("CUDASW4_AMD_TWO_WAVE_PENALTY", "1")
     rng = np.random.default_rng(77)
     short = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1, 260, 37))]
     long_ = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1281, 1700, 9))]
