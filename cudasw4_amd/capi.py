@@ -23,7 +23,8 @@ ERR_NAMES = {-1: "SW_ERR_INVALID", -2: "SW_ERR_HIP", -3: "SW_ERR_NO_QUERY", -4: 
 EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "sw_ctx_destroy", "sw_set_matrix",
            "sw_set_query", "sw_scan_temp_bytes", "sw_scan_partition", "sw_rescore_overflow", "sw_rescore_overflow_stat",
            "sw_topk_temp_bytes",
-           "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal"]
+           "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal",
+           "sw_window_overlap", "sw_reduce_windows"]
 
 
 class SwError(RuntimeError):
@@ -65,6 +66,9 @@ def _load():
     L.sw_plan_query.argtypes = [ctypes.c_int, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.sw_check_letter_codes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     L.sw_set_start_signal.argtypes = [vp, vp]
+    L.sw_window_overlap.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.sw_window_overlap.restype = i32
+    L.sw_reduce_windows.argtypes = [vp, vp, vp, vp, i32, vp, vp, ctypes.c_int64, vp]
     L.sw_plan_launch.argtypes = [vp, ctypes.c_int, ctypes.c_int, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32),
                                  ctypes.POINTER(i32), ctypes.POINTER(i32)]
     return L

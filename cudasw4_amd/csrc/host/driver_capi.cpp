@@ -296,6 +296,10 @@ int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_le
 
 int swdrv_last_rescored(swdrv* d) { return d ? d->lastRescored : 0; }
 
+int swdrv_window_stats(swdrv* d, int64_t* launches, int64_t* windows) {
+    return guarded([&] { d->driver->windowStats(launches, windows); });
+}
+
 int swdrv_numa_node(swdrv* d, int gpu) {
     int node = -1;
     (void)guarded([&] { node = d->driver->numaNode(gpu); });

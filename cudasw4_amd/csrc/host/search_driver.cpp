@@ -6,6 +6,7 @@
 #include <sched.h>
 
 #include <cctype>
+#include <cmath>
 
 #include <algorithm>
 #include <chrono>
@@ -221,6 +222,21 @@ struct SearchDriver::Gpu {
     // workgroups are resident; the bulk launch of the batch waits on the work stream for the count of side launches
     // enqueued so far.  Without it the persistent bulk grid, once dispatched, holds every workgroup slot to its end and a
     // side launch that loses the race for the first slots runs BEHIND it (tools/ubench/side_launch_probe.hip: 8 of 8).
+    // Windows of long subjects for short queries (include/cudasw4_amd.h: sw_window_overlap): per auxiliary stream one
+    // pinned host block (window offsets / lengths, first window and position of every subject) and its device copy with the
+    // windows' scores and ids behind it; the host block is rewritten by a later scan only after its copy has completed
+    struct WindowBuf {
+        char* h = nullptr; size_t hcap = 0;
+        char* d = nullptr; size_t dcap = 0;
+        hipEvent_t copied = nullptr;
+        bool used = false;
+    };
+    static constexpr int kWindowBufs = 4;  // per auxiliary stream: two queries in flight, two side launches each at most
+    WindowBuf winBuf[kAux][kWindowBufs];
+    int winNext[kAux] = {0, 0};
+    bool windows = true;               // CUDASW4_AMD_NO_WINDOWS=1 turns them off (A/B measurements, tests)
+    bool windowsAlways = false;        // CUDASW4_AMD_WINDOWS=always: whenever the bound cuts a subject, whatever the time estimate says
+    int64_t windowLaunches = 0, windowCount = 0;  // side launches that ran on windows / windows scanned, since the driver was created
     uint32_t* startSignal = nullptr;   // signal memory (hipMallocSignalMemory)
     uint32_t sideLaunches = 0;         // enqueued since the signal was last zeroed
     bool handshake = true;             // CUDASW4_AMD_NO_HANDSHAKE=1 turns it off (A/B measurements)
@@ -388,6 +404,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
                 }
             }
         }
+        if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
+        if (const char* e = std::getenv("CUDASW4_AMD_WINDOWS")) g->windowsAlways = std::string(e) == "always";
         if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
         g->ovfCountCap = 1 + Gpu::kOvfLists;
@@ -415,6 +433,11 @@ SearchDriver::~SearchDriver() {
         }
         (void)hipHostFree(g.h_pad);
         if (g.startSignal) (void)hipFree(g.startSignal);
+        for (auto& per : g.winBuf)
+            for (auto& wb : per) {
+                (void)hipHostFree(wb.h); (void)hipFree(wb.d);
+                if (wb.copied) (void)hipEventDestroy(wb.copied);
+            }
         for (hipEvent_t e : g.batchEv) (void)hipEventDestroy(e);
         if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
         if (g.recordRefEv) (void)hipEventDestroy(g.recordRefEv);
@@ -818,6 +841,108 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
             g.timed.push_back(t);
         }
     };
+    // A side launch of a 32-bit kind whose long subjects the current query allows to cut into windows (sw_window_overlap:
+    // exact).  The giants of a real DB are a handful of subjects of up to 35 000 residues, each one alignment group's
+    // 35 000 dependent steps: for a query of a few hundred residues that single group outlasted the scan of everything
+    // else.  Cut into windows of C = max(W, 2048) columns plus W columns of run-in, the same subjects are dozens of
+    // independent groups.  Returns false when the run is to be launched as it is.
+    auto launch_windows = [&](size_t ri, hipStream_t stream, int a) -> bool {
+        const LaunchRun& r = runs[ri];
+        if (!g.windows || is_packed(r.kind)) return false;
+        const int32_t W = sw_window_overlap(g.ctx, gop, gex);
+        if (W < 0) return false;
+        const int64_t W4 = (int64_t(W) + 3) / 4 * 4, C = std::max<int64_t>(W4, 2048);
+        if (int64_t(r.maxlen) <= C + W4) return false;  // nothing to cut
+        // Worth it only while the longest subject's lone group would outlast the bulk launch (windows double the side
+        // launch's work, which runs beside the bulk: measured -1 ... -1.7 % from 222 residues up on the Swiss-Prot-like DB,
+        // +47 % at 48, +23 % at 96, +4.5 % at 144, +3 % at 189).  Rough clocks: a wave-wide group alone on its SIMD issues a
+        // dependent step of R rows in ~(6.5 R + 19) * 8 cycles; the bulk runs at ~10 TCUPS.  CUDASW4_AMD_WINDOWS=always
+        // skips the estimate (tests).
+        if (!g.windowsAlways) {
+            const double rows = std::ceil(double(g.qlen) / 64.0), stripes = std::ceil(rows / 8.0);
+            const double tGiant = double(r.maxlen) * stripes * (6.5 * std::min(rows, 8.0) + 19.0) * 8.0 / 2.4e9;
+            const double tBulk = double(g.localOffsets[runs[mainIdx].end] - g.localOffsets[runs[mainIdx].begin]) * double(g.qlen) / 10e12;
+            if (tGiant < 1.15 * tBulk) return false;
+        }
+        const size_t nreal = r.end - r.begin;
+        // host side: windows of every subject of the run
+        size_t nwin = 0;
+        for (size_t pos = r.begin; pos < r.end; pos++) {
+            const int64_t len = db.length(size_t(g.toGlobal(int64_t(pos))));
+            nwin += len <= C + W4 ? 1 : size_t((len + C - 1) / C);
+        }
+        if (nwin > size_t(INT32_MAX) / 2) return false;
+        auto al = [](size_t x) { return (x + 15) / 16 * 16; };
+        const size_t offOff = 0, lenOff = al(nwin * 8), firstOff = lenOff + al(nwin * 4), posOff = firstOff + al((nreal + 1) * 4);
+        const size_t hostBytes = posOff + al(nreal * 4);
+        const size_t scoreOff = hostBytes, idOff = scoreOff + al(nwin * 4), devBytes = idOff + al(nwin * 4);
+        auto& wb = g.winBuf[a][g.winNext[a]];
+        g.winNext[a] = (g.winNext[a] + 1) % GpuT::kWindowBufs;
+        if (!wb.copied) HIPCHECK(hipEventCreateWithFlags(&wb.copied, hipEventDisableTiming));
+        if (wb.used) HIPCHECK(hipEventSynchronize(wb.copied));
+        if (hostBytes > wb.hcap) {
+            (void)hipHostFree(wb.h); wb.h = nullptr; wb.hcap = 0;
+            HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&wb.h), hostBytes * 2));
+            wb.hcap = hostBytes * 2;
+        }
+        if (devBytes > wb.dcap) {
+            (void)hipFree(wb.d); wb.d = nullptr; wb.dcap = 0;
+            HIPCHECK(hipMalloc(reinterpret_cast<void**>(&wb.d), devBytes * 2));
+            wb.dcap = devBytes * 2;
+        }
+        uint64_t* hOff = reinterpret_cast<uint64_t*>(wb.h + offOff);
+        int32_t* hLen = reinterpret_cast<int32_t*>(wb.h + lenOff);
+        int32_t* hFirst = reinterpret_cast<int32_t*>(wb.h + firstOff);
+        int32_t* hPos = reinterpret_cast<int32_t*>(wb.h + posOff);
+        size_t w = 0;
+        int32_t maxWin = 0;
+        for (size_t pos = r.begin; pos < r.end; pos++) {
+            const int64_t len = db.length(size_t(g.toGlobal(int64_t(pos))));
+            const uint64_t base = g.localOffsets[pos] - g.localOffsets[lbegin];  // the subject's first byte, relative to `chars`
+            hFirst[pos - r.begin] = int32_t(w);
+            hPos[pos - r.begin] = int32_t(pos - lbegin);
+            const int64_t k = len <= C + W4 ? 1 : (len + C - 1) / C;
+            for (int64_t i = 0; i < k; i++) {
+                const int64_t b = k == 1 ? 0 : std::max<int64_t>(0, i * C - W4), e = k == 1 ? len : std::min(len, (i + 1) * C);
+                hOff[w] = base + uint64_t(b);
+                hLen[w] = int32_t(e - b);
+                maxWin = std::max(maxWin, hLen[w]);
+                w++;
+            }
+        }
+        hFirst[nreal] = int32_t(w);
+        HIPCHECK(hipMemcpyAsync(wb.d, wb.h, hostBytes, hipMemcpyHostToDevice, stream));
+        HIPCHECK(hipEventRecord(wb.copied, stream));
+        wb.used = true;
+        const int32_t n = int32_t(nwin);
+        const int tslot = a + 1;
+        const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, maxWin);
+        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
+        TimedLaunch t;
+        const bool record = recordMode == 1;
+        if (record) {
+            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
+            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
+            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = false;
+            SWCHECK(sw_plan_launch(g.ctx, int(r.kind), r.part_id, n, maxWin, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
+            HIPCHECK(hipEventRecord(t.ev0, stream));
+        }
+        // the windows are subjects of their own: offsets relative to the first window's, whose first byte `chars + hOff[0]` is
+        SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, chars + hOff[0], reinterpret_cast<const uint64_t*>(wb.d + offOff),
+                                  reinterpret_cast<const int32_t*>(wb.d + lenOff), 0, n, maxWin, gop, gex,
+                                  reinterpret_cast<float*>(wb.d + scoreOff), reinterpret_cast<int32_t*>(wb.d + idOff), 0,
+                                  nullptr, nullptr, 0, temp, g.tempBytes[tslot], stream));
+        SWCHECK(sw_reduce_windows(g.ctx, reinterpret_cast<const float*>(wb.d + scoreOff), reinterpret_cast<const int32_t*>(wb.d + firstOff),
+                                  reinterpret_cast<const int32_t*>(wb.d + posOff), int32_t(nreal), g.d_scores + lbegin, g.d_ids + lbegin,
+                                  int64_t(lbegin), stream));
+        if (record) {
+            HIPCHECK(hipEventRecord(t.ev1, stream));
+            g.timed.push_back(t);
+        }
+        g.windowLaunches++;
+        g.windowCount += int64_t(nwin);
+        return true;
+    };
     auto rescore = [&](size_t ri, hipStream_t stream, int tslot) {  // cudasw4.cuh:2134-2169
         if (ovfList[ri] < 0) return;
         const LaunchRun& r = runs[ri];
@@ -858,7 +983,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
             g.sideLaunches++;
             anySide = true;
         }
-        launch(i, g.aux[a], a + 1);
+        if (!launch_windows(i, g.aux[a], a)) launch(i, g.aux[a], a + 1);
     }
     // the bulk launch goes in only after the side launches hold their workgroup slots
     if (anySide) HIPCHECK(hipStreamWaitValue32(work, g.startSignal, g.sideLaunches, hipStreamWaitValueGte, 0xffffffffu));
@@ -1284,6 +1409,12 @@ bool SearchDriver::isResident(int gpu) const {
     return g.cacheBegin == 0 && g.cacheFilled;
 }
 uint64_t SearchDriver::cachedChars(int gpu) const { return gpus_.at(size_t(gpu))->cacheBytes; }
+void SearchDriver::windowStats(int64_t* launches, int64_t* windows) const {
+    int64_t l = 0, w = 0;
+    for (auto& gp : gpus_) { l += gp->windowLaunches; w += gp->windowCount; }
+    if (launches) *launches = l;
+    if (windows) *windows = w;
+}
 uint64_t SearchDriver::streamedBytesTotal() const {
     uint64_t t = 0;
     for (auto& gp : gpus_) t += gp->streamedBytes;

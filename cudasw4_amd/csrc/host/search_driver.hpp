@@ -208,6 +208,9 @@ public:
     // bytes of subject chars copied host -> device by scans since the driver was created (the one-time upload of
     // resident / cached chars is NOT counted): what a streamed shard costs per query on the bus
     uint64_t streamedBytesTotal() const;
+    // side launches that scanned their long subjects as overlapping windows (short queries: sw_window_overlap), and the
+    // windows they scanned, since the driver was created
+    void windowStats(int64_t* launches, int64_t* windows) const;
     // every score of the last scan on `gpu` (the CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756) with
     // the global id of each position; both arrays hold numLocal(gpu) entries
     void lastScores(int gpu, float* scores, int64_t* ids);

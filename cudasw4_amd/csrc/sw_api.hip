@@ -565,6 +565,43 @@ int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal) {
     return SW_OK;
 }
 
+namespace {
+__global__ void reduce_windows_kernel(const float* __restrict__ win_scores, const int32_t* __restrict__ win_first,
+                                      const int32_t* __restrict__ real_pos, int32_t n_real, float* __restrict__ scores,
+                                      int32_t* __restrict__ ids, int64_t id_offset) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_real) return;
+    float m = -1.0f;
+    for (int32_t w = win_first[i]; w < win_first[i + 1]; w++) m = fmaxf(m, win_scores[w]);
+    const int32_t pos = real_pos[i];
+    scores[pos] = m;
+    ids[pos] = (int32_t)(id_offset + pos);
+}
+}  // namespace
+
+int32_t sw_window_overlap(sw_ctx* ctx, int gop, int gex) {
+    if (!ctx || !ctx->have_query || !ctx->have_matrix) return -1;
+    // every gap column costs at least min(|gop|, |gex|); an alignment with a positive score of a query of Q residues has at
+    // most Q aligned columns worth at most max(M) each: fewer than Q * max(M) / cost gap columns, Q * (1 + max(M) / cost)
+    // subject columns in all
+    const int cost = std::min(-gop, -gex);
+    if (cost <= 0) return -1;
+    const int64_t span = (int64_t)ctx->qlen + (int64_t)ctx->qlen * std::max(1, ctx->matrix_max) / cost + 1;
+    return span > 0x3fffffff ? -1 : (int32_t)span;
+}
+
+int sw_reduce_windows(sw_ctx* ctx, const float* win_scores, const int32_t* win_first, const int32_t* real_pos, int32_t n_real,
+                      float* scores, int32_t* ids, int64_t id_offset, void* stream) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    if (n_real <= 0) return SW_OK;
+    if (!win_scores || !win_first || !real_pos || !scores || !ids) return fail(SW_ERR_INVALID, "null buffer");
+    SW_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(reduce_windows_kernel, dim3((n_real + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), win_scores,
+                       win_first, real_pos, n_real, scores, ids, id_offset);
+    SW_HIP(hipGetLastError());
+    return SW_OK;
+}
+
 int sw_plan_query(int kind, int32_t qlen, int32_t* rows_per_lane, int32_t* nstripes) {
     if (!kind_launch(kind) || qlen <= 0) return fail(SW_ERR_INVALID, "bad kind or query length");
     const QueryPlan pl = plan_query(kind, qlen, 16);

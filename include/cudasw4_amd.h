@@ -166,6 +166,23 @@ int sw_rescore_overflow_stat(sw_ctx* ctx, int kind,
  * has n == 0 (nothing is enqueued, nothing will fire: do not wait for it). */
 int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
 
+/* Long subjects against SHORT queries: exact windowing.  An alignment with a positive score of a query of Q residues spans
+ * fewer than W = Q + Q * max(matrix) / min(|gop|, |gex|) + 1 subject columns (every gap column costs at least the
+ * cheaper gap score, the aligned columns are worth at most Q * max(matrix)), so the DP value of any cell is already exact
+ * when the recurrence starts W columns to its left with the local-alignment boundary.  A subject may therefore be cut into
+ * overlapping WINDOWS — window k = columns [k * C - W, (k + 1) * C), starts on multiples of 4 — that are scanned like
+ * independent subjects (sw_scan_partition on arrays of window offsets and lengths; a window is a valid subject as it is:
+ * the kernels read whole 4-letter words and treat everything from the window's length on as padding), and the subject's
+ * score is the maximum of its windows' scores: bit-identical to the unsplit scan, with len / C + 1 alignment groups
+ * working on a 35 000-residue protein instead of one (the reference, and rounds 1-3 here, walk such a subject's 35 000
+ * dependent steps with a single group: for a 48-residue query that one subject took longer than the rest of Swiss-Prot).
+ *   sw_window_overlap  W for the CURRENT query and these gap scores (-1: no bound, e.g. gex == 0)
+ *   sw_reduce_windows  scores[real_pos[i]] = max(win_scores[win_first[i] .. win_first[i + 1])), ids[real_pos[i]] =
+ *                      id_offset + real_pos[i] for i < n_real; all pointers DEVICE. */
+int32_t sw_window_overlap(sw_ctx* ctx, int gop, int gex);
+int sw_reduce_windows(sw_ctx* ctx, const float* win_scores, const int32_t* win_first, const int32_t* real_pos, int32_t n_real,
+                      float* scores, int32_t* ids, int64_t id_offset, void* stream);
+
 /* Per-GPU top-K (cudasw4.cuh:1357-1401): the k best (score desc, id asc on ties) of n results.
  * out_scores/out_ids: DEVICE, k entries, padded with (-1, -1) when n < k.
  * temp: DEVICE scratch of sw_topk_temp_bytes(n, k). */

@@ -114,6 +114,10 @@ int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_le
                          int64_t* cache_begin, int64_t* cache_bytes, int64_t* batch_bytes, int64_t* batches, int cap,
                          int64_t* temp_per_stream);
 
+/* long subjects scanned as overlapping windows (exact for short queries, include/cudasw4_amd.h: sw_window_overlap): side
+ * launches that did so and windows scanned since swdrv_create */
+int swdrv_window_stats(swdrv* d, int64_t* launches, int64_t* windows);
+
 /* NUMA placement: the node of the gpu-th GPU's PCI function (-1: unknown) and its HIP device ordinal.  In-process
  * multi-GPU drivers run each GPU's worker thread on that node themselves; a one-process-per-GPU caller binds its own
  * thread with swdrv_bind_to_numa_node (0: bound; -1: unknown node or none of its CPUs allowed, affinity unchanged). */

@@ -135,6 +135,67 @@ def test_driver_random_db_from_makedb(tmp_path):
             d.close()
 
 
+@pytest.mark.parametrize("kinds", [(0, 0, 3, 3), (1, 1, 2, 2)])
+def test_long_subjects_as_windows_for_short_queries(kinds, monkeypatch):
+    """Exact windowing (include/cudasw4_amd.h: sw_window_overlap): for a short query the giants of a DB
+    are cut into overlapping windows that are scanned as independent subjects, and a subject's score is the maximum over
+    its windows.  Every score must equal the unsplit scan's and the oracle's — in particular for alignments that straddle
+    a window boundary: the query itself, and the query with a 150-residue insertion in its middle, are planted right
+    across the first boundaries of several giants."""
+    from cudasw4_amd import driver
+    rng = np.random.default_rng(314)
+    _, letters = O.read_fasta(FASTA)
+    alphabet = b"ARNDCQEGHILKMFPSTWYV"
+    short_q = [letters[0][:48], letters[0], letters[3][:300]]          # 48, 144 and 300 residues
+    long_q = letters[9]                                                  # 1000 residues: W = 12 001, only the longest giant is cut
+    seqs = [bytes(rng.choice(list(alphabet), int(l)).astype(np.uint8)) for l in rng.integers(30, 1200, 1500)]
+    giants = []
+    for gi, l in enumerate((8100, 9000, 12000, 17000, 23000, 29000, 35000)):
+        s = bytearray(rng.choice(list(alphabet), l).astype(np.uint8).tobytes())
+        q = short_q[gi % 3]
+        # window stride for these queries: max(W rounded to 4, 2048); plant across the first two boundaries
+        W = len(q) + len(q) * 11 + 1
+        C = max((W + 3) // 4 * 4, 2048)
+        at = C - len(q) // 2
+        s[at:at + len(q)] = q
+        gapped = q[:len(q) // 2] + bytes(rng.choice(list(alphabet), 150).astype(np.uint8)) + q[len(q) // 2:]
+        at2 = 2 * C - len(q) // 2 - 40
+        if at2 + len(gapped) < l:
+            s[at2:at2 + len(gapped)] = gapped
+        giants.append(bytes(s))
+    db_seqs = sorted(seqs + giants, key=len)
+    enc = [O.encode(x) for x in db_seqs]
+    chars, offsets, lengths = O.make_db(enc)
+    results = {}
+    for windows in (True, False):
+        monkeypatch.setenv("CUDASW4_AMD_WINDOWS", "always")   # also where the driver's time estimate would not bother
+        if windows:
+            monkeypatch.delenv("CUDASW4_AMD_NO_WINDOWS", raising=False)
+        else:
+            monkeypatch.setenv("CUDASW4_AMD_NO_WINDOWS", "1")
+        d = driver.Driver(devices=[0], num_top=10, kinds=kinds)
+        d.db_from_arrays(chars, offsets, lengths)
+        d.upload()
+        out = []
+        for q in short_q + [long_q]:
+            r = d.scan(q)
+            sc, ids = d.last_scores(0)
+            out.append((sc.copy(), r["scores"].tolist(), r["ids"].tolist()))
+        launches, nwin = d.window_stats()
+        results[windows] = (out, launches, nwin)
+        d.close()
+    (with_w, launches, nwin), (without, l0, n0) = results[True], results[False]
+    assert l0 == 0 and n0 == 0
+    assert launches == 4 and nwin > 4 * len(giants)          # every query cut at least the longest giant
+    for qi, q in enumerate(short_q + [long_q]):
+        expect = O.scan(O.encode(q), chars, offsets, lengths, simd=True)
+        assert (with_w[qi][0] == expect).all(), (qi, np.nonzero(with_w[qi][0] != expect)[0][:5])
+        assert (without[qi][0] == expect).all()
+        assert with_w[qi][1:] == without[qi][1:]
+    # the planted alignments are what the top of the lists is made of: they were found across the boundaries
+    assert with_w[1][1][0] >= 700 and with_w[0][1][0] >= 230
+
+
 def test_align_cli_tsv_and_plain(tmp_path):
     from cudasw4_amd import driver
     g = O.golden("ref_scores.json")
