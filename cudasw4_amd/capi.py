@@ -24,7 +24,8 @@ EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "s
            "sw_set_query", "sw_scan_temp_bytes", "sw_scan_partition", "sw_rescore_overflow", "sw_rescore_overflow_stat",
            "sw_topk_temp_bytes",
            "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal",
-           "sw_window_overlap", "sw_reduce_windows"]
+           "sw_window_overlap", "sw_reduce_windows", "sw_rescore_service", "sw_rescore_overflow_claim",
+           "sw_rescore_service_temp_bytes"]
 
 
 class SwError(RuntimeError):

@@ -300,6 +300,12 @@ int swdrv_window_stats(swdrv* d, int64_t* launches, int64_t* windows) {
     return guarded([&] { d->driver->windowStats(launches, windows); });
 }
 
+int64_t swdrv_service_launches(swdrv* d) {
+    int64_t n = -1;
+    (void)guarded([&] { n = d->driver->serviceLaunches(); });
+    return n;
+}
+
 int swdrv_numa_node(swdrv* d, int gpu) {
     int node = -1;
     (void)guarded([&] { node = d->driver->numaNode(gpu); });

@@ -246,10 +246,24 @@ struct SearchDriver::Gpu {
     bool slotUsed[kSlots] = {};     // the buffer has been scanned from since the DB was set: scanned[] is valid
     bool prefetchNext = true;       // CUDASW4_AMD_NO_NEXT_PREFETCH=1 turns that off (A/B measurements)
     bool twoWorkStreams = true;   // CUDASW4_AMD_ONE_WORK_STREAM=1: every batch of a streamed scan on the work stream (A/B measurements)
-    void* d_temp[kAux + 2] = {nullptr, nullptr, nullptr, nullptr};  // work stream, auxiliary streams, stream2
-    size_t tempBytes[kAux + 2] = {0, 0, 0, 0};
+    void* d_temp[kAux + 3] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // work stream, auxiliary streams, stream2, re-score service
+    size_t tempBytes[kAux + 3] = {0, 0, 0, 0, 0};
+    // Re-score service (include/cudasw4_amd.h: sw_rescore_service): a few workgroups on a stream of their own re-score
+    // the bulk launch's overflow list while the bulk launch fills it; the work stream raises *doneSignal to doneSeq behind
+    // the bulk launch.  On while recent scans re-scored anything (a DB without relatives of its queries never pays the
+    // service's workgroup slots); CUDASW4_AMD_RESCORE_SERVICE=0|1 forces it off / on.
+    hipStream_t svcStream = nullptr;
+    hipEvent_t svcJoin = nullptr;
+    uint32_t* doneSignal = nullptr;
+    uint32_t doneSeq = 0;
+    bool svcUsed = false;
+    int svcForce = -1;
+    int quietScans = 0;                // consecutive scans without a re-scored subject
+    int64_t serviceLaunches = 0;
+    double rescoredEma = 8.0;          // recent re-scored subjects per scan: sizes the service (2, 4 or 8 workgroups)
+    int serviceWorkgroups() const { return rescoredEma < 8.0 ? 2 : rescoredEma < 64.0 ? 4 : 8; }
     size_t tempCap = SIZE_MAX;  // plan_residency: what each of them may grow to inside the memory limit
-    static_assert(kAux + 2 == kTempStreams, "plan_residency budgets the scratch of this many streams");
+    static_assert(kAux + 3 == kTempStreams, "plan_residency budgets the scratch of this many streams");
     void* d_topkTemp = nullptr;
     size_t topkTempBytes = 0;
     float* d_topS = nullptr;
@@ -395,14 +409,21 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             const char* no = std::getenv("CUDASW4_AMD_NO_HANDSHAKE");
             g->handshake = canWait != 0 && !(no && no[0] == '1');
             if (g->handshake) {
-                if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g->startSignal), 8, hipMallocSignalMemory) != hipSuccess) {
+                if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g->startSignal), 8, hipMallocSignalMemory) != hipSuccess ||
+                    hipExtMallocWithFlags(reinterpret_cast<void**>(&g->doneSignal), 8, hipMallocSignalMemory) != hipSuccess) {
                     (void)hipGetLastError();
+                    (void)hipFree(g->startSignal);
                     g->startSignal = nullptr;
+                    g->doneSignal = nullptr;
                     g->handshake = false;
                 } else {
                     *g->startSignal = 0;
+                    *g->doneSignal = 0;
+                    HIPCHECK(hipStreamCreateWithPriority(&g->svcStream, hipStreamNonBlocking, prioHigh));
+                    HIPCHECK(hipEventCreateWithFlags(&g->svcJoin, hipEventDisableTiming));
                 }
             }
+            if (const char* e = std::getenv("CUDASW4_AMD_RESCORE_SERVICE")) g->svcForce = e[0] == '1' ? 1 : 0;
         }
         if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_WINDOWS")) g->windowsAlways = std::string(e) == "always";
@@ -433,6 +454,9 @@ SearchDriver::~SearchDriver() {
         }
         (void)hipHostFree(g.h_pad);
         if (g.startSignal) (void)hipFree(g.startSignal);
+        if (g.doneSignal) (void)hipFree(g.doneSignal);
+        if (g.svcStream) (void)hipStreamDestroy(g.svcStream);
+        if (g.svcJoin) (void)hipEventDestroy(g.svcJoin);
         for (auto& per : g.winBuf)
             for (auto& wb : per) {
                 (void)hipHostFree(wb.h); (void)hipFree(wb.d);
@@ -809,7 +833,18 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     size_t mainIdx = 0;
     for (size_t i = 1; i < runs.size(); i++)
         if (runs[i].end - runs[i].begin > runs[mainIdx].end - runs[mainIdx].begin) mainIdx = i;
-    if (runs.size() > 1) HIPCHECK(hipEventRecord(fork, work));
+    // Re-score service for the bulk run's overflow list (Gpu::svcStream): resident chars only (a staging buffer would have
+    // to wait for it), a packed bulk run, and a query / subject size at which re-scoring one subject takes about as long as
+    // a launch does at all (5 * 10^5 cells)
+    const bool serviceWanted = g.svcForce >= 0 ? g.svcForce == 1 : g.quietScans < 3;
+    const bool useService = g.handshake && g.svcStream && slot < 0 && !second && serviceWanted && !runs.empty() && is_packed(runs[mainIdx].kind) &&
+                            double(g.qlen) * double(runs[mainIdx].maxlen) >= 5e5;
+    if (useService) {
+        // the list starts empty (-1) for the compare-and-swap of its takers
+        const LaunchRun& r = runs[mainIdx];
+        HIPCHECK(hipMemsetAsync(g.d_ovfPos + r.begin, 0xFF, (r.end - r.begin) * sizeof(int32_t), work));
+    }
+    if (runs.size() > 1 || useService) HIPCHECK(hipEventRecord(fork, work));
     std::vector<int> ovfList(runs.size(), -1);
     int numLists = 0;
     for (size_t i = 0; i < runs.size(); i++)
@@ -958,6 +993,13 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
             SWCHECK(sw_plan_launch(g.ctx, int(kt.overflowType), -1, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
             HIPCHECK(hipEventRecord(t.ev0, stream));
         }
+        if (useService && ri == mainIdx)   // what the service has not taken
+            SWCHECK(sw_rescore_overflow_claim(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[ri], n,
+                                              chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
+                                              int64_t(lbegin), temp, g.tempBytes[tslot],
+                                              r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16,
+                                              g.d_ovfCount, stream));
+        else
         SWCHECK(sw_rescore_overflow_stat(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[ri], n,
                                          chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
                                          int64_t(lbegin), temp, g.tempBytes[tslot],
@@ -985,10 +1027,32 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         }
         if (!launch_windows(i, g.aux[a], a)) launch(i, g.aux[a], a + 1);
     }
+    if (useService) {
+        const LaunchRun& r = runs[mainIdx];
+        const int32_t n = int32_t(r.end - r.begin);
+        const int tslot = GpuT::kAux + 2;
+        const size_t need = sw_rescore_service_temp_bytes(g.ctx, int(kt.overflowType), r.maxlen, g.serviceWorkgroups());
+        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
+        HIPCHECK(hipStreamWaitEvent(g.svcStream, fork, 0));
+        SWCHECK(sw_set_start_signal(g.ctx, g.startSignal));
+        g.sideLaunches++;
+        anySide = true;
+        g.doneSeq++;
+        SWCHECK(sw_rescore_service(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[mainIdx], n, chars, offsets,
+                                   lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), temp,
+                                   g.tempBytes[tslot], r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16, g.d_ovfCount,
+                                   g.doneSignal, g.doneSeq, g.serviceWorkgroups(), g.svcStream));
+        g.svcUsed = true;
+        g.serviceLaunches++;
+    }
     // the bulk launch goes in only after the side launches hold their workgroup slots
     if (anySide) HIPCHECK(hipStreamWaitValue32(work, g.startSignal, g.sideLaunches, hipStreamWaitValueGte, 0xffffffffu));
     for (size_t i = 0; i < runs.size(); i++)
-        if (streamOf[i] < 0) launch(i, work, workTemp);
+        if (streamOf[i] < 0) {
+            launch(i, work, workTemp);
+            // the service leaves once the list's producer has finished
+            if (useService && i == mainIdx) HIPCHECK(hipStreamWriteValue32(work, g.doneSignal, g.doneSeq, 0));
+        }
     for (size_t i = 0; i < runs.size(); i++) {
         if (streamOf[i] >= 0) rescore(i, g.aux[streamOf[i]], streamOf[i] + 1);
         else rescore(i, work, workTemp);
@@ -1015,6 +1079,11 @@ static void join_aux(GpuT& g) {
     // auxPending stays set: the host no longer waits for the end of a scan before it enqueues the next one, so the copy
     // that reuses a staging buffer must still wait for the auxiliary launches that read it (an event that has long
     // completed costs nothing)
+    if (g.svcUsed) {
+        HIPCHECK(hipEventRecord(g.svcJoin, g.svcStream));
+        HIPCHECK(hipStreamWaitEvent(g.stream, g.svcJoin, 0));
+        g.svcUsed = false;
+    }
     if (g.stream2Used) {
         HIPCHECK(hipEventRecord(g.join2Event, g.stream2));
         HIPCHECK(hipStreamWaitEvent(g.stream, g.join2Event, 0));
@@ -1225,6 +1294,7 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
     } catch (...) {
         // Work may still be queued on the auxiliary, second and copy streams, and the bookkeeping of who waits for
         // whom is half-updated: drain the device and forget it, so that a later scan starts from a clean state
+        if (g.doneSignal) *g.doneSignal = g.doneSeq;   // a re-score service that is still polling leaves now
         (void)hipDeviceSynchronize();
         (void)hipGetLastError();
         for (bool& u : g.auxUsed) u = false;
@@ -1239,6 +1309,7 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
         // a side launch may have been counted but never enqueued: nothing is in flight now, start the count afresh
         if (g.startSignal) *g.startSignal = 0;
         g.sideLaunches = 0;
+        g.svcUsed = false;
         rs.used = false;
         throw;
     }
@@ -1266,6 +1337,8 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot) {
     for (size_t i = 1; i < rs.ncounters; i++) g.lastRescored += rs.h_ovf[i];
     g.lastOverflows = rs.h_ovf[0];
     g.lastTop = rs.top;
+    g.quietScans = g.lastRescored > 0 ? 0 : std::min(g.quietScans + 1, 1000);
+    g.rescoredEma = 0.7 * g.rescoredEma + 0.3 * double(g.lastRescored);
     rs.used = false;
     g.spanEnd = now_seconds() - scanT0_;
 }
@@ -1414,6 +1487,11 @@ void SearchDriver::windowStats(int64_t* launches, int64_t* windows) const {
     for (auto& gp : gpus_) { l += gp->windowLaunches; w += gp->windowCount; }
     if (launches) *launches = l;
     if (windows) *windows = w;
+}
+int64_t SearchDriver::serviceLaunches() const {
+    int64_t n = 0;
+    for (auto& gp : gpus_) n += gp->serviceLaunches;
+    return n;
 }
 uint64_t SearchDriver::streamedBytesTotal() const {
     uint64_t t = 0;

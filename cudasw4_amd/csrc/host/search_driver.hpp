@@ -113,7 +113,7 @@ std::vector<LaunchRun> plan_launch_runs(const KernelTypeConfig& kt, const size_t
 // Residency of one GPU's shard (GpuWorkingSet + assignBatchesToGpuMem + computeDbCopyPlan, cudasw4.cuh:317-392,1087-1144,
 // 1177-1277): what stays in device memory and how the rest is cut into streamed batches.  Pure host logic (no GPU call);
 // the driver calls it in setDatabase, the CPU tests through swdrv_plan_residency.
-constexpr int kTempStreams = 4;  // streams of a GPU that can hold a stripe-border scratch at a time: work, second work, 2 auxiliary
+constexpr int kTempStreams = 5;  // streams of a GPU that can hold a stripe-border scratch at a time: work, second work, 2 auxiliary, re-score service
 struct ResidencyPlan {
     size_t cacheBegin = 0;      // shard-local subjects [cacheBegin, n) keep their chars in device memory (0: resident)
     uint64_t cacheBytes = 0;
@@ -211,6 +211,7 @@ public:
     // side launches that scanned their long subjects as overlapping windows (short queries: sw_window_overlap), and the
     // windows they scanned, since the driver was created
     void windowStats(int64_t* launches, int64_t* windows) const;
+    int64_t serviceLaunches() const;   // re-score service launches (sw_rescore_service) since the driver was created
     // every score of the last scan on `gpu` (the CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756) with
     // the global id of each position; both arrays hold numLocal(gpu) entries
     void lastScores(int gpu, float* scores, int64_t* ids);

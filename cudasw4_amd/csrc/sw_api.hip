@@ -259,11 +259,19 @@ __global__ void max_length_kernel(const int32_t* lengths, const int32_t* positio
     if (m > 0) atomicMax(out, m);
 }
 
+// overflow lists that are re-scored while they are filled (sw_dp_kernel.hpp: ScanParams::claim / service)
+struct ListMode {
+    int32_t* claim = nullptr;          // the list, writable: entries are taken by compare-and-swap
+    int service_workgroups = 0;        // > 0: a service launch of this many workgroups
+    const uint32_t* done_flag = nullptr;
+    uint32_t done_value = 0;
+};
+
 int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
                 const int32_t* positions, const int32_t* count_ptr, int32_t first_pos, int32_t n,
                 int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
                 int32_t* ovf_pos, int32_t* ovf_count, int ovf_check, void* temp, size_t temp_bytes,
-                hipStream_t stream, int32_t* stat_count = nullptr, int32_t stat_limit = 0) {
+                hipStream_t stream, int32_t* stat_count = nullptr, int32_t stat_limit = 0, const ListMode& list = ListMode()) {
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
     // one-shot: whatever happens to this call, the pending start signal belongs to it (an error or an empty launch
     // cancels it: nothing will fire, the caller must not wait)
@@ -317,8 +325,13 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     const int subj_per_batch = (swk::kThreads / lanes) * (kind_packed(kind) ? 2 : 1);
     const int nbatches = (n + subj_per_batch - 1) / subj_per_batch;
     int grid = std::min(nbatches, max_grid(ctx));
+    if (list.service_workgroups > 0) grid = std::min(grid, list.service_workgroups);
 
     swk::ScanParams p{};
+    p.claim = list.claim;
+    p.service = list.service_workgroups > 0 ? 1 : 0;
+    p.done_flag = list.done_flag;
+    p.done_value = list.done_value;
     p.chars = chars; p.offsets = offsets; p.lengths = lengths;
     p.positions = positions; p.count_ptr = count_ptr;
     p.first_pos = first_pos; p.n = n;
@@ -673,6 +686,51 @@ int sw_rescore_overflow_stat(sw_ctx* ctx, int kind, const int32_t* ovf_pos, cons
     return scan_common(ctx, kind, lanes, chars, offsets, lengths, ovf_pos, ovf_count, 0, max_count, max_subject_len, gop, gex,
                        scores, ids, id_offset, nullptr, nullptr, 0, temp, temp_bytes, static_cast<hipStream_t>(stream),
                        true_overflow_count, packed_limit);
+}
+
+size_t sw_rescore_service_temp_bytes(sw_ctx* ctx, int kind, int32_t max_subject_len, int workgroups) {
+    if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0 || workgroups <= 0) return 0;
+    kind = effective_kind_of(ctx, kind, max_subject_len);
+    const int lanes = rescore_lanes(max_subject_len);
+    const QueryPlan pl = plan_query(kind, ctx->qlen, lanes);
+    if (pl.nstripes <= 1) return 0;
+    return (size_t)workgroups * border_bytes_per_wg(border_capacity(max_subject_len, lanes), lanes);
+}
+
+int sw_rescore_service(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
+                       const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
+                       int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
+                       int32_t packed_limit, int32_t* true_overflow_count, const uint32_t* done_flag, uint32_t done_value,
+                       int workgroups, void* stream) {
+    if (kind != SW_KIND_I32 && kind != SW_KIND_F32) return fail(SW_ERR_INVALID, "overflow re-score needs a 32-bit kind");
+    if (!ovf_pos || !ovf_count || !done_flag) return fail(SW_ERR_INVALID, "null overflow buffers or flag");
+    if (max_count <= 0 || workgroups <= 0) { if (ctx) ctx->start_signal = nullptr; return SW_OK; }
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    kind = effective_kind_of(ctx, kind, max_subject_len);
+    ListMode lm;
+    lm.claim = ovf_pos;
+    lm.service_workgroups = workgroups;
+    lm.done_flag = done_flag;
+    lm.done_value = done_value;
+    return scan_common(ctx, kind, rescore_lanes(max_subject_len), chars, offsets, lengths, ovf_pos, ovf_count, 0, max_count, max_subject_len,
+                       gop, gex, scores, ids, id_offset, nullptr, nullptr, 0, temp, temp_bytes, static_cast<hipStream_t>(stream),
+                       true_overflow_count, packed_limit, lm);
+}
+
+int sw_rescore_overflow_claim(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
+                              const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
+                              int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
+                              int32_t packed_limit, int32_t* true_overflow_count, void* stream) {
+    if (kind != SW_KIND_I32 && kind != SW_KIND_F32) return fail(SW_ERR_INVALID, "overflow re-score needs a 32-bit kind");
+    if (!ovf_pos || !ovf_count) return fail(SW_ERR_INVALID, "null overflow buffers");
+    if (max_count <= 0) return SW_OK;
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    kind = effective_kind_of(ctx, kind, max_subject_len);
+    ListMode lm;
+    lm.claim = ovf_pos;
+    return scan_common(ctx, kind, rescore_lanes(max_subject_len), chars, offsets, lengths, ovf_pos, ovf_count, 0, max_count, max_subject_len,
+                       gop, gex, scores, ids, id_offset, nullptr, nullptr, 0, temp, temp_bytes, static_cast<hipStream_t>(stream),
+                       true_overflow_count, packed_limit, lm);
 }
 
 // ------------------------------------------------------------------ top-K

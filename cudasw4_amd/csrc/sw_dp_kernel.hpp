@@ -391,7 +391,19 @@ struct ScanParams {
     // scope; signal memory a stream can wait on: hipStreamWaitValue32).  nullptr: no handshake.
     u32* start_signal;
     u32 start_quorum;
+    // Overflow lists that are re-scored WHILE they are filled (sw_rescore_service).  claim: the list's entries are taken
+    // with a compare-and-swap (-1: not written yet, >= 0: a subject to re-score, -2: taken), so that a service launch that
+    // runs beside the producing launch and the ordinary re-score launch behind it never score an entry twice; the producer
+    // publishes an entry with an agent-scope store (its plain stores would sit in its XCD's L2).  service: the list's length
+    // (count_ptr) is polled per batch instead of read once, a batch is taken as soon as its first entry is there, and the
+    // workgroup leaves when *done_flag has reached done_value (the producer has finished) and nothing is left for it.
+    int32_t* claim;            // == positions, writable; nullptr: plain list
+    int32_t service;
+    const u32* done_flag;
+    u32 done_value;
 };
+
+constexpr int32_t kListEmpty = -1, kListTaken = -2;
 
 typedef u32 u32x3 __attribute__((ext_vector_type(3)));
 
@@ -868,10 +880,11 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         if (atomicAdd(p.work_counter + 1, 1u) + 1u == p.start_quorum)
             __hip_atomic_fetch_add(p.start_signal, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const int n = p.count_ptr ? *p.count_ptr : p.n;
+    const bool service = p.service != 0;  // uniform
+    const int n = (p.count_ptr && !service) ? *p.count_ptr : p.n;  // service: the list's capacity; its length is polled per batch
     constexpr int kSubjPerBatch = kGroups * A::kSubjects;
     const int nbatches = (n + kSubjPerBatch - 1) / kSubjPerBatch;
-    if ((int)blockIdx.x >= nbatches) return;  // workgroup-uniform (device-side count of the re-score path)
+    if (!service && (int)blockIdx.x >= nbatches) return;  // workgroup-uniform (device-side count of the re-score path)
 
     if constexpr (!MULTI) {
         load_tile<G::kTileBytes>(lds, p.profile);
@@ -893,31 +906,74 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     const u32 zstart = OFFS ? A::zero_at(p.gex_mag, LANES - lane) : A::kZero;
     const u32 zbefore = OFFS ? A::zero_at(p.gex_mag, LANES - lane - 1) : A::kZero;  // the column before
 
-    __shared__ int next_batch;
+    __shared__ int next_batch, batch_avail;
+    // an entry of a claimed list: wait (briefly: the producer stores it right after it has counted it) until it is written,
+    // then take it; -1: somebody else has it
+    auto claim_entry = [&](int i) -> int {
+        for (int spin = 0; spin < (1 << 20); spin++) {
+            const int v = __hip_atomic_load(p.claim + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == kListTaken) return -1;
+            if (v >= 0) return atomicCAS(p.claim + i, v, kListTaken) == v ? v : -1;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return -1;
+    };
     for (;;) {
         // dynamic batch distribution: one atomic per workgroup per batch
         __syncthreads();
-        if (tid == 0) next_batch = (int)atomicAdd(p.work_counter, 1u);
+        if (tid == 0) {
+            int b = (int)atomicAdd(p.work_counter, 1u), avail = n;
+            if (service) {
+                // the batch is there as soon as its first entry is; the producer's end (done_flag) ends the wait — what the
+                // service has not taken by then is the ordinary re-score launch's
+                avail = 0;
+                for (u32 spin = 0; b < nbatches; spin++) {
+                    avail = __hip_atomic_load(p.count_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (avail > b * kSubjPerBatch) break;
+                    const u32 done = __hip_atomic_load(p.done_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((int32_t)(done - p.done_value) >= 0 || spin > 9000000u) { b = nbatches; break; }  // (the bound, ~30 s: never hang a GPU on a lost flag)
+                    __builtin_amdgcn_s_sleep(127);
+                }
+                avail = min(avail, n);
+            }
+            next_batch = b;
+            batch_avail = avail;
+        }
         __syncthreads();
         const int b = next_batch;
         if (b >= nbatches) break;
-        const int batch = nbatches - 1 - b;  // DB is length-sorted ascending: longest first
+        const int navail = batch_avail;
+        const int batch = service ? b : nbatches - 1 - b;  // DB is length-sorted ascending: longest first; a service walks its list as it grows
         const int i0 = batch * kSubjPerBatch + group * A::kSubjects;
         const int i1 = i0 + 1;
-        const bool valid0 = i0 < n;
-        const bool valid1 = A::kPacked && (i1 < n);
+        bool valid0 = i0 < navail;
+        bool valid1 = A::kPacked && (i1 < navail);
         int pos0 = 0, pos1 = 0, len0 = 0, len1 = 0;
         const int8_t* s0 = p.chars;
         const int8_t* s1 = p.chars;
-        if (valid0) {
-            pos0 = p.positions ? p.positions[i0] : p.first_pos + i0;
-            len0 = p.lengths[pos0];
-            s0 = p.chars + (p.offsets[pos0] - p.offsets[0]);
-        }
-        if (valid1) {
-            pos1 = p.positions ? p.positions[i1] : p.first_pos + i1;
-            len1 = p.lengths[pos1];
-            s1 = p.chars + (p.offsets[pos1] - p.offsets[0]);
+        if (p.claim) {  // (32-bit kinds only: one subject per group; read by the group's lane 0, broadcast below)
+            int v = -1;
+            if (valid0 && lane == 0) v = claim_entry(i0);
+            if constexpr (LANES == 64) v = __builtin_amdgcn_readfirstlane(v);
+            else v = __shfl(v, (tid & 63) & ~(LANES - 1));
+            valid0 = v >= 0;
+            pos0 = valid0 ? v : 0;
+            if (valid0) {
+                len0 = p.lengths[pos0];
+                s0 = p.chars + (p.offsets[pos0] - p.offsets[0]);
+            }
+            valid1 = false;
+        } else {
+            if (valid0) {
+                pos0 = p.positions ? p.positions[i0] : p.first_pos + i0;
+                len0 = p.lengths[pos0];
+                s0 = p.chars + (p.offsets[pos0] - p.offsets[0]);
+            }
+            if (valid1) {
+                pos1 = p.positions ? p.positions[i1] : p.first_pos + i1;
+                len1 = p.lengths[pos1];
+                s1 = p.chars + (p.offsets[pos1] - p.offsets[0]);
+            }
         }
         int lmax = len0 > len1 ? len0 : len1;
         if constexpr (LANES <= 16) {  // the 4 (8) groups of a wave run in lock-step
@@ -1198,7 +1254,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         if (lane == 0) {
             if (valid0) {
                 if (A::kPacked && p.ovf_check && sc0 >= A::kLimit - guard) {
-                    p.ovf_pos[atomicAdd(p.ovf_count, 1)] = pos0;
+                    __hip_atomic_store(p.ovf_pos + atomicAdd(p.ovf_count, 1), pos0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     p.scores[pos0] = (float)sc0;
                     if (p.stat_count && sc0 >= p.stat_limit) atomicAdd(p.stat_count, 1);
@@ -1207,7 +1263,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             }
             if (valid1) {
                 if (p.ovf_check && sc1 >= A::kLimit - guard) {
-                    p.ovf_pos[atomicAdd(p.ovf_count, 1)] = pos1;
+                    __hip_atomic_store(p.ovf_pos + atomicAdd(p.ovf_count, 1), pos1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     p.scores[pos1] = (float)sc1;
                 }

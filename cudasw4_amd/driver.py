@@ -21,7 +21,7 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges", "swdrv_matrix25",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
            "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency", "swdrv_numa_node", "swdrv_device_of",
-           "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats"]
+           "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats", "swdrv_service_launches"]
 
 
 class DriverError(RuntimeError):
@@ -90,6 +90,8 @@ def _load():
     L.swdrv_matrix25.argtypes = [ctypes.c_int, vp]
     L.swdrv_last_rescored.argtypes = [vp]
     L.swdrv_numa_node.argtypes = [vp, ctypes.c_int]
+    L.swdrv_service_launches.restype = ctypes.c_int64
+    L.swdrv_service_launches.argtypes = [vp]
     L.swdrv_window_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     L.swdrv_device_of.argtypes = [vp, ctypes.c_int]
     L.swdrv_bind_to_numa_node.argtypes = [ctypes.c_int]
@@ -298,6 +300,10 @@ class Driver:
         a, b = ctypes.c_int64(), ctypes.c_int64()
         _check(lib.swdrv_window_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def service_launches(self):
+        """Re-score service launches since the driver was created."""
+        return int(lib.swdrv_service_launches(self.handle))
 
     def numa_node(self, gpu=0):
         """NUMA node of the GPU's PCI function (-1: unknown)."""

@@ -121,7 +121,7 @@ size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t
  *                   The list may hold a few subjects more than strictly overflowed: the kernels keep
  *                   column j's values raised by |gex|*(j+16) and flag a subject as soon as the bound
  *                   score + |gex|*(min(columns,K)+36) reaches the limit (never one scoring below limit-1536
- *                   for F16X2 / limit-12500 for I16X2).  Re-scoring them all keeps every score exact.
+ *                   for F16X2 / limit-2100 for I16X2 with gex = -1).  Re-scoring them all keeps every score exact.
  *   temp            DEVICE scratch of at least sw_scan_temp_bytes() (may be NULL when that is 0)
  */
 int sw_scan_partition(sw_ctx* ctx, int kind, int part_id,
@@ -154,6 +154,26 @@ int sw_rescore_overflow_stat(sw_ctx* ctx, int kind,
                              float* scores, int32_t* ids, int64_t id_offset,
                              void* temp, size_t temp_bytes,
                              int32_t packed_limit, int32_t* true_overflow_count, void* stream);
+
+/* Re-scoring an overflow list WHILE it is filled.  The ordinary re-score launch runs behind the packed launch that fills
+ * its list: on real data (the queries' own family in the DB) the few long subjects it then walks are pure tail — 9 ms for
+ * one 5 500-residue subject against a 5 478-residue query, behind a 106 ms scan.  A SERVICE launch of a few workgroups,
+ * started beside the packed launch (sw_set_start_signal), polls the list's length, takes entries as they appear and
+ * leaves when *done_flag (a word the caller sets behind the packed launch, e.g. hipStreamWriteValue32) has reached
+ * done_value; sw_rescore_overflow_claim then re-scores what the service has not taken.  Both take entries by
+ * compare-and-swap, so the list must start as all -1 (hipMemsetAsync 0xFF over the packed launch's ovf_pos slice) and is
+ * consumed (entries become -2).  `workgroups`: size of the service (each holds a workgroup slot for the packed launch's
+ * whole duration); temp: sw_rescore_service_temp_bytes.  Otherwise as sw_rescore_overflow_stat. */
+size_t sw_rescore_service_temp_bytes(sw_ctx* ctx, int kind, int32_t max_subject_len, int workgroups);
+int sw_rescore_service(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
+                       const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
+                       int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
+                       int32_t packed_limit, int32_t* true_overflow_count, const uint32_t* done_flag, uint32_t done_value,
+                       int workgroups, void* stream);
+int sw_rescore_overflow_claim(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
+                              const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
+                              int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
+                              int32_t packed_limit, int32_t* true_overflow_count, void* stream);
 
 /* Start handshake for launches that must run BESIDE a launch that fills the GPU (the reference gets that overlap from
  * its ten work streams, cudasw4.cuh:293,1745-1748; on this runtime a persistent grid that is dispatched first keeps every

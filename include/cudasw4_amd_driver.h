@@ -117,6 +117,10 @@ int swdrv_plan_residency(const uint64_t* local_offsets, size_t n, int32_t max_le
 /* long subjects scanned as overlapping windows (exact for short queries, include/cudasw4_amd.h: sw_window_overlap): side
  * launches that did so and windows scanned since swdrv_create */
 int swdrv_window_stats(swdrv* d, int64_t* launches, int64_t* windows);
+/* re-score service launches (include/cudasw4_amd.h: sw_rescore_service) since swdrv_create: the bulk launch's overflow list
+ * re-scored while it was being filled.  CUDASW4_AMD_RESCORE_SERVICE=0|1 forces the service off / on; by default it runs
+ * while recent scans re-scored anything. */
+int64_t swdrv_service_launches(swdrv* d);
 
 /* NUMA placement: the node of the gpu-th GPU's PCI function (-1: unknown) and its HIP device ordinal.  In-process
  * multi-GPU drivers run each GPU's worker thread on that node themselves; a one-process-per-GPU caller binds its own

@@ -103,6 +103,12 @@ hipError_t hipStreamWaitValue32(hipStream_t s, void* ptr, uint32_t value, unsign
     return hipSuccess;
 }
 
+hipError_t hipStreamWriteValue32(hipStream_t s, void* ptr, uint32_t value, unsigned) {
+    check_stream("hipStreamWriteValue32", s);
+    *static_cast<uint32_t*>(ptr) = value;
+    return hipSuccess;
+}
+
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(new FakeEvent{t_device, 0.0}); return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<FakeEvent*>(e); return hipSuccess; }

@@ -133,6 +133,18 @@ int sw_plan_launch(sw_ctx*, int kind, int part_id, int32_t, int32_t, int32_t* ek
     if (lanes) *lanes = part_id >= 34 ? 64 : 16;
     return SW_OK;
 }
+size_t sw_rescore_service_temp_bytes(sw_ctx*, int, int32_t, int) { return 0; }
+int sw_rescore_service(sw_ctx* c, int, int32_t*, const int32_t*, int32_t, const int8_t*, const uint64_t*, const int32_t*, int32_t, int, int,
+                       float*, int32_t*, int64_t, void*, size_t, int32_t, int32_t*, const uint32_t*, uint32_t, int, void*) {
+    if (c->start_signal) (*c->start_signal)++;   // its workgroups are "resident"
+    c->start_signal = nullptr;
+    return SW_OK;   // the fake executes at enqueue time: a service started before its producer finds an empty list and leaves
+}
+int sw_rescore_overflow_claim(sw_ctx* c, int kind, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count, const int8_t* chars,
+                              const uint64_t* offsets, const int32_t* lengths, int32_t m, int gop, int gex, float* scores, int32_t* ids,
+                              int64_t id_offset, void* t, size_t tb, int32_t lim, int32_t* cnt, void* s) {
+    return sw_rescore_overflow_stat(c, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, m, gop, gex, scores, ids, id_offset, t, tb, lim, cnt, s);
+}
 int32_t sw_window_overlap(sw_ctx*, int, int) { return -1; }   // the fake's scores are no alignment scores: never cut
 int sw_reduce_windows(sw_ctx*, const float*, const int32_t*, const int32_t*, int32_t, float*, int32_t*, int64_t, void*) { return SW_OK; }
 int sw_plan_query(int, int32_t, int32_t* r, int32_t* ns) { if (r) *r = 8; if (ns) *ns = 1; return SW_OK; }

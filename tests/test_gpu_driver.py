@@ -196,6 +196,49 @@ def test_long_subjects_as_windows_for_short_queries(kinds, monkeypatch):
     assert with_w[1][1][0] >= 700 and with_w[0][1][0] >= 230
 
 
+@pytest.mark.parametrize("kinds", [(0, 0, 3, 3), (1, 1, 2, 2)])
+def test_rescore_service_beside_the_bulk_launch(kinds, monkeypatch):
+    """The bulk launch's overflow list is re-scored WHILE it is filled (include/cudasw4_amd.h: sw_rescore_service): a few
+    workgroups started beside the packed launch poll the list, the ordinary re-score launch takes what they have not
+    taken, entries are claimed by compare-and-swap.  Same DB — relatives of the queries among 20 000 unrelated sequences,
+    so that hundreds of subjects overflow in fp16 and some in int16 — with the service forced on, forced off, and left to
+    the driver's feedback: every score equals the oracle, the re-score counts agree, nothing is scored twice or lost."""
+    from cudasw4_amd import driver, synthdb
+    rng = np.random.default_rng(99)
+    _, letters = O.read_fasta(FASTA)
+    queries = [letters[5], letters[11], letters[16]]          # 567, 2005 and 4548 residues
+    fam = synthdb.family_members([O.encode(q) for q in queries], seed=7, min_size=60, max_size=60)
+    lengths = synthdb.sprot_like_lengths(20000, seed=8, max_len=6000)
+    bg = synthdb.random_db(lengths, seed=9, composition=synthdb.SPROT_COMPOSITION)
+    seqs = [bg[0][int(bg[1][i]):int(bg[1][i]) + int(bg[2][i])] for i in range(len(lengths))] + list(fam)
+    seqs.sort(key=len)
+    chars, offsets, lens = O.make_db(seqs)
+    expect = [O.scan(O.encode(q), chars, offsets, lens, simd=True) for q in queries]
+    limit = 2048 if kinds[0] == 0 else 25000
+    runs = {}
+    for mode in ("1", "0", None):
+        if mode is None:
+            monkeypatch.delenv("CUDASW4_AMD_RESCORE_SERVICE", raising=False)
+        else:
+            monkeypatch.setenv("CUDASW4_AMD_RESCORE_SERVICE", mode)
+        d = driver.Driver(devices=[0], num_top=20, kinds=kinds)
+        d.db_from_arrays(chars, offsets, lens)
+        d.upload()
+        out = []
+        for rep in range(2):
+            for qi, q in enumerate(queries):
+                r = d.scan(q)
+                sc, _ = d.last_scores(0)
+                assert (sc == expect[qi]).all(), (mode, qi, np.nonzero(sc != expect[qi])[0][:5])
+                assert r["num_overflows"] == int((expect[qi] >= limit).sum()) and r["num_rescored"] >= r["num_overflows"]
+                out.append((r["scores"].tolist(), r["ids"].tolist(), r["num_overflows"], r["num_rescored"]))
+        runs[mode] = (out, d.service_launches())
+        d.close()
+    assert runs["1"][0] == runs["0"][0] == runs[None][0]
+    assert runs["1"][1] == 6 and runs["0"][1] == 0 and runs[None][1] >= 3      # feedback: on while scans re-score
+    assert sum(o[3] for o in runs["1"][0]) > (100 if kinds[0] == 0 else 0)
+
+
 def test_align_cli_tsv_and_plain(tmp_path):
     from cudasw4_amd import driver
     g = O.golden("ref_scores.json")
