@@ -25,7 +25,7 @@ EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "s
            "sw_topk_temp_bytes",
            "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal",
            "sw_window_overlap", "sw_reduce_windows", "sw_rescore_service", "sw_rescore_overflow_claim",
-           "sw_rescore_service_temp_bytes"]
+           "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently"]
 
 
 class SwError(RuntimeError):

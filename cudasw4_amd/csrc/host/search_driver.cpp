@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -42,6 +43,11 @@ double now_seconds() {
 }
 
 bool is_packed(KernelType t) { return t == KernelType::Half2 || t == KernelType::DPXs16; }
+
+// drivers' GPU objects alive per device in this process (several shards of one device, or several drivers): the re-score
+// service keeps a polling kernel on a stream, and with other objects' streams multiplexed onto the same few hardware
+// queues a launch it waits for could be queued behind another object's polling kernel
+std::atomic<int> g_liveOnDevice[64];
 
 }  // namespace
 
@@ -257,6 +263,7 @@ struct SearchDriver::Gpu {
     uint32_t* doneSignal = nullptr;
     uint32_t doneSeq = 0;
     bool svcUsed = false;
+    bool svcConcurrent = false;        // probed at construction: the service stream runs beside the auxiliary and work streams
     int svcForce = -1;
     int quietScans = 0;                // consecutive scans without a re-scored subject
     int64_t serviceLaunches = 0;
@@ -431,6 +438,13 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
         g->ovfCountCap = 1 + Gpu::kOvfLists;
         HIPCHECK(hipMalloc(&g->d_ovfCount, g->ovfCountCap * sizeof(int32_t)));
+        // the service's polling kernel must not share a hardware queue with the side launches the bulk launch waits for
+        if (g->svcStream) {
+            g->svcConcurrent = sw_streams_run_concurrently(g->ctx, g->svcStream, g->aux[0]) == 1 &&
+                               sw_streams_run_concurrently(g->ctx, g->svcStream, g->aux[1]) == 1 &&
+                               sw_streams_run_concurrently(g->ctx, g->svcStream, g->stream) == 1;
+        }
+        if (dev >= 0 && dev < 64) g_liveOnDevice[dev]++;
         gpus_.push_back(std::move(g));
     }
     if (gpus_.size() > 1)
@@ -485,6 +499,7 @@ SearchDriver::~SearchDriver() {
         if (g.copyStream) (void)hipStreamDestroy(g.copyStream);
         if (g.stream2) (void)hipStreamDestroy(g.stream2);
         if (g.ctx) sw_ctx_destroy(g.ctx);
+        if (g.device >= 0 && g.device < 64) g_liveOnDevice[g.device]--;
     }
     unregisterRanges();
 }
@@ -837,8 +852,9 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // to wait for it), a packed bulk run, and a query / subject size at which re-scoring one subject takes about as long as
     // a launch does at all (5 * 10^5 cells)
     const bool serviceWanted = g.svcForce >= 0 ? g.svcForce == 1 : g.quietScans < 3;
-    const bool useService = g.handshake && g.svcStream && slot < 0 && !second && serviceWanted && !runs.empty() && is_packed(runs[mainIdx].kind) &&
-                            double(g.qlen) * double(runs[mainIdx].maxlen) >= 5e5;
+    const bool aloneOnDevice = g.device < 0 || g.device >= 64 || g_liveOnDevice[g.device].load() == 1;
+    const bool useService = g.handshake && g.svcStream && g.svcConcurrent && aloneOnDevice && slot < 0 && !second && serviceWanted &&
+                            !runs.empty() && is_packed(runs[mainIdx].kind) && double(g.qlen) * double(runs[mainIdx].maxlen) >= 5e5;
     if (useService) {
         // the list starts empty (-1) for the compare-and-swap of its takers
         const LaunchRun& r = runs[mainIdx];

@@ -427,7 +427,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_SUBJECT")) ctx->lanes8_max_subject = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_CHECK_BOUNDS")) ctx->check_bounds = e[0] == '1';
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check (word 64) and the two of sw_streams_run_concurrently (72, 73)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, 2 * kWorkSlots * sizeof(uint32_t));
     if (e == hipSuccess) {
         uint32_t z[64] = {};
@@ -591,6 +591,36 @@ __global__ void reduce_windows_kernel(const float* __restrict__ win_scores, cons
     ids[pos] = (int32_t)(id_offset + pos);
 }
 }  // namespace
+
+namespace {
+__global__ void probe_wait_kernel(unsigned* flag, unsigned* saw, unsigned long long max_ticks) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned v = 0;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(8);
+    *saw = v;
+}
+__global__ void probe_set_kernel(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}  // namespace
+
+int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    SW_HIP(hipSetDevice(ctx->device));
+    // a kernel on stream A waits (at most ~5 ms) for a word that a kernel on stream B sets: it sees the word only if the
+    // second kernel could start while the first one was still running, i.e. if the runtime did not put both streams on
+    // one hardware queue
+    unsigned* words = reinterpret_cast<unsigned*>(ctx->d_zeros + 72);  // two spare words of the context's constant block
+    SW_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), static_cast<hipStream_t>(stream_a)));
+    SW_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream_a)));
+    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_a), words, words + 1, 500000ull);  // 100 MHz ticks
+    hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_b), words);
+    SW_HIP(hipGetLastError());
+    unsigned saw = 0;
+    SW_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream_b)));
+    SW_HIP(hipMemcpyAsync(&saw, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream_a)));
+    SW_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream_a)));
+    return saw ? 1 : 0;
+}
 
 int32_t sw_window_overlap(sw_ctx* ctx, int gop, int gex) {
     if (!ctx || !ctx->have_query || !ctx->have_matrix) return -1;

@@ -931,7 +931,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                     avail = __hip_atomic_load(p.count_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (avail > b * kSubjPerBatch) break;
                     const u32 done = __hip_atomic_load(p.done_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if ((int32_t)(done - p.done_value) >= 0 || spin > 9000000u) { b = nbatches; break; }  // (the bound, ~30 s: never hang a GPU on a lost flag)
+                    if ((int32_t)(done - p.done_value) >= 0 || spin > 600000u) { b = nbatches; break; }  // (the bound, ~2 s: never hang a GPU on a lost flag; what is left goes to the ordinary re-score launch)
                     __builtin_amdgcn_s_sleep(127);
                 }
                 avail = min(avail, n);

@@ -175,6 +175,12 @@ int sw_rescore_overflow_claim(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int
                               int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
                               int32_t packed_limit, int32_t* true_overflow_count, void* stream);
 
+/* 1 if a kernel on stream_b can start while a kernel on stream_a is still running, 0 if the runtime serialises the two
+ * streams (it multiplexes streams onto a few hardware queues; two kernels of one queue never overlap), < 0 on error.  A
+ * ~5 ms probe for callers that are about to keep a POLLING kernel on one of the streams (sw_rescore_service): behind a
+ * polling kernel on the same queue, the launch it waits for would never start.  Synchronises both streams. */
+int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b);
+
 /* Start handshake for launches that must run BESIDE a launch that fills the GPU (the reference gets that overlap from
  * its ten work streams, cudasw4.cuh:293,1745-1748; on this runtime a persistent grid that is dispatched first keeps every
  * workgroup slot until its end, and a small launch on another stream — the few giant subjects of partition 35 — then

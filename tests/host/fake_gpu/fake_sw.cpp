@@ -145,6 +145,7 @@ int sw_rescore_overflow_claim(sw_ctx* c, int kind, int32_t* ovf_pos, const int32
                               int64_t id_offset, void* t, size_t tb, int32_t lim, int32_t* cnt, void* s) {
     return sw_rescore_overflow_stat(c, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, m, gop, gex, scores, ids, id_offset, t, tb, lim, cnt, s);
 }
+int sw_streams_run_concurrently(sw_ctx*, void*, void*) { return 1; }
 int32_t sw_window_overlap(sw_ctx*, int, int) { return -1; }   // the fake's scores are no alignment scores: never cut
 int sw_reduce_windows(sw_ctx*, const float*, const int32_t*, const int32_t*, int32_t, float*, int32_t*, int64_t, void*) { return SW_OK; }
 int sw_plan_query(int, int32_t, int32_t* r, int32_t* ns) { if (r) *r = 8; if (ns) *ns = 1; return SW_OK; }

@@ -18,6 +18,9 @@ OUT=gpurun_out/profiles_$TAG
 RAW=gpurun_out/prof_raw_$TAG
 mkdir -p $OUT $RAW
 export TMPDIR=/tmp
+# rocprofv3 --pmc serialises kernels: a re-score service (a kernel that polls for a flag set BEHIND the bulk launch) would
+# sit there until its spin bound expires (5 s per query).  The profiled passes run without it; the timed bench has it.
+export CUDASW4_AMD_RESCORE_SERVICE=0
 BENCH="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-secondary --kernel-table $EXTRA"
 PASSES=${PASSES:-"stats traffic valu lds clock"}
 has() { case " $PASSES " in *" $1 "*) return 0;; *) return 1;; esac; }
