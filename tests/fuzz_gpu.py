@@ -120,6 +120,21 @@ def main(argv=None):
                 kw = dict(max_gpu_mem=int((float(r.uniform(0.1, 0.9)) * shard + 3 * (batch + 64) + 64) / 0.75) + 24 * n + 8,
                           max_batch_bytes=batch)
                 mode = "hybrid"
+            # round 4: long subjects as windows (forced on wherever the span bound cuts a subject, off, or left to the
+            # driver's estimate) and the re-score service (forced on / off / feedback; it only runs for a driver that is
+            # alone on its device)
+            wmode = int(r.integers(0, 3))
+            os.environ.pop("CUDASW4_AMD_WINDOWS", None)
+            os.environ.pop("CUDASW4_AMD_NO_WINDOWS", None)
+            if wmode == 0:
+                os.environ["CUDASW4_AMD_WINDOWS"] = "always"
+            elif wmode == 1:
+                os.environ["CUDASW4_AMD_NO_WINDOWS"] = "1"
+            smode = int(r.integers(0, 3))
+            os.environ.pop("CUDASW4_AMD_RESCORE_SERVICE", None)
+            if smode < 2:
+                os.environ["CUDASW4_AMD_RESCORE_SERVICE"] = str(smode)
+            mode += " windows=%s service=%s" % (["always", "off", "auto"][wmode], ["off", "on", "auto"][smode])
             d = driver.Driver(devices=devs, num_top=min(10, n), kinds=kinds, **kw)
             d.db_from_arrays(chars, offsets, lens)
             if r.integers(0, 3) == 0:

@@ -21,6 +21,10 @@ export TMPDIR=/tmp
 # rocprofv3 --pmc serialises kernels: a re-score service (a kernel that polls for a flag set BEHIND the bulk launch) would
 # sit there until its spin bound expires (5 s per query).  The profiled passes run without it; the timed bench has it.
 export CUDASW4_AMD_RESCORE_SERVICE=0
+# ... and without the start handshake: under the profiler's kernel serialisation a stream that waits for a device-side signal
+# (hipStreamWaitValue32) never got released (the Swiss-Prot-like passes hung until their timeout); with one kernel at a
+# time there is nothing to run beside anyway
+export CUDASW4_AMD_NO_HANDSHAKE=1
 BENCH="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-secondary --kernel-table $EXTRA"
 PASSES=${PASSES:-"stats traffic valu lds clock"}
 has() { case " $PASSES " in *" $1 "*) return 0;; *) return 1;; esac; }
