@@ -7,6 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#ifdef BINDING_ON_GPU   // the same block on real device buffers (tests/boundary/Makefile -> _build/binding_gpu)
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <fstream>
+#include <string>
+#endif
 
 #include "types.hpp"              // cudasw4::KernelType, BlosumType, BLOSUM62_20
 #include "length_partitions.hpp"  // cudasw4::getLengthPartitionBoundaries
@@ -40,6 +46,7 @@ struct GpuWorkingSet {  // cudasw4.cuh:251-480 (the members the patch uses)
     char* d_tempStorageHE; size_t numTempBytes;
 };
 
+#ifndef BINDING_ON_GPU
 int main() {
     const int numGpus = 1;
     std::vector<int> deviceIds{0};
@@ -59,15 +66,103 @@ int main() {
     const SequenceLengthT queryLength = 4;
     const int gop = -11, gex = -1, gpu = 0;
     void* stream = nullptr;
-    int32_t exclPs = 0;
     const int64_t globalOffsetOfBatch = 0;
     const int32_t maxOverflows = 0, maxLen = 0;
     const int64_t numResults = 0; const int results_per_query = 0;
     float* d_topS = nullptr; int32_t* d_topI = nullptr; void* d_tmp = nullptr; size_t tmpBytes = 0;
     static_assert(sizeof(size_t) == sizeof(uint64_t), "offsets are 64-bit");
+#else
+template <class T>
+static std::vector<T> read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { std::fprintf(stderr, "cannot read %s\n", path.c_str()); std::exit(2); }
+    const size_t bytes = size_t(f.tellg());
+    std::vector<T> v(bytes / sizeof(T));
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), std::streamsize(v.size() * sizeof(T)));
+    return v;
+}
+#define HIPOK(x) do { if ((x) != hipSuccess) { std::fprintf(stderr, "%s failed\n", #x); std::exit(3); } } while (0)
+template <class T>
+static T* to_device(const std::vector<T>& v, size_t extra = 0) {
+    T* d = nullptr;
+    HIPOK(hipMalloc(reinterpret_cast<void**>(&d), (v.size() + extra) * sizeof(T) + 64));
+    HIPOK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+// binding_gpu <dbdata prefix> <query = subject index>: the documented call sequence on the reference's dbdata files
+int main(int argc, char** argv) {
+    if (argc < 3) { std::fprintf(stderr, "usage: binding_gpu dbprefix subjectIndexAsQuery [DPX]\n"); return 2; }
+    const std::string prefix = argv[1];
+    const auto hChars = read_file<char>(prefix + "0chars");
+    const auto hOffsets = read_file<size_t>(prefix + "0offsets");
+    const auto hLengths = read_file<SequenceLengthT>(prefix + "0lengths");
+    const int numSubjects = int(hLengths.size());
+    const int qi = std::atoi(argv[2]);
+    const bool dpx = argc > 3;
+    const int numGpus = 1;
+    std::vector<int> deviceIds{0};
+    std::vector<void*> gpuStreams{nullptr};
+    const KernelTypeConfig kernelTypeConfig = dpx ? KernelTypeConfig{KernelType::DPXs16, KernelType::DPXs16, KernelType::DPXs32, KernelType::DPXs32}
+                                                  : KernelTypeConfig{KernelType::Half2, KernelType::Half2, KernelType::Float, KernelType::Float};
+    const int numLengthPartitions = SW_NUM_LENGTH_PARTITIONS;
+    const auto boundaries = cudasw4::getLengthPartitionBoundaries();
+    auto kindForPartition = [&](int lp) {
+        return int(lp < numLengthPartitions - 2 ? kernelTypeConfig.singlePassType
+                   : lp == numLengthPartitions - 2 ? kernelTypeConfig.manyPassType_small : kernelTypeConfig.manyPassType_large);
+    };
+    // the batch plan of a DB that is one batch: subjects per length partition (dbdata.cpp:91-115)
+    DeviceBatchCopyToPinnedPlan plan{std::vector<int>(36), std::vector<int>(36, 0)};
+    for (int i = 0; i < numSubjects; i++) {
+        int lp = 0;
+        while (lp < numLengthPartitions - 1 && hLengths[size_t(i)] > boundaries[size_t(lp)]) lp++;
+        plan.h_numPerPartition[size_t(lp)]++;
+    }
+    GpuWorkingSet ws{};
+    HIPOK(hipSetDevice(0));
+    const char* inputChars = to_device(hChars);
+    const size_t* inputOffsets = to_device(hOffsets);
+    const SequenceLengthT* inputLengths = to_device(hLengths);
+    HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_scores), size_t(numSubjects) * 4));
+    HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_ids), size_t(numSubjects) * 4));
+    HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_overflow_positions), size_t(numSubjects) * 4));
+    HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_overflow_number), 4));
+    HIPOK(hipMemset(ws.d_overflow_number, 0, 4));
+    ws.numTempBytes = size_t(256) << 20;
+    HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_tempStorageHE), ws.numTempBytes));
+    // the query: subject qi of the same files (already encoded with ConvertAA_20)
+    const int8_t* encodedQuery = reinterpret_cast<const int8_t*>(hChars.data() + (hOffsets[size_t(qi)] - hOffsets[0]));
+    const SequenceLengthT queryLength = hLengths[size_t(qi)];
+    const int gop = -11, gex = -1, gpu = 0;
+    void* stream = nullptr;
+    const int64_t globalOffsetOfBatch = 0;
+    const int32_t maxOverflows = numSubjects, maxLen = *std::max_element(hLengths.begin(), hLengths.end());
+    const int64_t numResults = numSubjects; const int results_per_query = 5;
+    float* d_topS = nullptr; int32_t* d_topI = nullptr; void* d_tmp = nullptr;
+    size_t tmpBytes = sw_topk_temp_bytes(numResults, results_per_query);
+    HIPOK(hipMalloc(reinterpret_cast<void**>(&d_topS), 64)); HIPOK(hipMalloc(reinterpret_cast<void**>(&d_topI), 64));
+    HIPOK(hipMalloc(&d_tmp, tmpBytes + 64));
+    static_assert(sizeof(size_t) == sizeof(uint64_t), "offsets are 64-bit");
+#endif
 
 //@@INTEGRATION_MD_PATCH@@
 
+#ifdef BINDING_ON_GPU
+    HIPOK(hipDeviceSynchronize());
+    std::vector<float> sc(static_cast<size_t>(numSubjects), 0.0f), ts(5, 0.0f);
+    std::vector<int32_t> ti(5, 0);
+    int novf = 0;
+    HIPOK(hipMemcpy(sc.data(), ws.d_scores, sc.size() * 4, hipMemcpyDeviceToHost));
+    HIPOK(hipMemcpy(ts.data(), d_topS, 20, hipMemcpyDeviceToHost));
+    HIPOK(hipMemcpy(ti.data(), d_topI, 20, hipMemcpyDeviceToHost));
+    HIPOK(hipMemcpy(&novf, ws.d_overflow_number, 4, hipMemcpyDeviceToHost));
+    std::printf("SCORES");
+    for (float v : sc) std::printf(" %d", int(v));
+    std::printf("\nTOP");
+    for (int i = 0; i < 5; i++) std::printf(" %d:%d", int(ts[size_t(i)]), ti[size_t(i)]);
+    std::printf("\nOVERFLOWS %d\n", novf);
+#endif
     for (auto* c : swCtx) sw_ctx_destroy(c);
     std::puts("binding ok");
     return 0;
