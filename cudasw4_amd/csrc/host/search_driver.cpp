@@ -159,6 +159,12 @@ struct TimedLaunch {
 };
 
 struct SearchDriver::Gpu {
+    // counted in g_liveOnDevice for as long as the object exists (also when a constructor of the driver throws half-way)
+    struct LiveToken {
+        int dev = -1;
+        void hold(int d) { if (d >= 0 && d < 64) { dev = d; g_liveOnDevice[d]++; } }
+        ~LiveToken() { if (dev >= 0) g_liveOnDevice[dev]--; }
+    } live;
     int index = 0;   // position in gpus_
     int device = 0;
     int numaNode = -1;  // of the device's PCI function; the GPU's worker thread (and the staging copies it starts) run there
@@ -444,7 +450,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
                                sw_streams_run_concurrently(g->ctx, g->svcStream, g->aux[1]) == 1 &&
                                sw_streams_run_concurrently(g->ctx, g->svcStream, g->stream) == 1;
         }
-        if (dev >= 0 && dev < 64) g_liveOnDevice[dev]++;
+        g->live.hold(dev);
         gpus_.push_back(std::move(g));
     }
     if (gpus_.size() > 1)
@@ -499,7 +505,6 @@ SearchDriver::~SearchDriver() {
         if (g.copyStream) (void)hipStreamDestroy(g.copyStream);
         if (g.stream2) (void)hipStreamDestroy(g.stream2);
         if (g.ctx) sw_ctx_destroy(g.ctx);
-        if (g.device >= 0 && g.device < 64) g_liveOnDevice[g.device]--;
     }
     unregisterRanges();
 }
