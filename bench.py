@@ -674,6 +674,9 @@ def measure(env, args, workload, want_cpu):
                        "db_subjects": total_subjects, "db_residues": int(total_residues), "queries": len(queries),
                        "kernel": kernel_name, "host": "libcudasw4_host.so (SearchDriver)",
                        "queries_in_flight": 2 if pipelined else 1,
+                       # queries of rank 0 whose bulk launch was gated on the dry signal of the query before it (tail
+                       # hand-over on small resident shards, include/cudasw4_amd_driver.h: swdrv_tail_overlaps), all steps
+                       "tail_overlaps": drv.tail_overlaps(),
                        "numa_node_rank0": env.numa_node, "numa_bound": env.numa_bound,
                        "resident": info["resident"], "residency": residency_of(info),
                        "cached_chars": info.get("cached_chars"), "shard_chars": info["chars"],

@@ -25,7 +25,7 @@ EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "s
            "sw_topk_temp_bytes",
            "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal",
            "sw_window_overlap", "sw_reduce_windows", "sw_rescore_service", "sw_rescore_overflow_claim",
-           "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently"]
+           "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_grid_reserve"]
 
 
 class SwError(RuntimeError):
@@ -67,6 +67,8 @@ def _load():
     L.sw_plan_query.argtypes = [ctypes.c_int, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.sw_check_letter_codes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     L.sw_set_start_signal.argtypes = [vp, vp]
+    L.sw_set_dry_signal.argtypes = [vp, vp, ctypes.c_uint32]
+    L.sw_set_grid_reserve.argtypes = [vp, i32]
     L.sw_window_overlap.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.sw_window_overlap.restype = i32
     L.sw_reduce_windows.argtypes = [vp, vp, vp, vp, i32, vp, vp, ctypes.c_int64, vp]

@@ -306,6 +306,12 @@ int64_t swdrv_service_launches(swdrv* d) {
     return n;
 }
 
+int64_t swdrv_tail_overlaps(swdrv* d) {
+    int64_t n = -1;
+    (void)guarded([&] { n = d->driver->tailOverlaps(); });
+    return n;
+}
+
 int swdrv_numa_node(swdrv* d, int gpu) {
     int node = -1;
     (void)guarded([&] { node = d->driver->numaNode(gpu); });

@@ -275,6 +275,69 @@ struct SearchDriver::Gpu {
     int64_t serviceLaunches = 0;
     double rescoredEma = 8.0;          // recent re-scored subjects per scan: sizes the service (2, 4 or 8 workgroups)
     int serviceWorkgroups() const { return rescoredEma < 8.0 ? 2 : rescoredEma < 64.0 ? 4 : 8; }
+    // Tail hand-over between two queries in flight (include/cudasw4_amd.h: sw_set_dry_signal).  A query that is submitted
+    // while the one before is still running goes to the OTHER lane: a second context (its own profile and work counters),
+    // the second work stream with its scratch, and second score / id / overflow / top-K arrays (Lane below; the first set is
+    // the fields above, LaneGuard exchanges the two for the duration of an enqueue).  Its bulk launch waits on its stream
+    // for the value the bulk launch of the query before stores when its work counter runs dry, so its workgroups take the
+    // slots that launch frees one by one; both bulk grids leave kLaneReserve slots free for the small launches around them
+    // (profile build, re-score, top-K).  Resident shards of at most kLaneMaxRounds rounds of workgroups only: on a large
+    // shard the last round is a small part of the scan.  CUDASW4_AMD_TAIL_OVERLAP=0 turns it off, =1 lifts the size rule.
+    struct Lane {
+        sw_ctx* ctx = nullptr;
+        float* d_scores = nullptr;
+        int32_t* d_ids = nullptr;
+        int32_t* d_ovfPos = nullptr;
+        int32_t* d_ovfCount = nullptr;
+        size_t ovfCountCap = 0;
+        hipEvent_t scanStartEv = nullptr;
+        void* d_topkTemp = nullptr;
+        size_t topkTempBytes = 0;
+        float* d_topS = nullptr;
+        int32_t* d_topI = nullptr;
+        int topCapacity = 0;
+    } lane1;
+    static constexpr int kLaneReserve = 16;
+    static constexpr size_t kLaneMaxRounds = 16;
+    int laneForce = -1;                // CUDASW4_AMD_TAIL_OVERLAP
+    bool lanesConcurrent = false;      // probed with the second work stream: the two work streams run beside each other
+    bool lanesProbed = false;
+    bool lanesFailed = false;          // the second set could not be allocated: stay on one lane
+    bool lane1Ready = false;           // lane1's per-DB arrays exist
+    bool laneSwapped = false;          // the fields above currently hold lane 1's set (inside an enqueue only)
+    bool laneActive = false;           // the query being enqueued overlaps the one before
+    int lastLane = 0;                  // lane of the query enqueued last
+    int resultLane = 0;                // lane of the query collected last (lastScores)
+    uint32_t* drySignal = nullptr;     // signal memory
+    uint32_t drySeq = 0;               // value the bulk launch armed last stores
+    uint32_t lastArmedSeq = 0;         // ... of the query enqueued last (0: it armed none)
+    uint32_t waitDry = 0;              // the bulk launch being enqueued waits for this value (0: no wait)
+    int64_t laneOverlaps = 0;          // queries whose bulk launch was gated on the one before
+    void swapLane() {
+        std::swap(ctx, lane1.ctx);
+        std::swap(stream, stream2);
+        std::swap(d_temp[0], d_temp[kAux + 1]);
+        std::swap(tempBytes[0], tempBytes[kAux + 1]);
+        std::swap(forkEvent[0], forkEvent[1]);
+        std::swap(d_scores, lane1.d_scores);
+        std::swap(d_ids, lane1.d_ids);
+        std::swap(d_ovfPos, lane1.d_ovfPos);
+        std::swap(d_ovfCount, lane1.d_ovfCount);
+        std::swap(ovfCountCap, lane1.ovfCountCap);
+        std::swap(scanStartEv, lane1.scanStartEv);
+        std::swap(d_topkTemp, lane1.d_topkTemp);
+        std::swap(topkTempBytes, lane1.topkTempBytes);
+        std::swap(d_topS, lane1.d_topS);
+        std::swap(d_topI, lane1.d_topI);
+        std::swap(topCapacity, lane1.topCapacity);
+        laneSwapped = !laneSwapped;
+    }
+    struct LaneGuard {
+        Gpu& g;
+        bool swapped;
+        LaneGuard(Gpu& gpu, int lane) : g(gpu), swapped(lane == 1) { if (swapped) g.swapLane(); }
+        ~LaneGuard() { if (swapped) g.swapLane(); }
+    };
     size_t tempCap = SIZE_MAX;  // plan_residency: what each of them may grow to inside the memory limit
     static_assert(kAux + 3 == kTempStreams, "plan_residency budgets the scratch of this many streams");
     void* d_topkTemp = nullptr;
@@ -294,6 +357,7 @@ struct SearchDriver::Gpu {
         size_t ncounters = 0;
         int top = 0;
         bool used = false;         // this GPU took part in the scan (its shard is not empty)
+        int lane = 0;              // whose score arrays the scan filled (Gpu::Lane)
     };
     ResultSlot res[SearchDriver::kMaxInFlight];
     int lastTop = 0;
@@ -434,8 +498,15 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
                     *g->doneSignal = 0;
                     HIPCHECK(hipStreamCreateWithPriority(&g->svcStream, hipStreamNonBlocking, prioHigh));
                     HIPCHECK(hipEventCreateWithFlags(&g->svcJoin, hipEventDisableTiming));
+                    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g->drySignal), 8, hipMallocSignalMemory) != hipSuccess) {
+                        (void)hipGetLastError();
+                        g->drySignal = nullptr;
+                    } else {
+                        *g->drySignal = 0;
+                    }
                 }
             }
+            if (const char* e = std::getenv("CUDASW4_AMD_TAIL_OVERLAP")) g->laneForce = e[0] == '1' ? 1 : 0;
             if (const char* e = std::getenv("CUDASW4_AMD_RESCORE_SERVICE")) g->svcForce = e[0] == '1' ? 1 : 0;
         }
         if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
@@ -475,6 +546,12 @@ SearchDriver::~SearchDriver() {
         (void)hipHostFree(g.h_pad);
         if (g.startSignal) (void)hipFree(g.startSignal);
         if (g.doneSignal) (void)hipFree(g.doneSignal);
+        if (g.drySignal) (void)hipFree(g.drySignal);
+        if (g.laneSwapped) g.swapLane();
+        (void)hipFree(g.lane1.d_scores); (void)hipFree(g.lane1.d_ids); (void)hipFree(g.lane1.d_ovfPos); (void)hipFree(g.lane1.d_ovfCount);
+        (void)hipFree(g.lane1.d_topkTemp); (void)hipFree(g.lane1.d_topS); (void)hipFree(g.lane1.d_topI);
+        if (g.lane1.scanStartEv) (void)hipEventDestroy(g.lane1.scanStartEv);
+        if (g.lane1.ctx) sw_ctx_destroy(g.lane1.ctx);
         if (g.svcStream) (void)hipStreamDestroy(g.svcStream);
         if (g.svcJoin) (void)hipEventDestroy(g.svcJoin);
         for (auto& per : g.winBuf)
@@ -607,6 +684,11 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
 
         const size_t n = std::max<size_t>(g.numLocal, 1);
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos);
+        (void)hipFree(g.lane1.d_scores); (void)hipFree(g.lane1.d_ids); (void)hipFree(g.lane1.d_ovfPos);
+        g.lane1.d_scores = nullptr; g.lane1.d_ids = nullptr; g.lane1.d_ovfPos = nullptr;
+        g.lane1Ready = false;
+        g.lanesFailed = false;
+        g.lastLane = g.resultLane = 0;
         (void)hipFree(g.d_offsets); (void)hipFree(g.d_lengths); (void)hipFree(g.d_chars);
         g.d_chars = nullptr;
         for (int i = 0; i < Gpu::kSlots; i++) { (void)hipFree(g.d_staging[i]); g.d_staging[i] = nullptr; }
@@ -858,7 +940,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // a launch does at all (5 * 10^5 cells)
     const bool serviceWanted = g.svcForce >= 0 ? g.svcForce == 1 : g.quietScans < 3;
     const bool aloneOnDevice = g.device < 0 || g.device >= 64 || g_liveOnDevice[g.device].load() == 1;
-    const bool useService = g.handshake && g.svcStream && g.svcConcurrent && aloneOnDevice && slot < 0 && !second && serviceWanted &&
+    const bool useService = g.handshake && g.svcStream && g.svcConcurrent && aloneOnDevice && slot < 0 && !second && serviceWanted && !g.laneActive &&
                             !runs.empty() && is_packed(runs[mainIdx].kind) && double(g.qlen) * double(runs[mainIdx].maxlen) >= 5e5;
     if (useService) {
         // the list starts empty (-1) for the compare-and-swap of its takers
@@ -1068,8 +1150,19 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     }
     // the bulk launch goes in only after the side launches hold their workgroup slots
     if (anySide) HIPCHECK(hipStreamWaitValue32(work, g.startSignal, g.sideLaunches, hipStreamWaitValueGte, 0xffffffffu));
+    // ... and, when the query before is still running on the other lane, only when that one's work counter has run dry
+    if (g.waitDry && slot < 0 && !second) {
+        HIPCHECK(hipStreamWaitValue32(work, g.drySignal, g.waitDry, hipStreamWaitValueGte, 0xffffffffu));
+        g.waitDry = 0;
+        g.laneOverlaps++;
+    }
     for (size_t i = 0; i < runs.size(); i++)
         if (streamOf[i] < 0) {
+            if (i == mainIdx && g.drySignal && g.handshake && slot < 0 && !second) {
+                // whoever is submitted while this query runs is gated on this launch running dry (Gpu::Lane)
+                SWCHECK(sw_set_dry_signal(g.ctx, g.drySignal, ++g.drySeq));
+                g.lastArmedSeq = g.drySeq;
+            }
             launch(i, work, workTemp);
             // the service leaves once the list's producer has finished
             if (useService && i == mainIdx) HIPCHECK(hipStreamWriteValue32(work, g.doneSignal, g.doneSeq, 0));
@@ -1241,18 +1334,73 @@ void SearchDriver::scanStreamed(Gpu& g) {
 // result slot `slot` and finishOnGpu picks them up.  The scans of consecutive queries are ordered by the streams alone:
 // the query upload, the zeroed counters and the first launches of query i + 1 queue up behind the top-K and the copies of
 // query i on the work stream, the auxiliary streams fork from it and join it again before the top-K.
-void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
+// The second lane's resources (Gpu::Lane), created with the first query that can use them.  False: stay on one lane.
+bool SearchDriver::prepareLane(Gpu& g) {
+    if (g.lanesFailed || !g.handshake || !g.drySignal || g.laneForce == 0) return false;
+    if (g.cacheBegin != 0 || !g.batches.empty() || !g.cacheFilled) return false;  // resident shards only
+    if (g.laneForce != 1) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g.device) != hipSuccess || cus <= 0) return false;
+        // a round: three workgroups per CU, 16 groups of two subjects each
+        if (g.numLocal > Gpu::kLaneMaxRounds * size_t(cus) * 3 * 32) return false;
+    }
+    try {
+        if (!g.stream2) HIPCHECK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+        if (!g.lanesProbed) {
+            g.lanesConcurrent = sw_streams_run_concurrently(g.ctx, g.stream, g.stream2) == 1;
+            g.lanesProbed = true;
+        }
+        if (!g.lanesConcurrent) { g.lanesFailed = true; return false; }
+        if (!g.lane1.ctx) {
+            SWCHECK(sw_ctx_create(g.device, &g.lane1.ctx));
+            SWCHECK(sw_set_matrix(g.lane1.ctx, matrix_.m.data(), matrix_.dim));
+        }
+        if (!g.lane1.scanStartEv) HIPCHECK(hipEventCreate(&g.lane1.scanStartEv));
+        if (!g.lane1.d_ovfCount) {
+            g.lane1.ovfCountCap = 1 + Gpu::kOvfLists;
+            HIPCHECK(hipMalloc(&g.lane1.d_ovfCount, g.lane1.ovfCountCap * sizeof(int32_t)));
+        }
+        if (!g.lane1Ready) {
+            const size_t n = std::max<size_t>(g.numLocal, 1);
+            HIPCHECK(hipMalloc(&g.lane1.d_scores, n * sizeof(float)));
+            HIPCHECK(hipMalloc(&g.lane1.d_ids, n * sizeof(int32_t)));
+            HIPCHECK(hipMalloc(&g.lane1.d_ovfPos, n * sizeof(int32_t)));
+            g.lane1Ready = true;
+        }
+    } catch (const std::exception&) {
+        (void)hipGetLastError();
+        (void)hipFree(g.lane1.d_scores); (void)hipFree(g.lane1.d_ids); (void)hipFree(g.lane1.d_ovfPos);
+        g.lane1.d_scores = nullptr; g.lane1.d_ids = nullptr; g.lane1.d_ovfPos = nullptr;
+        g.lane1Ready = false;
+        g.lanesFailed = true;
+        return false;
+    }
+    return true;
+}
+
+void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bool inFlight) {
     Gpu::ResultSlot& rs = g.res[slot];
     rs.used = false;
     rs.top = 0;
     rs.ncounters = 0;
+    rs.lane = 0;
     g.spanBegin = g.spanEnd = now_seconds() - scanT0_;
     if (g.numLocal == 0) return;
     g.use();
+    // a query submitted while the one before is running takes the other lane and is gated on that one's dry signal
+    const bool overlap = inFlight && prepareLane(g);
+    const int lane = overlap ? 1 - g.lastLane : 0;
+    Gpu::LaneGuard laneGuard(g, lane);
+    g.laneActive = overlap;
+    g.waitDry = overlap ? g.lastArmedSeq : 0;
+    g.lastArmedSeq = 0;
+    g.lastLane = lane;
+    rs.lane = lane;
     try {
         if (g.badCodes) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
         g.qlen = queryLength;
         if (!g.cacheFilled) uploadShard(g);  // the first query pays the upload unless --uploadFull
+        SWCHECK(sw_set_grid_reserve(g.ctx, overlap ? Gpu::kLaneReserve : 0));
         SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
         // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
         // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed)
@@ -1316,6 +1464,9 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot) {
         // Work may still be queued on the auxiliary, second and copy streams, and the bookkeeping of who waits for
         // whom is half-updated: drain the device and forget it, so that a later scan starts from a clean state
         if (g.doneSignal) *g.doneSignal = g.doneSeq;   // a re-score service that is still polling leaves now
+        if (g.drySignal) *g.drySignal = g.drySeq;      // ... and so does a bulk launch that waits for a launch that never went in
+        g.waitDry = 0;
+        g.lastArmedSeq = 0;
         (void)hipDeviceSynchronize();
         (void)hipGetLastError();
         for (bool& u : g.auxUsed) u = false;
@@ -1344,6 +1495,7 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot) {
     g.lastRescored = 0;
     g.lastTopS = rs.h_topS;
     g.lastTopI = rs.h_topI;
+    g.resultLane = rs.lane;
     if (!rs.used) return;
     g.use();
     HIPCHECK(hipEventSynchronize(rs.done));
@@ -1381,7 +1533,8 @@ void SearchDriver::submit(const char* query, int32_t queryLength) {
     ps.t0 = now_seconds();
     if (pendingCount_ == 0) scanT0_ = ps.t0;
     const int slot = ps.slot, k = ps.k;
-    forEachGpu([this, queryLength, k, slot](Gpu& g) { enqueueOnGpu(g, queryLength, k, slot); });
+    const bool inFlight = pendingCount_ > 0;
+    forEachGpu([this, queryLength, k, slot, inFlight](Gpu& g) { enqueueOnGpu(g, queryLength, k, slot, inFlight); });
     nextSlot_ = (nextSlot_ + 1) % kMaxInFlight;
     pending_[(pendingHead_ + pendingCount_) % kMaxInFlight] = ps;
     pendingCount_++;
@@ -1509,6 +1662,12 @@ void SearchDriver::windowStats(int64_t* launches, int64_t* windows) const {
     if (launches) *launches = l;
     if (windows) *windows = w;
 }
+int64_t SearchDriver::tailOverlaps() const {
+    int64_t n = 0;
+    for (auto& gp : gpus_) n += gp->laneOverlaps;
+    return n;
+}
+
 int64_t SearchDriver::serviceLaunches() const {
     int64_t n = 0;
     for (auto& gp : gpus_) n += gp->serviceLaunches;
@@ -1524,7 +1683,7 @@ void SearchDriver::lastScores(int gpu, float* scores, int64_t* ids) {
     Gpu& g = *gpus_.at(size_t(gpu));
     if (!g.numLocal) return;
     g.use();
-    HIPCHECK(hipMemcpy(scores, g.d_scores, g.numLocal * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(scores, g.resultLane == 1 ? g.lane1.d_scores : g.d_scores, g.numLocal * sizeof(float), hipMemcpyDeviceToHost));
     for (int p = 0; p < kNumLengthPartitions; p++)
         for (size_t i = 0; i < g.ranges[p].size(); i++) ids[g.localBegin[p] + i] = idBase_ + int64_t(g.ranges[p].begin + i);
 }

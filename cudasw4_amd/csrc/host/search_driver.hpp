@@ -212,6 +212,9 @@ public:
     // windows they scanned, since the driver was created
     void windowStats(int64_t* launches, int64_t* windows) const;
     int64_t serviceLaunches() const;   // re-score service launches (sw_rescore_service) since the driver was created
+    // queries whose bulk launch was gated on the dry signal of the query before it (tail hand-over between two queries in
+    // flight: submit() while a query is pending, resident shards of a few rounds of workgroups), since the driver was created
+    int64_t tailOverlaps() const;
     // every score of the last scan on `gpu` (the CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756) with
     // the global id of each position; both arrays hold numLocal(gpu) entries
     void lastScores(int gpu, float* scores, int64_t* ids);
@@ -227,7 +230,8 @@ private:
     struct Worker;
     void uploadShard(Gpu& g);
     void scanStreamed(Gpu& g);
-    void enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot);
+    void enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bool inFlight);
+    bool prepareLane(Gpu& g);
     void finishOnGpu(Gpu& g, int slot);
     void registerStreamedRanges();
     void unregisterRanges();

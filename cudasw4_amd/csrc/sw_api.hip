@@ -134,6 +134,9 @@ struct sw_ctx {
     uint32_t* d_work = nullptr;  // kWorkSlots pairs (batch counter of the dynamic batch distribution, started workgroups), one per launch in flight
     uint32_t work_next = 0;
     uint32_t* start_signal = nullptr;  // sw_set_start_signal: one-shot, consumed by the next scan / re-score launch
+    uint32_t* dry_signal = nullptr;    // sw_set_dry_signal: one-shot as well
+    uint32_t dry_value = 0;
+    int grid_reserve = 0;              // sw_set_grid_reserve: workgroup slots a scan launch leaves free (until changed)
     int grid_mult = 4;           // persistent workgroups per CU (CUDASW4_AMD_GRID_MULT overrides, for experiments)
     bool have_matrix = false;
     int8_t* d_query = nullptr;
@@ -277,6 +280,8 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // cancels it: nothing will fire, the caller must not wait)
     uint32_t* const start_signal = ctx->start_signal;
     ctx->start_signal = nullptr;
+    uint32_t* const dry_signal = ctx->dry_signal;
+    ctx->dry_signal = nullptr;
     const swk::KindLaunch* kl = kind_launch(kind);
     if (!kl) return fail(SW_ERR_INVALID, "unknown kind");
     if (n < 0 || max_subject_len < 0) return fail(SW_ERR_INVALID, "negative count or length");
@@ -389,7 +394,11 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     // launch, the first 64 of a larger one (its remaining workgroups are next in its queue when the waiter is released)
     p.start_signal = start_signal;
     p.start_quorum = (uint32_t)std::min(grid, 64);
-    SW_HIP(kl->scan(pl.rows, lanes, multi, offs, grid, stream, p));
+    p.dry_signal = dry_signal;
+    p.dry_value = ctx->dry_value;
+    // (the launcher caps the grid at the kernel's resident workgroups minus the reserve and the quorum with it)
+    const int reserve = (list.service_workgroups > 0 || list.claim) ? 0 : ctx->grid_reserve;
+    SW_HIP(kl->scan(pl.rows, lanes, multi, offs, grid, reserve, stream, p));
     return SW_OK;
 }
 
@@ -575,6 +584,20 @@ int sw_check_letter_codes(sw_ctx* ctx, const int8_t* chars, size_t n, int32_t* b
 int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal) {
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
     ctx->start_signal = signal;
+    return SW_OK;
+}
+
+int sw_set_dry_signal(sw_ctx* ctx, uint32_t* signal, uint32_t value) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    ctx->dry_signal = signal;
+    ctx->dry_value = value;
+    return SW_OK;
+}
+
+int sw_set_grid_reserve(sw_ctx* ctx, int32_t workgroups) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    if (workgroups < 0) return fail(SW_ERR_INVALID, "negative reserve");
+    ctx->grid_reserve = workgroups;
     return SW_OK;
 }
 

@@ -401,6 +401,13 @@ struct ScanParams {
     int32_t service;
     const u32* done_flag;
     u32 done_value;
+    // Tail hand-over (sw_set_dry_signal): the workgroup that finds the work counter dry — the first one that has nothing
+    // left to take, while the others are still busy with their last batches — stores dry_value in *dry_signal (system
+    // scope, signal memory).  A caller that ordered the NEXT query's launch behind that value on another stream gets a
+    // grid that fills the slots this launch's workgroups leave one by one, instead of one that shares the CUs with it
+    // from the start.  nullptr: none.
+    u32* dry_signal;
+    u32 dry_value;
 };
 
 constexpr int32_t kListEmpty = -1, kListTaken = -2;
@@ -936,6 +943,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 }
                 avail = min(avail, n);
             }
+            if (b == nbatches && p.dry_signal) __hip_atomic_store(p.dry_signal, p.dry_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             next_batch = b;
             batch_avail = avail;
         }

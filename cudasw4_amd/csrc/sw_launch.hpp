@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "sw_dp_kernel.hpp"
 
@@ -41,7 +42,9 @@ constexpr int max_rows(int kind, int lanes) {
 struct KindLaunch {
     // return hipSuccess or the launch error; (R, lanes) must be a compiled combination, else hipErrorInvalidValue
     // offs: the column-offset form of the recurrence (sw_dp_kernel.hpp: dp_step<OFFS>); needs a profile built with shift = a
-    hipError_t (*scan)(int R, int lanes, bool multi, bool offs, int grid, hipStream_t stream, const ScanParams& p);
+    // reserve > 0: the grid is capped at the workgroups the device holds of this kernel at once, minus `reserve` (slots left
+    // free for small launches of other streams while the persistent grid runs: sw_set_grid_reserve)
+    hipError_t (*scan)(int R, int lanes, bool multi, bool offs, int grid, int reserve, hipStream_t stream, const ScanParams& p);
     hipError_t (*profile)(int R, int lanes, const int8_t* query, int32_t qlen, const int8_t* matrix21, int32_t pad_row,
                           int32_t nstripes, unsigned char* out, int32_t shift, hipStream_t stream);
     size_t (*tile_bytes)(int R, int lanes);
@@ -57,8 +60,45 @@ const KindLaunch& launch_i32();
 const KindLaunch& launch_f32();
 
 // ---- helpers used by the kind TUs ----
+// workgroups of `kernel` the current device holds at once (asked once per instantiation and device); 0: unknown
+template <class K>
+int resident_workgroups(K kernel) {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu <= 0 || cus <= 0) {
+            (void)hipGetLastError();
+            v = -1;
+        } else {
+            v = per_cu * cus;
+        }
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0 ? v : 0;
+}
+
+template <class K>
+hipError_t launch_scan_k(K kernel, int grid, int reserve, hipStream_t stream, const ScanParams& p) {
+    if (reserve > 0) {
+        const int resident = resident_workgroups(kernel);
+        if (resident > 0 && grid > resident - reserve) {
+            ScanParams q = p;
+            grid = resident - reserve > 1 ? resident - reserve : 1;
+            if (q.start_quorum > (u32)grid) q.start_quorum = (u32)grid;
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, stream, q);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <int KIND, int R, int LANES, bool OFFS>
-hipError_t launch_scan_ro(bool multi, int grid, hipStream_t stream, const ScanParams& p) {
+hipError_t launch_scan_ro(bool multi, int grid, int reserve, hipStream_t stream, const ScanParams& p) {
     // a query that needs more than one stripe always gets R > max/2 from the planner
     constexpr int kMaxR = max_rows(KIND, LANES);
     if constexpr (R > kMaxR) {
@@ -66,21 +106,20 @@ hipError_t launch_scan_ro(bool multi, int grid, hipStream_t stream, const ScanPa
     } else {
         if (multi) {
             if constexpr (2 * R > kMaxR) {
-                hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, true, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
+                return launch_scan_k(sw_scan_kernel<KIND, R, LANES, true, OFFS>, grid, reserve, stream, p);
             } else {
                 return hipErrorInvalidValue;
             }
         } else {
-            hipLaunchKernelGGL((sw_scan_kernel<KIND, R, LANES, false, OFFS>), dim3(grid), dim3(kThreads), 0, stream, p);
+            return launch_scan_k(sw_scan_kernel<KIND, R, LANES, false, OFFS>, grid, reserve, stream, p);
         }
-        return hipGetLastError();
     }
 }
 
 template <int KIND, int R, int LANES>
-hipError_t launch_scan_r(bool multi, bool offs, int grid, hipStream_t stream, const ScanParams& p) {
-    return offs ? launch_scan_ro<KIND, R, LANES, true>(multi, grid, stream, p)
-                : launch_scan_ro<KIND, R, LANES, false>(multi, grid, stream, p);
+hipError_t launch_scan_r(bool multi, bool offs, int grid, int reserve, hipStream_t stream, const ScanParams& p) {
+    return offs ? launch_scan_ro<KIND, R, LANES, true>(multi, grid, reserve, stream, p)
+                : launch_scan_ro<KIND, R, LANES, false>(multi, grid, reserve, stream, p);
 }
 
 template <int KIND, int R, int LANES>
@@ -110,7 +149,7 @@ constexpr size_t tile_bytes_r() {
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
 #define SWK_DEFINE_KIND(FN, KIND, FOR_EACH_R)                                                                      \
-    static hipError_t FN##_scan(int R, int lanes, bool multi, bool offs, int grid, hipStream_t stream,            \
+    static hipError_t FN##_scan(int R, int lanes, bool multi, bool offs, int grid, int reserve, hipStream_t stream, \
                                 const ScanParams& p) {                                                              \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN64_##KIND) } }                                 \

@@ -21,7 +21,8 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_batch_intervals", "swdrv_gpu_spans", "swdrv_plan_runs", "swdrv_shard_ranges", "swdrv_matrix25",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
            "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency", "swdrv_numa_node", "swdrv_device_of",
-           "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats", "swdrv_service_launches"]
+           "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats", "swdrv_service_launches",
+           "swdrv_tail_overlaps"]
 
 
 class DriverError(RuntimeError):
@@ -92,6 +93,8 @@ def _load():
     L.swdrv_numa_node.argtypes = [vp, ctypes.c_int]
     L.swdrv_service_launches.restype = ctypes.c_int64
     L.swdrv_service_launches.argtypes = [vp]
+    L.swdrv_tail_overlaps.restype = ctypes.c_int64
+    L.swdrv_tail_overlaps.argtypes = [vp]
     L.swdrv_window_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     L.swdrv_device_of.argtypes = [vp, ctypes.c_int]
     L.swdrv_bind_to_numa_node.argtypes = [ctypes.c_int]
@@ -304,6 +307,10 @@ class Driver:
     def service_launches(self):
         """Re-score service launches since the driver was created."""
         return int(lib.swdrv_service_launches(self.handle))
+
+    def tail_overlaps(self):
+        """Queries whose bulk launch was gated on the dry signal of the query before (swdrv_tail_overlaps)."""
+        return int(lib.swdrv_tail_overlaps(self.handle))
 
     def numa_node(self, gpu=0):
         """NUMA node of the GPU's PCI function (-1: unknown)."""

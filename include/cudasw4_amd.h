@@ -192,6 +192,20 @@ int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b);
  * has n == 0 (nothing is enqueued, nothing will fire: do not wait for it). */
 int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
 
+/* Tail hand-over between consecutive queries.  The reference scans one query at a time (main.cu:217-260); on a small
+ * shard (what each of N GPUs gets from a DB) the last, partly filled round of a query's persistent grid leaves most of
+ * the GPU idle.  sw_set_dry_signal is one-shot like sw_set_start_signal: the NEXT sw_scan_partition launch of this
+ * context stores `value` in *signal (system scope; signal memory) when its work counter runs dry — the first workgroup
+ * finds nothing left to take while the others finish their last batches.  The caller orders the next query's bulk launch
+ * (another context, stream, score array and scratch) behind that value with hipStreamWaitValue32(..., Gte), so that its
+ * workgroups take the slots this launch frees one by one; launched without the gate, the two grids would share the CUs
+ * for their whole duration.  Values must increase from launch to launch.  A launch that fails or has n == 0 never fires.
+ * sw_set_grid_reserve (sticky): scan launches of this context leave `workgroups` of the slots the device has for their
+ * kernel free (the grid is capped at resident - reserve), so that the small launches of the query before — re-score,
+ * top-K — and of the query after — profile build — find a slot while a persistent grid holds the rest.  0: none. */
+int sw_set_dry_signal(sw_ctx* ctx, uint32_t* signal, uint32_t value);
+int sw_set_grid_reserve(sw_ctx* ctx, int32_t workgroups);
+
 /* Long subjects against SHORT queries: exact windowing.  An alignment with a positive score of a query of Q residues spans
  * fewer than W = Q + Q * max(matrix) / min(|gop|, |gex|) + 1 subject columns (every gap column costs at least the
  * cheaper gap score, the aligned columns are worth at most Q * max(matrix)), so the DP value of any cell is already exact

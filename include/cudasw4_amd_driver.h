@@ -121,6 +121,13 @@ int swdrv_window_stats(swdrv* d, int64_t* launches, int64_t* windows);
  * re-scored while it was being filled.  CUDASW4_AMD_RESCORE_SERVICE=0|1 forces the service off / on; by default it runs
  * while recent scans re-scored anything. */
 int64_t swdrv_service_launches(swdrv* d);
+/* Tail hand-over between two queries in flight (include/cudasw4_amd.h: sw_set_dry_signal): a query submitted with
+ * swdrv_submit while the one before is still pending runs on a second lane of the GPU (context, work stream, score arrays)
+ * and its bulk launch starts when the earlier one's work counter runs dry, filling the slots its last round leaves idle —
+ * on resident shards of a few rounds of workgroups (what each of N GPUs gets from a small DB); results are those of
+ * swdrv_scan.  Returns the queries gated that way since swdrv_create.  CUDASW4_AMD_TAIL_OVERLAP=0 turns the hand-over
+ * off, =1 lifts the shard-size rule. */
+int64_t swdrv_tail_overlaps(swdrv* d);
 
 /* NUMA placement: the node of the gpu-th GPU's PCI function (-1: unknown) and its HIP device ordinal.  In-process
  * multi-GPU drivers run each GPU's worker thread on that node themselves; a one-process-per-GPU caller binds its own

@@ -68,7 +68,10 @@ hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "fake hip error"; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
-hipError_t hipDeviceGetAttribute(int* pi, hipDeviceAttribute_t attr, int) { *pi = attr == hipDeviceAttributeCanUseStreamWaitValue ? 1 : 0; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* pi, hipDeviceAttribute_t attr, int) {
+    *pi = attr == hipDeviceAttributeCanUseStreamWaitValue ? 1 : attr == hipDeviceAttributeMultiprocessorCount ? 256 : 0;
+    return hipSuccess;
+}
 hipError_t hipDeviceGetPCIBusId(char* s, int len, int device) { snprintf(s, size_t(len), "0000:%02x:00.0", 0xc1 + device * 0x10); return hipSuccess; }
 hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 1; *hi = -1; return hipSuccess; }
 hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = size_t(64) << 30; *t = size_t(64) << 30; return hipSuccess; }

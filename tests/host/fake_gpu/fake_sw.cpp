@@ -19,7 +19,7 @@ extern "C" int fake_hip_current_device();
 namespace {
 std::string g_err;
 int g_bad_owner = 0;
-long g_scans[2] = {0, 0}, g_rescored[2] = {0, 0};
+long g_scans[2] = {0, 0}, g_rescored[2] = {0, 0}, g_dry[2] = {0, 0};
 }
 
 struct sw_ctx {
@@ -27,6 +27,9 @@ struct sw_ctx {
     std::vector<int8_t> query;
     bool have_matrix = false;
     uint32_t* start_signal = nullptr;
+    uint32_t* dry_signal = nullptr;
+    uint32_t dry_value = 0;
+    int grid_reserve = 0;
 };
 
 namespace {
@@ -63,6 +66,9 @@ int sw_set_matrix(sw_ctx* c, const int8_t*, int) { c->have_matrix = true; return
 int sw_set_query(sw_ctx* c, const int8_t* q, int32_t qlen, void*) { (void)hipSetDevice(c->device); c->query.assign(q, q + qlen); return SW_OK; }
 size_t sw_scan_temp_bytes(sw_ctx*, int, int, int32_t, int32_t) { return 0; }
 int sw_set_start_signal(sw_ctx* c, uint32_t* s) { c->start_signal = s; return SW_OK; }
+int sw_set_dry_signal(sw_ctx* c, uint32_t* s, uint32_t v) { c->dry_signal = s; c->dry_value = v; return SW_OK; }
+int sw_set_grid_reserve(sw_ctx* c, int32_t n) { c->grid_reserve = n; return SW_OK; }
+long fake_sw_dry_signals(int device) { return g_dry[device]; }
 
 int sw_scan_partition(sw_ctx* c, int kind, int, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
                       int32_t first_pos, int32_t n, int32_t max_subject_len, int, int, float* scores, int32_t* ids,
@@ -71,8 +77,11 @@ int sw_scan_partition(sw_ctx* c, int kind, int, const int8_t* chars, const uint6
     owned(c, chars); owned(c, offsets); owned(c, lengths); owned(c, scores); owned(c, ids); owned(c, ovf_pos); owned(c, ovf_count);
     uint32_t* sig = c->start_signal;
     c->start_signal = nullptr;
+    uint32_t* dry = c->dry_signal;
+    c->dry_signal = nullptr;
     if (n == 0) return SW_OK;
     if (sig) (*sig)++;
+    if (dry) { owned(c, dry); *dry = c->dry_value; g_dry[c->device]++; }
     g_scans[c->device]++;
     const bool packed = kind == SW_KIND_F16X2 || kind == SW_KIND_I16X2;
     for (int32_t i = 0; i < n; i++) {

@@ -239,6 +239,55 @@ def test_rescore_service_beside_the_bulk_launch(kinds, monkeypatch):
     assert sum(o[3] for o in runs["1"][0]) > (100 if kinds[0] == 0 else 0)
 
 
+@pytest.mark.parametrize("kinds", [(0, 0, 3, 3), (1, 1, 2, 2), (3, 0, 3, 3)])
+def test_tail_hand_over_between_two_queries_in_flight(kinds, monkeypatch):
+    """A query submitted while the one before is still running takes the GPU's other lane (context, work stream, score
+    arrays) and its bulk launch is gated on the dry signal of the earlier one (include/cudasw4_amd.h: sw_set_dry_signal).
+    Same DB as the service test (relatives of the queries: overflow lists, re-scores, a side launch for the long
+    subjects), queries of 48 ... 4548 residues submitted two at a time: every score of every query equals the oracle, top
+    lists and counters equal those of one query at a time, and every query but the first was gated."""
+    from cudasw4_amd import driver, synthdb
+    _, letters = O.read_fasta(FASTA)
+    queries = [letters[5], letters[11][:48], letters[11], letters[1], letters[16], letters[8]]
+    fam = synthdb.family_members([O.encode(q) for q in queries if len(q) > 400], seed=7, min_size=40, max_size=40)
+    lengths = synthdb.sprot_like_lengths(20000, seed=18, max_len=9000)
+    bg = synthdb.random_db(lengths, seed=19, composition=synthdb.SPROT_COMPOSITION)
+    seqs = [bg[0][int(bg[1][i]):int(bg[1][i]) + int(bg[2][i])] for i in range(len(lengths))] + list(fam)
+    seqs.sort(key=len)
+    chars, offsets, lens = O.make_db(seqs)
+    expect = [O.scan(O.encode(q), chars, offsets, lens, simd=True) for q in queries]
+    runs = {}
+    for mode in ("serial", "lanes", "off"):
+        monkeypatch.delenv("CUDASW4_AMD_TAIL_OVERLAP", raising=False)
+        if mode == "off":
+            monkeypatch.setenv("CUDASW4_AMD_TAIL_OVERLAP", "0")
+        d = driver.Driver(devices=[0], num_top=20, kinds=kinds)
+        d.db_from_arrays(chars, offsets, lens)
+        d.upload()
+        out = []
+        order = list(range(len(queries))) * 2
+        if mode == "serial":
+            for qi in order:
+                r = d.scan(queries[qi])
+                out.append((r["scores"].tolist(), r["ids"].tolist(), r["num_overflows"], r["num_rescored"]))
+        else:
+            d.submit(queries[order[0]])
+            for n, qi in enumerate(order):
+                if n + 1 < len(order):
+                    d.submit(queries[order[n + 1]])
+                r = d.collect()
+                if mode == "lanes":  # (on one lane the next query is already overwriting the score array)
+                    sc, _ = d.last_scores(0)     # of the query just collected, while the next one runs on the other lane
+                    assert (sc == expect[qi]).all(), (mode, n, qi, np.nonzero(sc != expect[qi])[0][:5])
+                out.append((r["scores"].tolist(), r["ids"].tolist(), r["num_overflows"], r["num_rescored"]))
+        runs[mode] = (out, d.tail_overlaps())
+        d.close()
+    assert runs["serial"][0] == runs["lanes"][0] == runs["off"][0]
+    assert runs["serial"][1] == 0 and runs["off"][1] == 0 and runs["lanes"][1] == 2 * len(queries) - 1
+    if kinds[0] != 3:
+        assert sum(o[3] for o in runs["lanes"][0]) > 0
+
+
 @pytest.mark.parametrize("dpx", [False, True])
 def test_documented_binding_runs_on_the_gpu(dpx):
     """VERDICT r3 test gap (ii): the reference-side binding of INTEGRATION.md section 2 — the verbatim code block, compiled

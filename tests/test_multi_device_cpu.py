@@ -36,6 +36,8 @@ L.fake_sw_scans.restype = ctypes.c_long
 L.fake_sw_scans.argtypes = [ctypes.c_int]
 L.fake_sw_rescored.restype = ctypes.c_long
 L.fake_sw_rescored.argtypes = [ctypes.c_int]
+L.fake_sw_dry_signals.restype = ctypes.c_long
+L.fake_sw_dry_signals.argtypes = [ctypes.c_int]
 
 lengths = synthdb.sprot_like_lengths(30000, seed=3, max_len=12000)
 chars, offsets, lengths = synthdb.random_db(lengths, seed=4)
@@ -55,7 +57,9 @@ for name, devices, kw in (("one", [0], {}), ("two", [0, 1], {}), ("rev", [1, 0],
         res.append({"scores": r["scores"].tolist(), "ids": r["ids"].tolist(), "rescored": r["num_rescored"],
                     "all": sc[order].tolist(), "ids_cover": bool((ids[order] == np.arange(len(lengths))).all())})
     pipelined = d.scan_many(queries)
+    ids, sc = d.all_scores()   # of the query collected last, whichever lane it ran on
     out[name] = {"res": res, "pipelined": [[p["scores"].tolist(), p["ids"].tolist()] for p in pipelined],
+                 "last_all_after_pipelined": sc[np.argsort(ids)].tolist(), "tail_overlaps": d.tail_overlaps(),
                  "devices": [d.device_of(g) for g in range(d.num_gpus())],
                  "subjects": [d.shard_info(g)["subjects"] for g in range(d.num_gpus())],
                  "numa": [d.numa_node(g) for g in range(d.num_gpus())]}
@@ -66,6 +70,7 @@ out["bad_owner"] = L.fake_sw_bad_owner()
 out["stream_calls"] = [L.fake_hip_stream_calls(0), L.fake_hip_stream_calls(1)]
 out["scans"] = [L.fake_sw_scans(0), L.fake_sw_scans(1)]
 out["rescored"] = [L.fake_sw_rescored(0), L.fake_sw_rescored(1)]
+out["dry_signals"] = [L.fake_sw_dry_signals(0), L.fake_sw_dry_signals(1)]
 print("RESULT " + json.dumps(out))
 '''
 
@@ -99,6 +104,12 @@ def test_driver_on_two_distinct_devices(fake_lib):
             assert a["scores"] == b["scores"] and a["ids"] == b["ids"]              # the merged top-25
             assert a["rescored"] == b["rescored"] > 0
         assert run["pipelined"] == one["pipelined"] == [[r["scores"], r["ids"]] for r in one["res"]]
+        assert run["last_all_after_pipelined"] == one["res"][-1]["all"]
+    # tail hand-over (two queries in flight on a resident shard): the second and third query of scan_many ran on the other
+    # lane, gated on the dry signal of the query before — per GPU; never on a streamed or hybrid shard
+    assert one["tail_overlaps"] == 2 and out["two"]["tail_overlaps"] == 4 and out["rev"]["tail_overlaps"] == 4
+    assert out["two_streamed"]["tail_overlaps"] == 0 and out["two_hybrid"]["tail_overlaps"] == 0
+    assert all(n > 0 for n in out["dry_signals"])
     assert out["two"]["numa"] == [-1, -1]       # the fake's PCI ids exist nowhere: unknown node, no binding attempted
 
 
