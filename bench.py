@@ -465,8 +465,10 @@ def measure(env, args, workload, want_cpu):
     from cudasw4_amd import capi, driver, search, synthdb
 
     _, query_letters = driver.read_sequences(os.path.join(ROOT, "tests", "golden", "allqueries.fasta"))
+    query_index = list(range(len(query_letters)))   # positions in allqueries.fasta (the golden scores are per file position)
     if args.queries:
-        query_letters = [query_letters[int(i)] for i in args.queries.split(",")]
+        query_index = [int(i) for i in args.queries.split(",")]
+        query_letters = [query_letters[i] for i in query_index]
     queries = [driver.encode(q) for q in query_letters]
     sum_q = sum(len(q) for q in queries)
     kernel_name, kinds = kinds_for(args)
@@ -523,7 +525,7 @@ def measure(env, args, workload, want_cpu):
 
     merged = [None] * len(queries)
     load = {"num_overflows": 0, "num_rescored": 0}  # of the last step: summed over its 20 queries (this rank's shard)
-    pipelined = os.environ["BENCH_PIPELINE"] == "1" if "BENCH_PIPELINE" in os.environ else world > 1
+    pipelined = os.environ["BENCH_PIPELINE"] == "1" if "BENCH_PIPELINE" in os.environ else (world > 1 or drv.prefers_two_in_flight())
 
     def one_step():
         """20 scans through the C++ driver (each returns this rank's top-K on the host), then ONE exchange of the
@@ -531,8 +533,10 @@ def measure(env, args, workload, want_cpu):
         mine = np.full((len(queries), max(K, 1), 2), -1, dtype=np.int64)
         # One query at a time, like the reference (main.cu:217-260), on one GPU; with several ranks — small shards, where
         # the fixed work per query weighs more — the driver takes the next query while the current one's top-K is still
-        # on its way back (Driver.scan_many, SearchDriver::submit / collect).  Measured on one GPU: +0.45 % on a
-        # 125 000-subject shard, +-0.1 % on the 10^6 x 512 DB, -0.1 ... -0.6 % on the Swiss-Prot-like DB.  BENCH_PIPELINE=0|1 forces it.
+        # on its way back (Driver.scan_many, SearchDriver::submit / collect), and on a small resident shard the next
+        # query's launch fills the slots the current one's last round leaves idle (tail hand-over: swdrv_tail_overlaps).
+        # Measured on one GPU: 125 000-subject shard 10.83 -> 11.28 TCUPS, +-0.1 % on the 10^6 x 512 DB (no hand-over
+        # there), -0.1 ... -0.6 % on the Swiss-Prot-like DB.  BENCH_PIPELINE=0|1 forces it.
         results = drv.scan_many(query_letters) if pipelined else [drv.scan(q) for q in query_letters]
         load["num_overflows"] = sum(r["num_overflows"] for r in results)
         load["num_rescored"] = sum(r["num_rescored"] for r in results)
@@ -587,6 +591,8 @@ def measure(env, args, workload, want_cpu):
         ok = True
         if args.workload == "peak":
             golden = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_scores.json")))["pseudo"].get(str(args.db_length))
+            if golden is not None:
+                golden = [golden[i] for i in query_index]
             if golden is None:
                 ok, verify_note = None, "no golden scores for pseudo-DB length %d" % args.db_length
             else:
@@ -702,7 +708,7 @@ def measure(env, args, workload, want_cpu):
             cpu_obj, cpu_scores = cpu_baseline(queries, *sample, "%d pseudo subjects of length %d" % (ns, args.db_length))
             if verified and args.workload == "peak":
                 golden = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_scores.json")))["pseudo"].get(str(args.db_length))
-                if golden is not None and any(int(s[0]) != int(g) for s, g in zip(cpu_scores, golden)):
+                if golden is not None and any(int(s[0]) != int(golden[i]) for s, i in zip(cpu_scores, query_index)):
                     out["verified"] = False
         out["cpu_baseline"] = cpu_obj
         if K > 0 and merged[-1] is not None:

@@ -55,18 +55,21 @@ void reportScan(const ProgramOptions& o, const ScanResult& r) {
     else std::cout << "Done.\n";
 }
 
-// All queries of a file (main.cu:217-260), one at a time like the reference.  With CUDASW4_AMD_PIPELINE=1 the next query
-// is submitted before the current one is collected (SearchDriver::submit / collect): its upload, profile build and first
-// launches queue up behind the current query's top-K on the GPU instead of waiting for the host to come back — worth
-// +0.4 % on small shards (125 000 subjects), nothing on a 10^6-subject DB and -0.8 % on a Swiss-Prot-like one, hence off
-// by default.  Output order and format are the reference's either way; a query's line is printed when its results are in.
+// All queries of a file (main.cu:217-260), one at a time like the reference — unless the DB's shards are small enough for
+// the tail hand-over (SearchDriver::prefersTwoInFlight: resident shards of a few rounds of workgroups, where the next
+// query's launch fills the slots the current one's last round leaves idle: +4 % on 125 000 subjects): then, and with
+// CUDASW4_AMD_PIPELINE=1, the next query is submitted before the current one is collected (SearchDriver::submit /
+// collect).  On large DBs two queries in flight bring nothing (10^6 subjects) or cost (-0.8 % on a Swiss-Prot-like one);
+// CUDASW4_AMD_PIPELINE=0 keeps one query at a time everywhere.  Output order and format are the reference's either way; a
+// query's line is printed when its results are in.
 void processQueryFile(const std::string& file, const ProgramOptions& o, SearchDriver& driver, std::ostream& out, bool interactive) {
     SequenceReader reader(file);
     struct Pending { int64_t num; std::string header, sequence; };
     std::deque<Pending> pending;
     int64_t query_num = 0;
     const char* pipe = std::getenv("CUDASW4_AMD_PIPELINE");
-    const int maxInFlight = (pipe && pipe[0] == '1') ? SearchDriver::kMaxInFlight : 1;
+    const bool two = pipe ? pipe[0] == '1' : driver.prefersTwoInFlight();
+    const int maxInFlight = two ? SearchDriver::kMaxInFlight : 1;
     if (!interactive) driver.totalTimerStart();
     auto finish_oldest = [&]() {
         const Pending q = std::move(pending.front());

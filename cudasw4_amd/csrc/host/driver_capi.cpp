@@ -312,6 +312,12 @@ int64_t swdrv_tail_overlaps(swdrv* d) {
     return n;
 }
 
+int swdrv_prefers_two_in_flight(swdrv* d) {
+    int v = 0;
+    (void)guarded([&] { v = d->driver->prefersTwoInFlight() ? 1 : 0; });
+    return v;
+}
+
 int swdrv_numa_node(swdrv* d, int gpu) {
     int node = -1;
     (void)guarded([&] { node = d->driver->numaNode(gpu); });

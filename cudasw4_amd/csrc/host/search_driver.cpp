@@ -280,9 +280,14 @@ struct SearchDriver::Gpu {
     // the second work stream with its scratch, and second score / id / overflow / top-K arrays (Lane below; the first set is
     // the fields above, LaneGuard exchanges the two for the duration of an enqueue).  Its bulk launch waits on its stream
     // for the value the bulk launch of the query before stores when its work counter runs dry, so its workgroups take the
-    // slots that launch frees one by one; both bulk grids leave kLaneReserve slots free for the small launches around them
-    // (profile build, re-score, top-K).  Resident shards of at most kLaneMaxRounds rounds of workgroups only: on a large
-    // shard the last round is a small part of the scan.  CUDASW4_AMD_TAIL_OVERLAP=0 turns it off, =1 lifts the size rule.
+    // slots that launch frees one by one.  The gate fixes the order: a persistent grid that is resident holds every slot,
+    // so a later grid can only fill what it frees — but two grids submitted back to back (the first two queries of a
+    // batch) would otherwise share the CUs half and half for their whole duration (round 3's two-lane experiment).
+    // Resident shards of at most kLaneMaxRounds rounds of workgroups only: on a large shard the last round is a small
+    // part of the scan (10^6 x 512 peak DB: -0.2 %; 500 000: +0.4 %; 250 000: +1.6 %; 125 000: +4.2 %; 62 500: +2.9 %).
+    // CUDASW4_AMD_TAIL_OVERLAP=0 turns it off, =1 lifts the size rule.  Slots left free for the small launches around the
+    // bulk grids (sw_set_grid_reserve) were measured and bring nothing (0 / 4 / 16: equal; 48: -0.8 %; 16 on the 567 ...
+    // 1000-residue queries: -5 %): the reserve stays 0.
     struct Lane {
         sw_ctx* ctx = nullptr;
         float* d_scores = nullptr;
@@ -297,8 +302,10 @@ struct SearchDriver::Gpu {
         int32_t* d_topI = nullptr;
         int topCapacity = 0;
     } lane1;
-    static constexpr int kLaneReserve = 16;
-    static constexpr size_t kLaneMaxRounds = 16;
+    static constexpr int kLaneReserve = 0;
+    int laneReserve = kLaneReserve;    // CUDASW4_AMD_LANE_RESERVE (A/B measurements)
+    bool laneGate = true;              // CUDASW4_AMD_TAIL_GATE=0: second lane without the dry-signal gate (A/B measurements)
+    static constexpr size_t kLaneMaxRounds = 24;
     int laneForce = -1;                // CUDASW4_AMD_TAIL_OVERLAP
     bool lanesConcurrent = false;      // probed with the second work stream: the two work streams run beside each other
     bool lanesProbed = false;
@@ -507,6 +514,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
                 }
             }
             if (const char* e = std::getenv("CUDASW4_AMD_TAIL_OVERLAP")) g->laneForce = e[0] == '1' ? 1 : 0;
+            if (const char* e = std::getenv("CUDASW4_AMD_LANE_RESERVE")) g->laneReserve = std::max(0, std::atoi(e));
+            if (const char* e = std::getenv("CUDASW4_AMD_TAIL_GATE")) g->laneGate = !(e[0] == '0');
             if (const char* e = std::getenv("CUDASW4_AMD_RESCORE_SERVICE")) g->svcForce = e[0] == '1' ? 1 : 0;
         }
         if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
@@ -1335,15 +1344,27 @@ void SearchDriver::scanStreamed(Gpu& g) {
 // the query upload, the zeroed counters and the first launches of query i + 1 queue up behind the top-K and the copies of
 // query i on the work stream, the auxiliary streams fork from it and join it again before the top-K.
 // The second lane's resources (Gpu::Lane), created with the first query that can use them.  False: stay on one lane.
-bool SearchDriver::prepareLane(Gpu& g) {
-    if (g.lanesFailed || !g.handshake || !g.drySignal || g.laneForce == 0) return false;
-    if (g.cacheBegin != 0 || !g.batches.empty() || !g.cacheFilled) return false;  // resident shards only
+bool SearchDriver::laneEligible(const Gpu& g) const {
+    if (g.lanesFailed || !g.handshake || !g.drySignal || g.laneForce == 0 || g.numLocal == 0) return false;
+    if (g.cacheBegin != 0 || !g.batches.empty()) return false;  // resident shards only
     if (g.laneForce != 1) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g.device) != hipSuccess || cus <= 0) return false;
         // a round: three workgroups per CU, 16 groups of two subjects each
         if (g.numLocal > Gpu::kLaneMaxRounds * size_t(cus) * 3 * 32) return false;
     }
+    return true;
+}
+
+bool SearchDriver::prefersTwoInFlight() const {
+    if (!db_) return false;
+    for (auto& gp : gpus_)
+        if (laneEligible(*gp)) return true;
+    return false;
+}
+
+bool SearchDriver::prepareLane(Gpu& g) {
+    if (!laneEligible(g) || !g.cacheFilled) return false;
     try {
         if (!g.stream2) HIPCHECK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
         if (!g.lanesProbed) {
@@ -1392,7 +1413,7 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
     const int lane = overlap ? 1 - g.lastLane : 0;
     Gpu::LaneGuard laneGuard(g, lane);
     g.laneActive = overlap;
-    g.waitDry = overlap ? g.lastArmedSeq : 0;
+    g.waitDry = overlap && g.laneGate ? g.lastArmedSeq : 0;
     g.lastArmedSeq = 0;
     g.lastLane = lane;
     rs.lane = lane;
@@ -1400,7 +1421,7 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
         if (g.badCodes) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
         g.qlen = queryLength;
         if (!g.cacheFilled) uploadShard(g);  // the first query pays the upload unless --uploadFull
-        SWCHECK(sw_set_grid_reserve(g.ctx, overlap ? Gpu::kLaneReserve : 0));
+        SWCHECK(sw_set_grid_reserve(g.ctx, overlap ? g.laneReserve : 0));
         SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
         // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
         // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed)

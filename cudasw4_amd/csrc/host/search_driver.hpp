@@ -215,6 +215,9 @@ public:
     // queries whose bulk launch was gated on the dry signal of the query before it (tail hand-over between two queries in
     // flight: submit() while a query is pending, resident shards of a few rounds of workgroups), since the driver was created
     int64_t tailOverlaps() const;
+    // true when a caller that has its next query at hand should submit() it before it collect()s the current one: some
+    // GPU's shard qualifies for the tail hand-over (after setDatabase)
+    bool prefersTwoInFlight() const;
     // every score of the last scan on `gpu` (the CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756) with
     // the global id of each position; both arrays hold numLocal(gpu) entries
     void lastScores(int gpu, float* scores, int64_t* ids);
@@ -232,6 +235,7 @@ private:
     void scanStreamed(Gpu& g);
     void enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bool inFlight);
     bool prepareLane(Gpu& g);
+    bool laneEligible(const Gpu& g) const;
     void finishOnGpu(Gpu& g, int slot);
     void registerStreamedRanges();
     void unregisterRanges();

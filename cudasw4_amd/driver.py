@@ -22,7 +22,7 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
            "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency", "swdrv_numa_node", "swdrv_device_of",
            "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats", "swdrv_service_launches",
-           "swdrv_tail_overlaps"]
+           "swdrv_tail_overlaps", "swdrv_prefers_two_in_flight"]
 
 
 class DriverError(RuntimeError):
@@ -95,6 +95,7 @@ def _load():
     L.swdrv_service_launches.argtypes = [vp]
     L.swdrv_tail_overlaps.restype = ctypes.c_int64
     L.swdrv_tail_overlaps.argtypes = [vp]
+    L.swdrv_prefers_two_in_flight.argtypes = [vp]
     L.swdrv_window_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     L.swdrv_device_of.argtypes = [vp, ctypes.c_int]
     L.swdrv_bind_to_numa_node.argtypes = [ctypes.c_int]
@@ -307,6 +308,10 @@ class Driver:
     def service_launches(self):
         """Re-score service launches since the driver was created."""
         return int(lib.swdrv_service_launches(self.handle))
+
+    def prefers_two_in_flight(self):
+        """True when the loaded DB's shards qualify for the tail hand-over: use scan_many / submit + collect."""
+        return bool(lib.swdrv_prefers_two_in_flight(self.handle))
 
     def tail_overlaps(self):
         """Queries whose bulk launch was gated on the dry signal of the query before (swdrv_tail_overlaps)."""

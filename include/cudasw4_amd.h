@@ -201,8 +201,8 @@ int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
  * workgroups take the slots this launch frees one by one; launched without the gate, the two grids would share the CUs
  * for their whole duration.  Values must increase from launch to launch.  A launch that fails or has n == 0 never fires.
  * sw_set_grid_reserve (sticky): scan launches of this context leave `workgroups` of the slots the device has for their
- * kernel free (the grid is capped at resident - reserve), so that the small launches of the query before — re-score,
- * top-K — and of the query after — profile build — find a slot while a persistent grid holds the rest.  0: none. */
+ * kernel free (the grid is capped at resident - reserve), so that small launches of other streams find a slot while a
+ * persistent grid holds the rest.  0: none (the host driver's setting: measured, the hand-over gains nothing from it). */
 int sw_set_dry_signal(sw_ctx* ctx, uint32_t* signal, uint32_t value);
 int sw_set_grid_reserve(sw_ctx* ctx, int32_t workgroups);
 

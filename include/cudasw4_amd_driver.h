@@ -128,6 +128,9 @@ int64_t swdrv_service_launches(swdrv* d);
  * swdrv_scan.  Returns the queries gated that way since swdrv_create.  CUDASW4_AMD_TAIL_OVERLAP=0 turns the hand-over
  * off, =1 lifts the shard-size rule. */
 int64_t swdrv_tail_overlaps(swdrv* d);
+/* 1 when the loaded DB's shards qualify for the hand-over: a caller with its next query at hand should then swdrv_submit it
+ * before it collects the current one (`align` and bench.py do) */
+int swdrv_prefers_two_in_flight(swdrv* d);
 
 /* NUMA placement: the node of the gpu-th GPU's PCI function (-1: unknown) and its HIP device ordinal.  In-process
  * multi-GPU drivers run each GPU's worker thread on that node themselves; a one-process-per-GPU caller binds its own

@@ -135,13 +135,18 @@ def main(argv=None):
             if smode < 2:
                 os.environ["CUDASW4_AMD_RESCORE_SERVICE"] = str(smode)
             mode += " windows=%s service=%s" % (["always", "off", "auto"][wmode], ["off", "on", "auto"][smode])
+            os.environ.pop("CUDASW4_AMD_TAIL_OVERLAP", None)
+            if r.integers(0, 4) == 0:
+                os.environ["CUDASW4_AMD_TAIL_OVERLAP"] = "0"
             d = driver.Driver(devices=devs, num_top=min(10, n), kinds=kinds, **kw)
             d.db_from_arrays(chars, offsets, lens)
             if r.integers(0, 3) == 0:
-                # two queries in flight (submit / collect): the second one's results are the ones checked
-                other = bytes(LETTERS21[c] for c in r.integers(0, 20, int(r.integers(1, 400))))
-                rr = d.scan_many([other, letters])[1]
-                mode += " pipelined"
+                # two queries in flight (submit / collect): the last one's results are the ones checked.  On a resident
+                # shard every query but the first runs on the GPU's other lane, gated on the dry signal of the one before
+                # (tail hand-over; CUDASW4_AMD_TAIL_OVERLAP=0: one lane)
+                others = [bytes(LETTERS21[c] for c in r.integers(0, 20, int(r.integers(1, 400)))) for _ in range(int(r.integers(1, 4)))]
+                rr = d.scan_many(others + [letters])[-1]
+                mode += " pipelined x%d lanes=%s gated=%d" % (len(others) + 1, os.environ.get("CUDASW4_AMD_TAIL_OVERLAP", "auto"), d.tail_overlaps())
             else:
                 rr = d.scan(letters)
             ids, sc = d.all_scores()
