@@ -56,8 +56,9 @@ void reportScan(const ProgramOptions& o, const ScanResult& r) {
 }
 
 // All queries of a file (main.cu:217-260), one at a time like the reference — unless the DB's shards are small enough for
-// the tail hand-over (SearchDriver::prefersTwoInFlight: resident shards of a few rounds of workgroups, where the next
-// query's launch fills the slots the current one's last round leaves idle: +4 % on 125 000 subjects): then, and with
+// the tail hand-over (SearchDriver::prefersTwoInFlight: resident shards of a few rounds of workgroups, or a query that is
+// scanned in a few milliseconds; the next query's launch fills the slots the current one's last round leaves idle: +4 %
+// on 125 000 subjects, +26 % for a stream of 48-residue queries on a Swiss-Prot-sized DB): then, and with
 // CUDASW4_AMD_PIPELINE=1, the next query is submitted before the current one is collected (SearchDriver::submit /
 // collect).  On large DBs two queries in flight bring nothing (10^6 subjects) or cost (-0.8 % on a Swiss-Prot-like one);
 // CUDASW4_AMD_PIPELINE=0 keeps one query at a time everywhere.  Output order and format are the reference's either way; a
@@ -68,8 +69,11 @@ void processQueryFile(const std::string& file, const ProgramOptions& o, SearchDr
     std::deque<Pending> pending;
     int64_t query_num = 0;
     const char* pipe = std::getenv("CUDASW4_AMD_PIPELINE");
-    const bool two = pipe ? pipe[0] == '1' : driver.prefersTwoInFlight();
-    const int maxInFlight = two ? SearchDriver::kMaxInFlight : 1;
+    // how many queries may be pending once a query of this length has been submitted
+    auto max_in_flight = [&](size_t queryLength) {
+        const bool two = pipe ? pipe[0] == '1' : driver.prefersTwoInFlight(int32_t(std::min<size_t>(queryLength, size_t(INT32_MAX))));
+        return two ? SearchDriver::kMaxInFlight : 1;
+    };
     if (!interactive) driver.totalTimerStart();
     auto finish_oldest = [&]() {
         const Pending q = std::move(pending.front());
@@ -93,7 +97,8 @@ void processQueryFile(const std::string& file, const ProgramOptions& o, SearchDr
         while (reader.next()) {
             pending.push_back(Pending{query_num++, reader.header(), reader.sequence()});
             driver.submit(pending.back().sequence.data(), int32_t(pending.back().sequence.size()));
-            if (driver.inFlight() >= maxInFlight) finish_oldest();
+            const int maxInFlight = max_in_flight(pending.back().sequence.size());
+            while (driver.inFlight() >= maxInFlight) finish_oldest();
         }
         while (driver.inFlight() > 0) finish_oldest();
     } catch (...) {

@@ -312,9 +312,9 @@ int64_t swdrv_tail_overlaps(swdrv* d) {
     return n;
 }
 
-int swdrv_prefers_two_in_flight(swdrv* d) {
+int swdrv_prefers_two_in_flight(swdrv* d, int32_t query_length) {
     int v = 0;
-    (void)guarded([&] { v = d->driver->prefersTwoInFlight() ? 1 : 0; });
+    (void)guarded([&] { v = d->driver->prefersTwoInFlight(query_length) ? 1 : 0; });
     return v;
 }
 

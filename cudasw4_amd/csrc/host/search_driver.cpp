@@ -283,8 +283,9 @@ struct SearchDriver::Gpu {
     // slots that launch frees one by one.  The gate fixes the order: a persistent grid that is resident holds every slot,
     // so a later grid can only fill what it frees — but two grids submitted back to back (the first two queries of a
     // batch) would otherwise share the CUs half and half for their whole duration (round 3's two-lane experiment).
-    // Resident shards of at most kLaneMaxRounds rounds of workgroups only: on a large shard the last round is a small
-    // part of the scan (10^6 x 512 peak DB: -0.2 %; 500 000: +0.4 %; 250 000: +1.6 %; 125 000: +4.2 %; 62 500: +2.9 %).
+    // Resident shards of at most kLaneMaxRounds rounds of workgroups, or queries whose scan takes at most kLaneMaxSeconds:
+    // on a large shard the last round is a small part of a long scan (10^6 x 512 peak DB: -0.2 %; 500 000: +0.4 %;
+    // 250 000: +1.6 %; 125 000: +4.2 %; 62 500: +2.9 %).
     // CUDASW4_AMD_TAIL_OVERLAP=0 turns it off, =1 lifts the size rule.  Slots left free for the small launches around the
     // bulk grids (sw_set_grid_reserve) were measured and bring nothing (0 / 4 / 16: equal; 48: -0.8 %; 16 on the 567 ...
     // 1000-residue queries: -5 %): the reserve stays 0.
@@ -305,7 +306,8 @@ struct SearchDriver::Gpu {
     static constexpr int kLaneReserve = 0;
     int laneReserve = kLaneReserve;    // CUDASW4_AMD_LANE_RESERVE (A/B measurements)
     bool laneGate = true;              // CUDASW4_AMD_TAIL_GATE=0: second lane without the dry-signal gate (A/B measurements)
-    static constexpr size_t kLaneMaxRounds = 24;
+    static constexpr size_t kLaneMaxRounds = 20;
+    static constexpr double kLaneMaxSeconds = 0.008;   // ... or scans of at most this long, at 10 TCUPS
     int laneForce = -1;                // CUDASW4_AMD_TAIL_OVERLAP
     bool lanesConcurrent = false;      // probed with the second work stream: the two work streams run beside each other
     bool lanesProbed = false;
@@ -1344,27 +1346,29 @@ void SearchDriver::scanStreamed(Gpu& g) {
 // the query upload, the zeroed counters and the first launches of query i + 1 queue up behind the top-K and the copies of
 // query i on the work stream, the auxiliary streams fork from it and join it again before the top-K.
 // The second lane's resources (Gpu::Lane), created with the first query that can use them.  False: stay on one lane.
-bool SearchDriver::laneEligible(const Gpu& g) const {
+// queryLength: the shorter one of the two queries that would overlap (0: only the shard-size rule)
+bool SearchDriver::laneEligible(const Gpu& g, int32_t queryLength) const {
     if (g.lanesFailed || !g.handshake || !g.drySignal || g.laneForce == 0 || g.numLocal == 0) return false;
     if (g.cacheBegin != 0 || !g.batches.empty()) return false;  // resident shards only
-    if (g.laneForce != 1) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g.device) != hipSuccess || cus <= 0) return false;
-        // a round: three workgroups per CU, 16 groups of two subjects each
-        if (g.numLocal > Gpu::kLaneMaxRounds * size_t(cus) * 3 * 32) return false;
-    }
-    return true;
+    if (g.laneForce == 1) return true;
+    // a scan that is over in a few milliseconds is mostly ramp-up, last round and fixed work per query, whatever the
+    // shard's size (streams of 48 ... 222-residue queries on the Swiss-Prot-like DB: +26 ... +8 %; 375 residues, 8 ms: +1 %)
+    if (queryLength > 0 && double(queryLength) * double(g.localResidues) / 1e13 <= Gpu::kLaneMaxSeconds) return true;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g.device) != hipSuccess || cus <= 0) return false;
+    // a round: three workgroups per CU, 16 groups of two subjects each
+    return g.numLocal <= Gpu::kLaneMaxRounds * size_t(cus) * 3 * 32;
 }
 
-bool SearchDriver::prefersTwoInFlight() const {
+bool SearchDriver::prefersTwoInFlight(int32_t queryLength) const {
     if (!db_) return false;
     for (auto& gp : gpus_)
-        if (laneEligible(*gp)) return true;
+        if (laneEligible(*gp, queryLength)) return true;
     return false;
 }
 
-bool SearchDriver::prepareLane(Gpu& g) {
-    if (!laneEligible(g) || !g.cacheFilled) return false;
+bool SearchDriver::prepareLane(Gpu& g, int32_t queryLength) {
+    if (!laneEligible(g, queryLength) || !g.cacheFilled) return false;
     try {
         if (!g.stream2) HIPCHECK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
         if (!g.lanesProbed) {
@@ -1409,7 +1413,7 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
     if (g.numLocal == 0) return;
     g.use();
     // a query submitted while the one before is running takes the other lane and is gated on that one's dry signal
-    const bool overlap = inFlight && prepareLane(g);
+    const bool overlap = inFlight && prepareLane(g, std::min(g.qlen, queryLength));  // (g.qlen: the query before)
     const int lane = overlap ? 1 - g.lastLane : 0;
     Gpu::LaneGuard laneGuard(g, lane);
     g.laneActive = overlap;

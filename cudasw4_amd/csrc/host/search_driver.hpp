@@ -216,8 +216,9 @@ public:
     // flight: submit() while a query is pending, resident shards of a few rounds of workgroups), since the driver was created
     int64_t tailOverlaps() const;
     // true when a caller that has its next query at hand should submit() it before it collect()s the current one: some
-    // GPU's shard qualifies for the tail hand-over (after setDatabase)
-    bool prefersTwoInFlight() const;
+    // GPU's shard qualifies for the tail hand-over (after setDatabase) — by its size, or because a query of queryLength
+    // residues (0: not considered) is scanned in a few milliseconds
+    bool prefersTwoInFlight(int32_t queryLength = 0) const;
     // every score of the last scan on `gpu` (the CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756) with
     // the global id of each position; both arrays hold numLocal(gpu) entries
     void lastScores(int gpu, float* scores, int64_t* ids);
@@ -234,8 +235,8 @@ private:
     void uploadShard(Gpu& g);
     void scanStreamed(Gpu& g);
     void enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bool inFlight);
-    bool prepareLane(Gpu& g);
-    bool laneEligible(const Gpu& g) const;
+    bool prepareLane(Gpu& g, int32_t queryLength);
+    bool laneEligible(const Gpu& g, int32_t queryLength) const;
     void finishOnGpu(Gpu& g, int slot);
     void registerStreamedRanges();
     void unregisterRanges();

@@ -95,7 +95,7 @@ def _load():
     L.swdrv_service_launches.argtypes = [vp]
     L.swdrv_tail_overlaps.restype = ctypes.c_int64
     L.swdrv_tail_overlaps.argtypes = [vp]
-    L.swdrv_prefers_two_in_flight.argtypes = [vp]
+    L.swdrv_prefers_two_in_flight.argtypes = [vp, ctypes.c_int32]
     L.swdrv_window_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     L.swdrv_device_of.argtypes = [vp, ctypes.c_int]
     L.swdrv_bind_to_numa_node.argtypes = [ctypes.c_int]
@@ -309,9 +309,10 @@ class Driver:
         """Re-score service launches since the driver was created."""
         return int(lib.swdrv_service_launches(self.handle))
 
-    def prefers_two_in_flight(self):
-        """True when the loaded DB's shards qualify for the tail hand-over: use scan_many / submit + collect."""
-        return bool(lib.swdrv_prefers_two_in_flight(self.handle))
+    def prefers_two_in_flight(self, query_length=0):
+        """True when the tail hand-over applies (small resident shards, or a query of query_length residues that is scanned
+        in a few milliseconds): use scan_many / submit + collect."""
+        return bool(lib.swdrv_prefers_two_in_flight(self.handle, int(query_length)))
 
     def tail_overlaps(self):
         """Queries whose bulk launch was gated on the dry signal of the query before (swdrv_tail_overlaps)."""

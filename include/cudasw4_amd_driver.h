@@ -124,13 +124,15 @@ int64_t swdrv_service_launches(swdrv* d);
 /* Tail hand-over between two queries in flight (include/cudasw4_amd.h: sw_set_dry_signal): a query submitted with
  * swdrv_submit while the one before is still pending runs on a second lane of the GPU (context, work stream, score arrays)
  * and its bulk launch starts when the earlier one's work counter runs dry, filling the slots its last round leaves idle —
- * on resident shards of a few rounds of workgroups (what each of N GPUs gets from a small DB); results are those of
- * swdrv_scan.  Returns the queries gated that way since swdrv_create.  CUDASW4_AMD_TAIL_OVERLAP=0 turns the hand-over
+ * on resident shards of a few rounds of workgroups (what each of N GPUs gets from a small DB) and for queries that are
+ * scanned in a few milliseconds; results are those of swdrv_scan.  Returns the queries gated that way since swdrv_create.  CUDASW4_AMD_TAIL_OVERLAP=0 turns the hand-over
  * off, =1 lifts the shard-size rule. */
 int64_t swdrv_tail_overlaps(swdrv* d);
-/* 1 when the loaded DB's shards qualify for the hand-over: a caller with its next query at hand should then swdrv_submit it
- * before it collects the current one (`align` and bench.py do) */
-int swdrv_prefers_two_in_flight(swdrv* d);
+/* 1 when the hand-over applies — the loaded DB's shards are small (at most 20 rounds of workgroups: 491 520 subjects on 256 CUs), or a query of
+ * query_length residues (0: not considered) is scanned in a few milliseconds (<= 8 ms at 10 TCUPS: short queries, whatever
+ * the DB) —: a caller with its next query at hand should then swdrv_submit it before it collects the current one (`align`
+ * and bench.py do) */
+int swdrv_prefers_two_in_flight(swdrv* d, int32_t query_length);
 
 /* NUMA placement: the node of the gpu-th GPU's PCI function (-1: unknown) and its HIP device ordinal.  In-process
  * multi-GPU drivers run each GPU's worker thread on that node themselves; a one-process-per-GPU caller binds its own

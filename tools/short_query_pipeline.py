@@ -11,7 +11,7 @@ import numpy as np
 from cudasw4_amd import driver, synthdb
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--lengths", default="48,96,144,189,222,375,567")
+ap.add_argument("--lengths", default="48,96,144,189,222,300,375,464,567")
 ap.add_argument("--copies", type=int, default=16)
 ap.add_argument("--configs", default="dpx")
 ap.add_argument("--db-size", type=int, default=synthdb.SPROT_SEQUENCES)
@@ -26,9 +26,10 @@ for cname in args.configs.split(","):
     for n in (int(x) for x in args.lengths.split(",")):
         queries = [alphabet[rng.integers(0, 20, n)].tobytes() for _ in range(args.copies)]
         row, tops = [], {}
-        for mode, env in (("one at a time", None), ("two in flight, one lane", "0"), ("two in flight, two lanes", "1")):
+        for mode, env in (("one at a time", None), ("two in flight, one lane", "0"), ("two in flight, two lanes", "1"),
+                          ("two in flight, driver's rule", "auto")):
             os.environ.pop("CUDASW4_AMD_TAIL_OVERLAP", None)
-            if env is not None:
+            if env in ("0", "1"):
                 os.environ["CUDASW4_AMD_TAIL_OVERLAP"] = env
             d = driver.Driver(devices=[0], num_top=10, kinds=CONFIGS[cname])
             d.db_from_arrays(chars, offsets, lengths)
@@ -46,5 +47,6 @@ for cname in args.configs.split(","):
         table[n] = row
     print("%s: %d queries per length, GCUPS over the stream (same top-10 lists in every mode)" % (cname, args.copies))
     print("%-28s %s" % ("query residues", " ".join("%7d" % n for n in table)))
-    for i in range(3):
+    for i in range(4):
         print("%-28s %s" % (table[next(iter(table))][i][0], " ".join("%7.0f" % table[n][i][1] for n in table)))
+    print("%-28s %s" % ("  ... queries gated", " ".join("%7d" % table[n][3][2] for n in table)))
