@@ -438,8 +438,7 @@ def peak_sweep(env, args):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(max(args.sweep_steps, 1)):
-                for q in query_letters:
-                    drv.scan(q)
+                drv.scan_stream(query_letters)   # the way `align` walks a query file (one at a time, two where the driver's rule says so)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             drv.close()
@@ -447,7 +446,7 @@ def peak_sweep(env, args):
             ok_all = ok_all and bool(ok)
         table[kname] = row
     return {"unit": "GCUPS", "protocol": "runpeakbenchmark.sh:26-83: allqueries.fasta x pseudo DB %d x L, resident, blosum62, gop -11 gex -1, "
-                                        "top %d, C++ host driver; per cell 1 verified warm-up pass + %d timed passes" % (num, K, max(args.sweep_steps, 1)),
+                                        "top %d, C++ host driver, queries walked like `align` does (Driver.scan_stream); per cell 1 verified warm-up pass + %d timed passes" % (num, K, max(args.sweep_steps, 1)),
             "gcups": table, "verified": ok_all,
             "verified_how": "in every cell all %d scores of each of the 20 queries equal the reference's golden score" % num,
             "dpxs32_note": "int32 results computed in fp32 lanes (exact below 2^24, bound checked per launch)"
@@ -525,7 +524,11 @@ def measure(env, args, workload, want_cpu):
 
     merged = [None] * len(queries)
     load = {"num_overflows": 0, "num_rescored": 0}  # of the last step: summed over its 20 queries (this rank's shard)
+    # "always": every query submitted before the one before it is collected (multi-rank runs: small shards); "never": one
+    # at a time; "rule": like `align` — two in flight exactly where the driver says the tail hand-over applies
+    # (Driver.scan_stream: small resident shards, queries that are scanned in a few milliseconds)
     pipelined = os.environ["BENCH_PIPELINE"] == "1" if "BENCH_PIPELINE" in os.environ else (world > 1 or drv.prefers_two_in_flight())
+    by_rule = "BENCH_PIPELINE" not in os.environ and not pipelined
 
     def one_step():
         """20 scans through the C++ driver (each returns this rank's top-K on the host), then ONE exchange of the
@@ -537,7 +540,7 @@ def measure(env, args, workload, want_cpu):
         # query's launch fills the slots the current one's last round leaves idle (tail hand-over: swdrv_tail_overlaps).
         # Measured on one GPU: 125 000-subject shard 10.83 -> 11.28 TCUPS, +-0.1 % on the 10^6 x 512 DB (no hand-over
         # there), -0.1 ... -0.6 % on the Swiss-Prot-like DB.  BENCH_PIPELINE=0|1 forces it.
-        results = drv.scan_many(query_letters) if pipelined else [drv.scan(q) for q in query_letters]
+        results = drv.scan_many(query_letters) if pipelined else drv.scan_stream(query_letters) if by_rule else [drv.scan(q) for q in query_letters]
         load["num_overflows"] = sum(r["num_overflows"] for r in results)
         load["num_rescored"] = sum(r["num_rescored"] for r in results)
         for qi, r in enumerate(results):
@@ -680,6 +683,8 @@ def measure(env, args, workload, want_cpu):
                        "db_subjects": total_subjects, "db_residues": int(total_residues), "queries": len(queries),
                        "kernel": kernel_name, "host": "libcudasw4_host.so (SearchDriver)",
                        "queries_in_flight": 2 if pipelined else 1,
+                       "queries_in_flight_rule": "always two" if pipelined else "two where the driver's rule says so (swdrv_prefers_two_in_flight: %d of the %d queries), else one" % (
+                           sum(1 for q in query_letters if drv.prefers_two_in_flight(len(q))), len(query_letters)) if by_rule else "one at a time",
                        # queries of rank 0 whose bulk launch was gated on the dry signal of the query before it (tail
                        # hand-over on small resident shards, include/cudasw4_amd_driver.h: swdrv_tail_overlaps), all steps
                        "tail_overlaps": drv.tail_overlaps(),

@@ -418,6 +418,21 @@ class Driver:
             out.append(self.collect())
         return out
 
+    def scan_stream(self, queries):
+        """Every query of a list the way `align` processes a query file (align_main.cpp: processQueryFile): one query at a
+        time like the reference, except where the driver says the tail hand-over applies to the query just submitted (a
+        small resident shard, or a query that is scanned in a few milliseconds) — then the next query is submitted before
+        that one is collected.  -> list of result dicts, in the order of the queries."""
+        out = []
+        for q in queries:
+            self.submit(q)
+            limit = 2 if self.prefers_two_in_flight(len(q)) else 1
+            while lib.swdrv_in_flight(self.handle) >= limit:
+                out.append(self.collect())
+        while lib.swdrv_in_flight(self.handle) > 0:
+            out.append(self.collect())
+        return out
+
     def reference_length(self, i):
         return int(lib.swdrv_reference_length(self.handle, i))
 

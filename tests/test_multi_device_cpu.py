@@ -58,8 +58,11 @@ for name, devices, kw in (("one", [0], {}), ("two", [0, 1], {}), ("rev", [1, 0],
                     "all": sc[order].tolist(), "ids_cover": bool((ids[order] == np.arange(len(lengths))).all())})
     pipelined = d.scan_many(queries)
     ids, sc = d.all_scores()   # of the query collected last, whichever lane it ran on
+    overlaps = d.tail_overlaps()
+    by_rule = d.scan_stream(queries)   # align's loop: two in flight where the driver's rule says so
     out[name] = {"res": res, "pipelined": [[p["scores"].tolist(), p["ids"].tolist()] for p in pipelined],
-                 "last_all_after_pipelined": sc[np.argsort(ids)].tolist(), "tail_overlaps": d.tail_overlaps(),
+                 "last_all_after_pipelined": sc[np.argsort(ids)].tolist(), "tail_overlaps": overlaps,
+                 "by_rule": [[p["scores"].tolist(), p["ids"].tolist()] for p in by_rule],
                  "devices": [d.device_of(g) for g in range(d.num_gpus())],
                  "subjects": [d.shard_info(g)["subjects"] for g in range(d.num_gpus())],
                  "numa": [d.numa_node(g) for g in range(d.num_gpus())]}
@@ -105,8 +108,10 @@ def test_driver_on_two_distinct_devices(fake_lib):
             assert a["rescored"] == b["rescored"] > 0
         assert run["pipelined"] == one["pipelined"] == [[r["scores"], r["ids"]] for r in one["res"]]
         assert run["last_all_after_pipelined"] == one["res"][-1]["all"]
+        assert run["by_rule"] == one["pipelined"]
     # tail hand-over (two queries in flight on a resident shard): the second and third query of scan_many ran on the other
     # lane, gated on the dry signal of the query before — per GPU; never on a streamed or hybrid shard
+    # (tail_overlaps was read before the scan_stream pass)
     assert one["tail_overlaps"] == 2 and out["two"]["tail_overlaps"] == 4 and out["rev"]["tail_overlaps"] == 4
     assert out["two_streamed"]["tail_overlaps"] == 0 and out["two_hybrid"]["tail_overlaps"] == 0
     assert all(n > 0 for n in out["dry_signals"])
