@@ -25,7 +25,8 @@ EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "s
            "sw_topk_temp_bytes",
            "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal",
            "sw_window_overlap", "sw_reduce_windows", "sw_rescore_service", "sw_rescore_overflow_claim",
-           "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_grid_reserve"]
+           "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_grid_reserve",
+           "sw_scan_rows", "sw_scan_rows_max_subject", "sw_set_long16_min"]
 
 
 class SwError(RuntimeError):
@@ -69,6 +70,10 @@ def _load():
     L.sw_set_start_signal.argtypes = [vp, vp]
     L.sw_set_dry_signal.argtypes = [vp, vp, ctypes.c_uint32]
     L.sw_set_grid_reserve.argtypes = [vp, i32]
+    L.sw_set_long16_min.argtypes = [vp, i32]
+    L.sw_scan_rows_max_subject.restype = i32
+    L.sw_scan_rows_max_subject.argtypes = []
+    L.sw_scan_rows.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp]
     L.sw_window_overlap.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.sw_window_overlap.restype = i32
     L.sw_reduce_windows.argtypes = [vp, vp, vp, vp, i32, vp, vp, ctypes.c_int64, vp]
@@ -87,6 +92,10 @@ def check(rc):
 
 def version():
     return lib.sw_version().decode()
+
+
+def scan_rows_max_subject():
+    return int(lib.sw_scan_rows_max_subject())
 
 
 def device_count():
@@ -138,6 +147,11 @@ class Context:
         check(lib.sw_scan_partition(self.handle, kind, part_id, chars, offsets, lengths, first_pos, n, max_subject_len,
                                     gop, gex, scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
                                     stream))
+
+    def scan_rows(self, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids, id_offset=0, stream=0):
+        """The row-parallel scan of very long subjects (sw_scan_rows): one 1024-thread workgroup per subject."""
+        check(lib.sw_scan_rows(self.handle, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
+                               id_offset, stream))
 
     def rescore_overflow(self, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len, gop, gex,
                          scores, ids, id_offset=0, temp=0, temp_bytes=0, stream=0):

@@ -306,6 +306,18 @@ int64_t swdrv_service_launches(swdrv* d) {
     return n;
 }
 
+int64_t swdrv_latency_scans(swdrv* d) {
+    int64_t n = -1;
+    (void)guarded([&] { n = d->driver->latencyScans(); });
+    return n;
+}
+
+int64_t swdrv_rows_launches(swdrv* d) {
+    int64_t n = -1;
+    (void)guarded([&] { n = d->driver->rowsLaunches(); });
+    return n;
+}
+
 int64_t swdrv_tail_overlaps(swdrv* d) {
     int64_t n = -1;
     (void)guarded([&] { n = d->driver->tailOverlaps(); });

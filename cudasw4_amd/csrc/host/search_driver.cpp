@@ -246,6 +246,10 @@ struct SearchDriver::Gpu {
     static constexpr int kWindowBufs = 4;  // per auxiliary stream: two queries in flight, two side launches each at most
     WindowBuf winBuf[kAux][kWindowBufs];
     int winNext[kAux] = {0, 0};
+    int latencyMode = 1;               // CUDASW4_AMD_LATENCY_MODE=never|always (0 / 2): partition 34 on wave-wide groups beside the bulk launch never / always
+    int64_t latencyScans = 0;          // scans (batches) planned in latency mode, since the driver was created
+    int rowsMode = 1;                  // CUDASW4_AMD_ROWS=never|always (0 / 2): the row-parallel kernel for partition 35 never / whatever the time estimate says
+    int64_t rowsLaunches = 0;          // side launches that ran row-parallel, since the driver was created
     bool windows = true;               // CUDASW4_AMD_NO_WINDOWS=1 turns them off (A/B measurements, tests)
     bool windowsAlways = false;        // CUDASW4_AMD_WINDOWS=always: whenever the bound cuts a subject, whatever the time estimate says
     int64_t windowLaunches = 0, windowCount = 0;  // side launches that ran on windows / windows scanned, since the driver was created
@@ -520,6 +524,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             if (const char* e = std::getenv("CUDASW4_AMD_TAIL_GATE")) g->laneGate = !(e[0] == '0');
             if (const char* e = std::getenv("CUDASW4_AMD_RESCORE_SERVICE")) g->svcForce = e[0] == '1' ? 1 : 0;
         }
+        if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : 1;
+        if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : 1;
         if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_WINDOWS")) g->windowsAlways = std::string(e) == "always";
         if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
@@ -935,8 +941,28 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     const hipStream_t work = second ? g.stream2 : g.stream;
     const int workTemp = second ? GpuT::kAux + 1 : 0;
     const hipEvent_t fork = g.forkEvent[second ? 1 : 0];
+    // Latency mode.  Partition 34 (1281 ... 8000 residues) normally joins the bulk launch from 512 subjects up: one grid of
+    // 16-lane groups that takes the long subjects first.  A 16-lane group walks an 8000-residue subject for 8000 x
+    // (stripes of the query) steps of ~0.29 us — 26 ms for a 5 478-residue query — and on a SHARD of a real DB the whole bulk
+    // launch is shorter than that (71 000 Swiss-Prot-like subjects: 15 ms of work, measured 50 ms).  Then the partition
+    // keeps a launch of its own on wave-wide groups (a subject done 3 x sooner, sw_set_long16_min) beside the bulk launch:
+    // 71 250-subject shard, 20 queries, 224 -> 192 ms per pass (tools/shard_proxy.sh).  CUDASW4_AMD_LATENCY_MODE=never|always.
+    bool latencyMode = g.latencyMode == 2;
+    if (g.latencyMode == 1 && slot < 0) {
+        constexpr int kSmallLong = kNumLengthPartitions - 2;
+        const size_t b34 = std::max(lbegin, g.localBegin[kSmallLong]), e34 = std::min(lend, g.localBegin[kSmallLong + 1]);
+        if (e34 > b34 && e34 - b34 >= kLongPartitionMergeMin) {
+            const double longest = double(db.length(size_t(g.toGlobal(int64_t(e34 - 1)))));
+            const double tLong16 = longest * std::ceil(double(g.qlen) / 512.0) * 0.29e-6;
+            const double tAll = double(g.localOffsets[lend] - g.localOffsets[lbegin]) * double(g.qlen) / 1e13;
+            latencyMode = tLong16 >= 0.5 * tAll;
+        }
+    }
+    SWCHECK(sw_set_long16_min(g.ctx, latencyMode ? INT32_MAX : -1));
     const auto runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, lend,
-                                       [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); });
+                                       [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); },
+                                       latencyMode ? SIZE_MAX : kLongPartitionMergeMin);
+    if (latencyMode) g.latencyScans++;
     const uint64_t* offsets = g.d_offsets + lbegin;
     const int32_t* lengths = g.d_lengths + lbegin;
     // Every packed run keeps its own overflow list (the slice of d_ovfPos at its first subject) and counter, and is
@@ -995,6 +1021,44 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // 35 000 dependent steps: for a query of a few hundred residues that single group outlasted the scan of everything
     // else.  Cut into windows of C = max(W, 2048) columns plus W columns of run-in, the same subjects are dozens of
     // independent groups.  Returns false when the run is to be launched as it is.
+    // Rough clocks of a side launch of long subjects and of the bulk launch beside it: a wave-wide group alone on its SIMD
+    // issues a dependent step of R rows in ~(6.5 R + 19) * 8 cycles (measured: 60 ms for 35 000 columns x 11 stripes, this
+    // says 91); the bulk runs at ~10 TCUPS.
+    auto giant_seconds = [&](const LaunchRun& r) {
+        const double rows = std::ceil(double(g.qlen) / 64.0), stripes = std::ceil(rows / 8.0);
+        return double(r.maxlen) * stripes * (6.5 * std::min(rows, 8.0) + 19.0) * 8.0 / 2.4e9;
+    };
+    auto bulk_seconds = [&]() {
+        return double(g.localOffsets[runs[mainIdx].end] - g.localOffsets[runs[mainIdx].begin]) * double(g.qlen) / 10e12;
+    };
+    // The few subjects of partition 35, ROW-parallel (include/cudasw4_amd.h: sw_scan_rows): a whole workgroup of 1024
+    // threads per subject instead of one wave, 3 x faster for a long query and 20 x for a short one, for 2.3 x the
+    // instructions — so only where the one-wave launch would be (close to) what the scan waits for: shards of a real DB,
+    // short queries.  Returns false when the run is to be launched as it is.
+    auto launch_rows = [&](size_t ri, hipStream_t stream) -> bool {
+        const LaunchRun& r = runs[ri];
+        if (g.rowsMode == 0 || is_packed(r.kind) || r.part_id != kNumLengthPartitions - 1) return false;
+        if (gop > gex || r.maxlen > sw_scan_rows_max_subject() || r.end - r.begin > 64) return false;
+        if (g.rowsMode != 2 && giant_seconds(r) < 0.8 * bulk_seconds()) return false;
+        const int32_t n = int32_t(r.end - r.begin);
+        TimedLaunch t;
+        const bool record = recordMode == 1;
+        if (record) {
+            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
+            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
+            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = false;
+            t.eff_kind = SW_KIND_I32; t.rows = (r.maxlen + 1023) / 1024; t.nstripes = 1; t.lanes = 1024;
+            HIPCHECK(hipEventRecord(t.ev0, stream));
+        }
+        SWCHECK(sw_scan_rows(g.ctx, chars, offsets, lengths, int32_t(r.begin - lbegin), n, r.maxlen, gop, gex, g.d_scores + lbegin,
+                             g.d_ids + lbegin, int64_t(lbegin), stream));
+        if (record) {
+            HIPCHECK(hipEventRecord(t.ev1, stream));
+            g.timed.push_back(t);
+        }
+        g.rowsLaunches++;
+        return true;
+    };
     auto launch_windows = [&](size_t ri, hipStream_t stream, int a) -> bool {
         const LaunchRun& r = runs[ri];
         if (!g.windows || is_packed(r.kind)) return false;
@@ -1007,12 +1071,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         // +47 % at 48, +23 % at 96, +4.5 % at 144, +3 % at 189).  Rough clocks: a wave-wide group alone on its SIMD issues a
         // dependent step of R rows in ~(6.5 R + 19) * 8 cycles; the bulk runs at ~10 TCUPS.  CUDASW4_AMD_WINDOWS=always
         // skips the estimate (tests).
-        if (!g.windowsAlways) {
-            const double rows = std::ceil(double(g.qlen) / 64.0), stripes = std::ceil(rows / 8.0);
-            const double tGiant = double(r.maxlen) * stripes * (6.5 * std::min(rows, 8.0) + 19.0) * 8.0 / 2.4e9;
-            const double tBulk = double(g.localOffsets[runs[mainIdx].end] - g.localOffsets[runs[mainIdx].begin]) * double(g.qlen) / 10e12;
-            if (tGiant < 1.15 * tBulk) return false;
-        }
+        if (!g.windowsAlways && giant_seconds(r) < 1.15 * bulk_seconds()) return false;
         const size_t nreal = r.end - r.begin;
         // host side: windows of every subject of the run
         size_t nwin = 0;
@@ -1124,7 +1183,12 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
             g.timed.push_back(t);
         }
     };
-    int auxNext = 0;
+    // Two queries in flight: the side launches of consecutive queries start on different auxiliary streams, so that the
+    // long-subject launch of query i + 1 runs beside the one of query i instead of behind it.  On a small shard of a real
+    // DB that launch outlasts everything else — one 35 000-residue subject is one wave's 35 000 dependent steps per
+    // stripe of the query, 60 ms for a 5 478-residue query whatever the shard's size — and the queries' long-subject
+    // launches back to back are the floor of the whole stream (tools/shard_proxy.sh).
+    int auxNext = g.lastLane == 1 && slot < 0 ? 1 : 0;
     bool auxBusy[GpuT::kAux] = {};
     std::vector<int> streamOf(runs.size(), -1);  // auxiliary stream of a run, -1: work stream
     bool anySide = false;
@@ -1139,7 +1203,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
             g.sideLaunches++;
             anySide = true;
         }
-        if (!launch_windows(i, g.aux[a], a)) launch(i, g.aux[a], a + 1);
+        if (!launch_rows(i, g.aux[a]) && !launch_windows(i, g.aux[a], a)) launch(i, g.aux[a], a + 1);
     }
     if (useService) {
         const LaunchRun& r = runs[mainIdx];
@@ -1687,6 +1751,18 @@ void SearchDriver::windowStats(int64_t* launches, int64_t* windows) const {
     if (launches) *launches = l;
     if (windows) *windows = w;
 }
+int64_t SearchDriver::latencyScans() const {
+    int64_t n = 0;
+    for (auto& gp : gpus_) n += gp->latencyScans;
+    return n;
+}
+
+int64_t SearchDriver::rowsLaunches() const {
+    int64_t n = 0;
+    for (auto& gp : gpus_) n += gp->rowsLaunches;
+    return n;
+}
+
 int64_t SearchDriver::tailOverlaps() const {
     int64_t n = 0;
     for (auto& gp : gpus_) n += gp->laneOverlaps;

@@ -82,14 +82,15 @@ constexpr size_t kLongPartitionMergeMin = 512;
 // created in, 10.0 ... 11.15 TCUPS on the Swiss-Prot-like DB).  A merged run reports part_id 33.
 // maxLenOf(pos) = true length of the subject at pos.
 // The ONE planner: the Python mirror (cudasw4_amd/search.py) calls it through swdrv_plan_runs.
+// mergeMin: partition 34 merges from this many subjects up (SIZE_MAX: never — the driver's latency mode, search_driver.cpp)
 template <class MaxLenOf>
 std::vector<LaunchRun> plan_launch_runs(const KernelTypeConfig& kt, const size_t* partBegin, size_t begin, size_t end,
-                                        MaxLenOf&& maxLenOf) {
+                                        MaxLenOf&& maxLenOf, size_t mergeMin = kLongPartitionMergeMin) {
     std::vector<LaunchRun> runs;
     constexpr int kSmallLong = kNumLengthPartitions - 2, kLargeLong = kNumLengthPartitions - 1;
     auto shape_of = [&](int p, size_t count) {  // 2: giants, 1: few long subjects, 0: bulk
         if (p == kLargeLong) return 2;
-        if (p == kSmallLong && count < kLongPartitionMergeMin) return 1;
+        if (p == kSmallLong && count < mergeMin) return 1;
         return 0;
     };
     int lastShape = -1;
@@ -212,6 +213,8 @@ public:
     // windows they scanned, since the driver was created
     void windowStats(int64_t* launches, int64_t* windows) const;
     int64_t serviceLaunches() const;   // re-score service launches (sw_rescore_service) since the driver was created
+    int64_t latencyScans() const;      // scans planned in latency mode (partition 34 on wave-wide groups beside the bulk launch: small shards of real DBs)
+    int64_t rowsLaunches() const;      // side launches of partition 35 that ran row-parallel (sw_scan_rows) since the driver was created
     // queries whose bulk launch was gated on the dry signal of the query before it (tail hand-over between two queries in
     // flight: submit() while a query is pending, resident shards of a few rounds of workgroups), since the driver was created
     int64_t tailOverlaps() const;

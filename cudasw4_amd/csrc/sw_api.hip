@@ -15,6 +15,7 @@
 
 #include "../../include/cudasw4_amd.h"
 #include "sw_launch.hpp"
+#include "sw_rows_kernel.hpp"
 
 namespace {
 
@@ -153,7 +154,8 @@ struct sw_ctx {
     bool have_query = false;
     Profile profiles[4][3][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups, 2 = 8-lane groups][plain | column-offset recurrence]
     bool use_offs = true;        // CUDASW4_AMD_NO_OFFS=1: always the plain recurrence (A/B measurements)
-    int64_t long16_min = -1;     // CUDASW4_AMD_LONG16_MIN: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
+    int64_t long16_min = -1;     // CUDASW4_AMD_LONG16_MIN / sw_set_long16_min: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
+    int64_t long16_min_default = -1;  // what the environment said at creation (sw_set_long16_min(ctx, -1) returns to it)
     int matrix_max = 1;          // largest substitution score of the installed matrix
     bool i32_native = false;     // CUDASW4_AMD_I32_NATIVE=1: never compute the int32 kind in fp32 lanes (tests of the int32 kernels)
     int32_t lanes8_max_subject = -1;  // CUDASW4_AMD_LANES8_MAX_SUBJECT: multi-stripe queries use 8-lane groups when no subject of the launch is longer (-1: built-in)
@@ -430,7 +432,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     ctx->num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
-    if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = atoll(e);
+    if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = ctx->long16_min_default = atoll(e);
     if (const char* e = getenv("CUDASW4_AMD_I32_NATIVE")) ctx->i32_native = e[0] == '1';
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_Q")) ctx->lanes8_max_q = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_SUBJECT")) ctx->lanes8_max_subject = atoi(e);
@@ -587,10 +589,56 @@ int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal) {
     return SW_OK;
 }
 
+int32_t sw_scan_rows_max_subject(void) { return swk::kRowsMaxSubject; }
+
+int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos, int32_t n,
+                 int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* stream_) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    // one-shot signals belong to this call whatever happens to it (scan_common)
+    uint32_t* const start_signal = ctx->start_signal;
+    ctx->start_signal = nullptr;
+    ctx->dry_signal = nullptr;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n < 0 || max_subject_len < 0) return fail(SW_ERR_INVALID, "negative count or length");
+    if (gop > 0 || gex > 0) return fail(SW_ERR_INVALID, "gap scores must be <= 0");
+    if (gop > gex) return fail(SW_ERR_INVALID, "sw_scan_rows needs gop <= gex (the prefix form of the horizontal gap)");
+    if (gex < -10000 || gop < -100000) return fail(SW_ERR_INVALID, "gap score out of range for sw_scan_rows");
+    if (max_subject_len > swk::kRowsMaxSubject) return fail(SW_ERR_INVALID, "subject too long for sw_scan_rows (sw_scan_rows_max_subject)");
+    if (!ctx->have_matrix) return fail(SW_ERR_NO_MATRIX, "sw_set_matrix has not been called");
+    if (!ctx->have_query) return fail(SW_ERR_NO_QUERY, "sw_set_query has not been called");
+    if (n == 0) return SW_OK;
+    if (!chars || !offsets || !lengths || !scores || !ids) return fail(SW_ERR_INVALID, "null buffer");
+    SW_HIP(hipSetDevice(ctx->device));
+    swk::RowsParams p{};
+    p.chars = chars; p.offsets = offsets; p.lengths = lengths; p.first_pos = first_pos;
+    p.query = ctx->d_query; p.qlen = ctx->qlen; p.matrix = ctx->d_matrix; p.dim = ctx->dim;
+    p.gop = gop; p.gex = gex; p.scores = scores; p.ids = ids; p.id_offset = id_offset;
+    p.start_counter = ctx->d_work + 2 * (ctx->work_next++ % kWorkSlots) + 1;
+    SW_HIP(hipMemsetAsync(p.start_counter, 0, sizeof(uint32_t), stream));
+    p.start_signal = start_signal;
+    p.start_quorum = (uint32_t)std::min(n, 64);
+    // columns per thread: the smallest compiled width that covers the longest subject of the launch
+    const int cpl = (max_subject_len + swk::kRowsThreads - 1) / swk::kRowsThreads;
+    const dim3 grid(n), block(swk::kRowsThreads);
+    if (cpl <= 8) hipLaunchKernelGGL(swk::sw_rows_kernel<8>, grid, block, 0, stream, p);
+    else if (cpl <= 16) hipLaunchKernelGGL(swk::sw_rows_kernel<16>, grid, block, 0, stream, p);
+    else if (cpl <= 24) hipLaunchKernelGGL(swk::sw_rows_kernel<24>, grid, block, 0, stream, p);
+    else if (cpl <= 32) hipLaunchKernelGGL(swk::sw_rows_kernel<32>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(swk::sw_rows_kernel<40>, grid, block, 0, stream, p);
+    SW_HIP(hipGetLastError());
+    return SW_OK;
+}
+
 int sw_set_dry_signal(sw_ctx* ctx, uint32_t* signal, uint32_t value) {
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
     ctx->dry_signal = signal;
     ctx->dry_value = value;
+    return SW_OK;
+}
+
+int sw_set_long16_min(sw_ctx* ctx, int32_t subjects) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    ctx->long16_min = subjects < 0 ? ctx->long16_min_default : subjects;
     return SW_OK;
 }
 

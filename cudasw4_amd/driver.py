@@ -22,7 +22,8 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
            "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency", "swdrv_numa_node", "swdrv_device_of",
            "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats", "swdrv_service_launches",
-           "swdrv_tail_overlaps", "swdrv_prefers_two_in_flight"]
+           "swdrv_tail_overlaps", "swdrv_prefers_two_in_flight", "swdrv_rows_launches",
+           "swdrv_latency_scans"]
 
 
 class DriverError(RuntimeError):
@@ -93,6 +94,10 @@ def _load():
     L.swdrv_numa_node.argtypes = [vp, ctypes.c_int]
     L.swdrv_service_launches.restype = ctypes.c_int64
     L.swdrv_service_launches.argtypes = [vp]
+    L.swdrv_latency_scans.restype = ctypes.c_int64
+    L.swdrv_latency_scans.argtypes = [vp]
+    L.swdrv_rows_launches.restype = ctypes.c_int64
+    L.swdrv_rows_launches.argtypes = [vp]
     L.swdrv_tail_overlaps.restype = ctypes.c_int64
     L.swdrv_tail_overlaps.argtypes = [vp]
     L.swdrv_prefers_two_in_flight.argtypes = [vp, ctypes.c_int32]
@@ -313,6 +318,14 @@ class Driver:
         """True when the tail hand-over applies (small resident shards, or a query of query_length residues that is scanned
         in a few milliseconds): use scan_many / submit + collect."""
         return bool(lib.swdrv_prefers_two_in_flight(self.handle, int(query_length)))
+
+    def latency_scans(self):
+        """Scans planned in latency mode (swdrv_latency_scans)."""
+        return int(lib.swdrv_latency_scans(self.handle))
+
+    def rows_launches(self):
+        """Side launches of partition 35 that ran row-parallel (swdrv_rows_launches)."""
+        return int(lib.swdrv_rows_launches(self.handle))
 
     def tail_overlaps(self):
         """Queries whose bulk launch was gated on the dry signal of the query before (swdrv_tail_overlaps)."""

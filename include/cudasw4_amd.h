@@ -192,6 +192,27 @@ int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b);
  * has n == 0 (nothing is enqueued, nothing will fire: do not wait for it). */
 int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
 
+/* The few VERY long subjects of a real DB (partition 35: more than 8000 residues, 35 000 in Swiss-Prot), row-parallel.
+ * sw_scan_partition gives a subject to one alignment group — for these one wave —, which walks its columns one by one:
+ * 35 000 dependent steps per stripe of the query, whatever else the GPU does (the reference has the same shape: one
+ * thread group per subject, cudasw4.cuh:1832-1850).  Beside the bulk launch of a whole DB that is hidden; on a shard of a
+ * DB (what each of N GPUs gets) it is the floor of every query, and for short queries it outlasts the bulk launch on one
+ * GPU.  sw_scan_rows gives every subject of [first_pos, first_pos + n) a WORKGROUP of 1024 threads that walks the query
+ * row by row, all columns of the subject at once, the horizontal gap as a max-plus prefix over the workgroup (exact for
+ * gop <= gex; csrc/sw_rows_kernel.hpp).  int32 arithmetic; same scores (as floats) and ids as sw_scan_partition with a
+ * 32-bit kind, no overflow list, no scratch.  max_subject_len must not exceed sw_scan_rows_max_subject() (40 960);
+ * honours sw_set_start_signal.  Errors (SW_ERR_INVALID): gop > gex, a subject bound above the limit. */
+int32_t sw_scan_rows_max_subject(void);
+int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos,
+                 int32_t n, int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
+                 void* stream);
+
+/* Sticky: partition 34 (1281 ... 8000 residues) runs on 16-lane groups from `subjects` subjects of a launch up and on
+ * wave-wide groups below (default 512; < 0: back to the default).  Wave-wide groups finish ONE subject 3 x sooner at 60 %
+ * of the throughput: a caller whose launch is short against its longest subject's walk on 16 lanes — a small shard of a
+ * real DB — asks for them whatever the count (the host driver's latency mode). */
+int sw_set_long16_min(sw_ctx* ctx, int32_t subjects);
+
 /* Tail hand-over between consecutive queries.  The reference scans one query at a time (main.cu:217-260); on a small
  * shard (what each of N GPUs gets from a DB) the last, partly filled round of a query's persistent grid leaves most of
  * the GPU idle.  sw_set_dry_signal is one-shot like sw_set_start_signal: the NEXT sw_scan_partition launch of this

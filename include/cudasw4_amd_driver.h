@@ -121,6 +121,14 @@ int swdrv_window_stats(swdrv* d, int64_t* launches, int64_t* windows);
  * re-scored while it was being filled.  CUDASW4_AMD_RESCORE_SERVICE=0|1 forces the service off / on; by default it runs
  * while recent scans re-scored anything. */
 int64_t swdrv_service_launches(swdrv* d);
+/* side launches of the longest subjects (partition 35) that ran row-parallel (include/cudasw4_amd.h: sw_scan_rows) since
+ * swdrv_create: taken when the one-wave-per-subject launch would be what the scan waits for (shards of a real DB, short
+ * queries).  CUDASW4_AMD_ROWS=never|always overrides the estimate. */
+int64_t swdrv_rows_launches(swdrv* d);
+/* scans planned in LATENCY MODE since swdrv_create: partition 34 (1281 ... 8000 residues) on wave-wide groups beside the
+ * bulk launch instead of inside it, when the whole launch is short against the walk of its longest subject on 16 lanes
+ * (small shards of real DBs).  CUDASW4_AMD_LATENCY_MODE=never|always overrides the estimate. */
+int64_t swdrv_latency_scans(swdrv* d);
 /* Tail hand-over between two queries in flight (include/cudasw4_amd.h: sw_set_dry_signal): a query submitted with
  * swdrv_submit while the one before is still pending runs on a second lane of the GPU (context, work stream, score arrays)
  * and its bulk launch starts when the earlier one's work counter runs dry, filling the slots its last round leaves idle —

@@ -288,6 +288,48 @@ def test_tail_hand_over_between_two_queries_in_flight(kinds, monkeypatch):
         assert sum(o[3] for o in runs["lanes"][0]) > 0
 
 
+@pytest.mark.parametrize("kinds", [(1, 1, 2, 2), (0, 0, 3, 3)])
+def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
+    """Small shards of real DBs: partition 34 on wave-wide groups beside the bulk launch (latency mode, sw_set_long16_min)
+    and the giants of partition 35 row-parallel (sw_scan_rows), each forced on, forced off and left to the driver's
+    estimates: every score of every query equals the oracle in every combination, the counters say which path ran."""
+    from cudasw4_amd import driver, synthdb
+    rng = np.random.default_rng(5)
+    _, letters = O.read_fasta(FASTA)
+    queries = [letters[11][:60], letters[5], letters[11]]      # 60, 567 and 2005 residues
+    fam = synthdb.family_members([O.encode(q) for q in queries[1:]], seed=3, min_size=30, max_size=30)
+    lens = np.concatenate([synthdb.sprot_like_lengths(6000, seed=28, max_len=1200), rng.integers(1281, 7900, 700),
+                           np.array([8001, 9500, 15000, 26000, 40960])])
+    bg = synthdb.random_db(np.sort(lens).astype(np.int32), seed=29, composition=synthdb.SPROT_COMPOSITION)
+    seqs = [bg[0][int(bg[1][i]):int(bg[1][i]) + int(bg[2][i])] for i in range(len(lens))] + list(fam)
+    seqs.sort(key=len)
+    chars, offsets, lengths = O.make_db(seqs)
+    expect = [O.scan(O.encode(q), chars, offsets, lengths, simd=True) for q in queries]
+    seen = {}
+    for rows in ("never", "always", None):
+        for lat in ("never", "always", None):
+            for name, val in (("CUDASW4_AMD_ROWS", rows), ("CUDASW4_AMD_LATENCY_MODE", lat)):
+                if val is None:
+                    monkeypatch.delenv(name, raising=False)
+                else:
+                    monkeypatch.setenv(name, val)
+            d = driver.Driver(devices=[0], num_top=15, kinds=kinds)
+            d.db_from_arrays(chars, offsets, lengths)
+            d.upload()
+            tops = []
+            for qi, q in enumerate(queries):
+                r = d.scan(q)
+                sc, _ = d.last_scores(0)
+                assert (sc == expect[qi]).all(), (rows, lat, qi, np.nonzero(sc != expect[qi])[0][:5], lengths[np.nonzero(sc != expect[qi])[0][:5]])
+                tops.append((r["scores"].tolist(), r["ids"].tolist(), r["num_overflows"]))
+            seen[(rows, lat)] = (tops, d.rows_launches(), d.latency_scans())
+            d.close()
+    assert len({str(v[0]) for v in seen.values()}) == 1
+    assert seen[("never", "never")][1:] == (0, 0)
+    assert seen[("always", "always")][1:] == (3, 3)
+    assert seen[(None, None)][1] >= 1 and seen[(None, None)][2] >= 1     # this DB is a "small shard": the estimates say so
+
+
 @pytest.mark.parametrize("dpx", [False, True])
 def test_documented_binding_runs_on_the_gpu(dpx):
     """VERDICT r3 test gap (ii): the reference-side binding of INTEGRATION.md section 2 — the verbatim code block, compiled

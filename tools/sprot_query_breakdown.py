@@ -7,7 +7,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cudasw4_amd import driver, synthdb
-chars, offsets, lengths = synthdb.sprot_like()
+SIZE = int(os.environ.get("BREAKDOWN_DB_SIZE", synthdb.SPROT_SEQUENCES))  # a smaller DB of the same length distribution = a shard
+chars, offsets, lengths = synthdb.sprot_like(SIZE)
 residues = float(lengths.astype(np.int64).sum())
 _, letters = driver.read_sequences(os.path.join(ROOT, "tests", "golden", "allqueries.fasta"))
 kinds = (1, 1, 2, 2) if "--half2" not in sys.argv else (0, 0, 3, 3)
