@@ -624,6 +624,7 @@ int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, cons
     else if (cpl <= 16) hipLaunchKernelGGL(swk::sw_rows_kernel<16>, grid, block, 0, stream, p);
     else if (cpl <= 24) hipLaunchKernelGGL(swk::sw_rows_kernel<24>, grid, block, 0, stream, p);
     else if (cpl <= 32) hipLaunchKernelGGL(swk::sw_rows_kernel<32>, grid, block, 0, stream, p);
+    else if (cpl <= 36) hipLaunchKernelGGL(swk::sw_rows_kernel<36>, grid, block, 0, stream, p);   // (Swiss-Prot's longest: 35 213)
     else hipLaunchKernelGGL(swk::sw_rows_kernel<40>, grid, block, 0, stream, p);
     SW_HIP(hipGetLastError());
     return SW_OK;

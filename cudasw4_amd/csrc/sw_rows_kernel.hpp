@@ -56,7 +56,7 @@ __device__ __forceinline__ int rows_dpp(int v) {
     return __builtin_amdgcn_update_dpp(kRowsNeg, v, CTRL, ROW_MASK, 0xf, false);
 }
 
-template <int CPL>  // a multiple of 8
+template <int CPL>  // a multiple of 4
 __global__ void __launch_bounds__(kRowsThreads) sw_rows_kernel(const RowsParams p) {
     __shared__ int sub[26 * kRowsSubCols];
     __shared__ int xT[2][kRowsWaves], xX[2][kRowsWaves], xM1[2][kRowsWaves], xH[2][kRowsWaves];
@@ -120,19 +120,20 @@ __global__ void __launch_bounds__(kRowsThreads) sw_rows_kernel(const RowsParams 
         }
         // ---- pass 1: F and H~ of the owned columns; m = max over them of G' = H~ - c * gex (lane-local frame)
         int m = kRowsNeg, m1 = kRowsNeg, prevUp = hleft;
-        // eight columns at a time: their substitution scores are requested together, and a scheduling fence between the
+        // eight (four) columns at a time: their substitution scores are requested together, and a scheduling fence between the
         // groups keeps the compiler from requesting all CPL of them at once (CPL more live registers)
+        constexpr int kChunk = CPL % 8 == 0 ? 8 : 4;
 #pragma unroll
-        for (int c0 = 0; c0 < CPL; c0 += 8) {
-            int sc[8];
+        for (int c0 = 0; c0 < CPL; c0 += kChunk) {
+            int sc[kChunk];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < kChunk; u++) {
                 const int c = c0 + u;
                 const int lofs = (int)((lw[c >> 2] >> (8 * (c & 3))) & 0xffu);
                 sc[u] = *reinterpret_cast<const int*>(srow + lofs);
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < kChunk; u++) {
                 const int c = c0 + u;
                 const int up = H[c];
                 const int f = max(F[c] + gex, up + gop);

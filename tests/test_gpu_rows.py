@@ -55,7 +55,7 @@ def run_rows(torch, capi, search, ctx, seqs, q, gop, gex, maxlen=None):
     np.testing.assert_array_equal(ids.cpu().numpy(), 1000 + np.arange(n))
 
 
-@pytest.mark.parametrize("width", [8, 16, 24, 32, 40])
+@pytest.mark.parametrize("width", [8, 16, 24, 32, 36, 40])
 def test_rows_every_width_against_oracle(width):
     torch, capi, search = gpu_modules()
     rng = np.random.default_rng(100 + width)
@@ -63,7 +63,7 @@ def test_rows_every_width_against_oracle(width):
     ctx.set_matrix(O.blosum21(62))
     top = 1024 * width
     q = rng.integers(0, 20, 333).astype(np.int8)
-    lens = [top, top - 1, top - width, top - 64 * width + 3, 1024 * (width - 8) + 1, 8001, 5, 1]
+    lens = [top, top - 1, top - width, top - 64 * width + 3, max(1, 1024 * (width - 8) + 1), 8001, 5, 1]
     seqs = [rng.integers(0, 21, int(l)).astype(np.int8) for l in lens]
     seqs += relatives(rng, q, 4, max(2000, top // 2), top)
     run_rows(torch, capi, search, ctx, seqs, q, -11, -1, maxlen=top)
