@@ -326,7 +326,8 @@ def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
             d.close()
     assert len({str(v[0]) for v in seen.values()}) == 1
     assert seen[("never", "never")][1:] == (0, 0)
-    assert seen[("always", "always")][1:] == (3, 3)
+    # (where the span bound cuts the giants — the 60- and the 567-residue query — they run as windows instead of rows)
+    assert 1 <= seen[("always", "always")][1] <= 3 and seen[("always", "always")][2] == 3
     assert seen[(None, None)][1] >= 1 and seen[(None, None)][2] >= 1     # this DB is a "small shard": the estimates say so
 
 
