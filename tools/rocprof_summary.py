@@ -104,10 +104,9 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
         cur = json.load(open(out_path))
     except (OSError, ValueError):
         cur = {}
-    h = hashlib.sha256()
-    for rel in ("cudasw4_amd/csrc/sw_dp_kernel.hpp", "cudasw4_amd/csrc/sw_launch.hpp", "cudasw4_amd/csrc/sw_api.hip", "cudasw4_amd/csrc/Makefile"):
-        h.update(open(os.path.join(root, rel), "rb").read())
-    sha = h.hexdigest()[:16]
+    sys.path.insert(0, root)
+    import bench  # the ONE list of kernel sources and the one hash over them (bench.py: KERNEL_SOURCES, kernel_source_sha)
+    sha = bench.kernel_source_sha()
     if cur.get("kernel_src_sha16") != sha or "traffic_bytes_per_char" not in cur:
         cur = {"kernel_src_sha16": sha, "valu_instr_per_unit": {}, "traffic_bytes_per_char": {}}
     key = "%s:%s:%s%s" % (workload, kernel_cfg, residency, native)
