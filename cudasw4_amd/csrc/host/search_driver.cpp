@@ -1456,6 +1456,11 @@ bool SearchDriver::prepareLane(Gpu& g, int32_t queryLength) {
         }
         if (!g.lane1Ready) {
             const size_t n = std::max<size_t>(g.numLocal, 1);
+            // the second set of result arrays is not in the residency plan's budget: only with room to spare (a shard that
+            // fills the device keeps one lane rather than risk the scratch buffers it still has to grow)
+            size_t freeMem = 0, totalMem = 0;
+            HIPCHECK(hipMemGetInfo(&freeMem, &totalMem));
+            if (freeMem < 4 * n * 12 + (size_t(1) << 30)) { g.lanesFailed = true; return false; }
             HIPCHECK(hipMalloc(&g.lane1.d_scores, n * sizeof(float)));
             HIPCHECK(hipMalloc(&g.lane1.d_ids, n * sizeof(int32_t)));
             HIPCHECK(hipMalloc(&g.lane1.d_ovfPos, n * sizeof(int32_t)));
