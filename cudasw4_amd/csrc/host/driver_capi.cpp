@@ -227,6 +227,11 @@ int swdrv_gpu_spans(swdrv* d, double* out, int cap) {
 
 int swdrv_plan_runs(const int32_t* sorted_lengths, size_t n, int kind_single, int kind_many_small, int kind_many_large,
                     int64_t* out, int cap) {
+    return swdrv_plan_runs_mode(sorted_lengths, n, kind_single, kind_many_small, kind_many_large, 0, out, cap);
+}
+
+int swdrv_plan_runs_mode(const int32_t* sorted_lengths, size_t n, int kind_single, int kind_many_small, int kind_many_large,
+                         int latency_mode, int64_t* out, int cap) {
     int nruns = -1;
     const int rc = guarded([&] {
         for (int k : {kind_single, kind_many_small, kind_many_large})
@@ -240,7 +245,8 @@ int swdrv_plan_runs(const int32_t* sorted_lengths, size_t n, int kind_single, in
             first = std::upper_bound(first, sorted_lengths + n, bounds[size_t(p)]);
             partBegin[p + 1] = size_t(first - sorted_lengths);
         }
-        const auto runs = plan_launch_runs(kc, partBegin, 0, n, [&](size_t pos) { return sorted_lengths[pos]; });
+        const auto runs = plan_launch_runs(kc, partBegin, 0, n, [&](size_t pos) { return sorted_lengths[pos]; },
+                                           latency_mode ? SIZE_MAX : kLongPartitionMergeMin);
         nruns = int(runs.size());
         for (int i = 0; i < nruns && i < cap; i++) {
             int64_t* o = out + size_t(i) * 5;

@@ -23,7 +23,7 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency", "swdrv_numa_node", "swdrv_device_of",
            "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats", "swdrv_service_launches",
            "swdrv_tail_overlaps", "swdrv_prefers_two_in_flight", "swdrv_rows_launches",
-           "swdrv_latency_scans"]
+           "swdrv_latency_scans", "swdrv_plan_runs_mode"]
 
 
 class DriverError(RuntimeError):
@@ -88,6 +88,7 @@ def _load():
     L.swdrv_batch_intervals.argtypes = [vp, vp, ctypes.c_int]
     L.swdrv_gpu_spans.argtypes = [vp, vp, ctypes.c_int]
     L.swdrv_plan_runs.argtypes = [vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
+    L.swdrv_plan_runs_mode.argtypes = [vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
     L.swdrv_shard_ranges.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.swdrv_matrix25.argtypes = [ctypes.c_int, vp]
     L.swdrv_last_rescored.argtypes = [vp]
@@ -185,12 +186,14 @@ def _check(rc):
         raise DriverError(lib.swdrv_last_error().decode())
 
 
-def plan_runs(sorted_lengths, kind_single, kind_many_small, kind_many_large):
+def plan_runs(sorted_lengths, kind_single, kind_many_small, kind_many_large, latency_mode=False):
     """The launch planner of the C++ driver (plan_launch_runs; no GPU needed): runs of a length-sorted subject list,
-    largest partition first -> list of dicts (kind, part_id, begin, end, maxlen)."""
+    largest partition first -> list of dicts (kind, part_id, begin, end, maxlen).  latency_mode: the plan of small shards
+    of real DBs (partition 34 keeps a launch of its own whatever its size)."""
     l = np.ascontiguousarray(sorted_lengths, dtype=np.int32)
     out = np.zeros(36 * 5, dtype=np.int64)
-    n = lib.swdrv_plan_runs(l.ctypes.data, len(l), kind_single, kind_many_small, kind_many_large, out.ctypes.data, 36)
+    n = lib.swdrv_plan_runs_mode(l.ctypes.data, len(l), kind_single, kind_many_small, kind_many_large, int(bool(latency_mode)),
+                                 out.ctypes.data, 36)
     if n < 0:
         raise DriverError(lib.swdrv_last_error().decode())
     return [{"kind": int(out[5 * i]), "part_id": int(out[5 * i + 1]), "begin": int(out[5 * i + 2]),

@@ -95,6 +95,10 @@ int swdrv_gpu_spans(swdrv* d, double* out, int cap);
  * 5 int64 per run (kind, part_id, begin, end, max length); returns the number of runs, -1 on error. */
 int swdrv_plan_runs(const int32_t* sorted_lengths, size_t n, int kind_single, int kind_many_small, int kind_many_large,
                     int64_t* out, int cap);
+/* the same; latency_mode != 0: the plan of the driver's latency mode (swdrv_latency_scans) — partition 34 keeps a launch
+ * of its own whatever its size */
+int swdrv_plan_runs_mode(const int32_t* sorted_lengths, size_t n, int kind_single, int kind_many_small, int kind_many_large,
+                         int latency_mode, int64_t* out, int cap);
 
 /* partitionDBAmongstGpus (cudasw4.cuh:928-1004) on raw arrays (no GPU needed): out[(rank*36 + partition)*2 + {0,1}] =
  * begin / end of the subject range of `rank` in `partition`. */

@@ -88,6 +88,16 @@ def test_one_planner_for_both_host_drivers():
     assert [r["part_id"] for r in driver.plan_runs(lengths, 2, 1, 2)] == [35, 33, 15]
     assert [r["part_id"] for r in driver.plan_runs(lengths[:5100], 1, 1, 2)] == [34, 15]
     assert driver.plan_runs(np.zeros(0, np.int32), 0, 0, 3) == []
+    # latency mode (small shards of real DBs): partition 34 keeps a launch of its own whatever its size — three runs, the
+    # same subjects, every subject in exactly one of them
+    lat = driver.plan_runs(lengths, 1, 1, 2, latency_mode=True)
+    assert [(r["part_id"], r["begin"], r["end"], r["maxlen"]) for r in lat] == [(35, 5600, 5603, 9000), (34, 5000, 5600, 2000), (15, 0, 5000, 300)]
+    for trial in range(8):
+        ls = np.sort(rng.choice([3, 64, 700, 1280, 1281, 5000, 8000, 8001, 20000], int(rng.integers(600, 5000)))).astype(np.int32)
+        runs = driver.plan_runs(ls, 1, 1, 2, latency_mode=True)
+        covered = sorted((r["begin"], r["end"]) for r in runs)
+        assert covered[0][0] == 0 and covered[-1][1] == len(ls) and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        assert all(r["part_id"] >= 34 or r["maxlen"] <= 1280 for r in runs)       # nothing of partition 34 inside a bulk run
     # the Python mirror's merged plan IS the C++ planner's
     import inspect
     assert "driver.plan_runs" in inspect.getsource(search.Searcher._launch_plan)
