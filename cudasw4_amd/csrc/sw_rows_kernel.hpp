@@ -5,7 +5,7 @@
 // the subject column by column: 35 000 dependent steps per stripe of the query, 60 ms for a 5 478-residue query on one
 // SIMD, whatever else the GPU does.  Beside the bulk launch of a whole DB that is hidden; on a SHARD of a real DB (what
 // each of N GPUs gets) it is the floor of every query (tools/shard_proxy.sh), and for a short query it outlasts the bulk
-// launch on one GPU already.  The reference has the same shape (one thread group per subject, cudasw4.cuh:1832-1850).
+// launch on one GPU already.  The reference has the same shape (one thread group per subject, cudasw4.cuh:2026-2103).
 //
 // Here one WORKGROUP of 1024 threads takes a subject and walks the QUERY row by row; every thread owns CPL consecutive
 // subject columns, so a row is up to 40 960 cells computed at once by a whole CU.  The dependency inside a row — the

@@ -195,7 +195,7 @@ int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
 /* The few VERY long subjects of a real DB (partition 35: more than 8000 residues, 35 000 in Swiss-Prot), row-parallel.
  * sw_scan_partition gives a subject to one alignment group — for these one wave —, which walks its columns one by one:
  * 35 000 dependent steps per stripe of the query, whatever else the GPU does (the reference has the same shape: one
- * thread group per subject, cudasw4.cuh:1832-1850).  Beside the bulk launch of a whole DB that is hidden; on a shard of a
+ * thread group per subject, cudasw4.cuh:2026-2103).  Beside the bulk launch of a whole DB that is hidden; on a shard of a
  * DB (what each of N GPUs gets) it is the floor of every query, and for short queries it outlasts the bulk launch on one
  * GPU.  sw_scan_rows gives every subject of [first_pos, first_pos + n) a WORKGROUP of 1024 threads that walks the query
  * row by row, all columns of the subject at once, the horizontal gap as a max-plus prefix over the workgroup (exact for
