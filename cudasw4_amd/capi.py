@@ -26,7 +26,8 @@ EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "s
            "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal",
            "sw_window_overlap", "sw_reduce_windows", "sw_rescore_service", "sw_rescore_overflow_claim",
            "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_grid_reserve",
-           "sw_scan_rows", "sw_scan_rows_max_subject", "sw_set_long16_min"]
+           "sw_scan_rows", "sw_scan_rows_max_subject", "sw_set_long16_min", "sw_scan_rows_pipelined",
+           "sw_scan_rows_pipelined_temp_bytes", "sw_probe_handshake"]
 
 
 class SwError(RuntimeError):
@@ -68,12 +69,16 @@ def _load():
     L.sw_plan_query.argtypes = [ctypes.c_int, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.sw_check_letter_codes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     L.sw_set_start_signal.argtypes = [vp, vp]
+    L.sw_probe_handshake.argtypes = [vp, vp, vp, vp]
     L.sw_set_dry_signal.argtypes = [vp, vp, ctypes.c_uint32]
     L.sw_set_grid_reserve.argtypes = [vp, i32]
     L.sw_set_long16_min.argtypes = [vp, i32]
     L.sw_scan_rows_max_subject.restype = i32
     L.sw_scan_rows_max_subject.argtypes = []
     L.sw_scan_rows.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp]
+    L.sw_scan_rows_pipelined_temp_bytes.restype = sz
+    L.sw_scan_rows_pipelined_temp_bytes.argtypes = [vp, i32, i32]
+    L.sw_scan_rows_pipelined.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp, vp, sz, vp]
     L.sw_window_overlap.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.sw_window_overlap.restype = i32
     L.sw_reduce_windows.argtypes = [vp, vp, vp, vp, i32, vp, vp, ctypes.c_int64, vp]
@@ -152,6 +157,15 @@ class Context:
         """The row-parallel scan of very long subjects (sw_scan_rows): one 1024-thread workgroup per subject."""
         check(lib.sw_scan_rows(self.handle, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
                                id_offset, stream))
+
+    def scan_rows_pipelined_temp_bytes(self, n, max_subject_len):
+        return int(lib.sw_scan_rows_pipelined_temp_bytes(self.handle, n, max_subject_len))
+
+    def scan_rows_pipelined(self, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids, id_offset=0,
+                            fail_count=0, temp=0, temp_bytes=0, stream=0):
+        """Very long subjects as pipelines of one-wave stages across many CUs (sw_scan_rows_pipelined)."""
+        check(lib.sw_scan_rows_pipelined(self.handle, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores,
+                                         ids, id_offset, fail_count, temp, temp_bytes, stream))
 
     def rescore_overflow(self, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len, gop, gex,
                          scores, ids, id_offset=0, temp=0, temp_bytes=0, stream=0):

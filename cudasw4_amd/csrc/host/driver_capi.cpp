@@ -324,6 +324,18 @@ int64_t swdrv_rows_launches(swdrv* d) {
     return n;
 }
 
+int swdrv_handshake_active(swdrv* d) {
+    int n = -1;
+    (void)guarded([&] { n = d->driver->handshakeActive() ? 1 : 0; });
+    return n;
+}
+
+int64_t swdrv_pipeline_launches(swdrv* d) {
+    int64_t n = -1;
+    (void)guarded([&] { n = d->driver->pipelineLaunches(); });
+    return n;
+}
+
 int64_t swdrv_tail_overlaps(swdrv* d) {
     int64_t n = -1;
     (void)guarded([&] { n = d->driver->tailOverlaps(); });

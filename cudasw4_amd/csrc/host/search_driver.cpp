@@ -248,8 +248,13 @@ struct SearchDriver::Gpu {
     int winNext[kAux] = {0, 0};
     int latencyMode = 1;               // CUDASW4_AMD_LATENCY_MODE=never|always (0 / 2): partition 34 on wave-wide groups beside the bulk launch never / always
     int64_t latencyScans = 0;          // scans (batches) planned in latency mode, since the driver was created
-    int rowsMode = 1;                  // CUDASW4_AMD_ROWS=never|always (0 / 2): the row-parallel kernel for partition 35 never / whatever the time estimate says
+    // CUDASW4_AMD_ROWS=never|always|single (0 / 2 / 3): the row-parallel kernels for partition 35 never / whatever the time
+    // estimate says / only the one-workgroup form of round 4 (sw_scan_rows), by its time estimate.  Default (1): the
+    // pipelined form (sw_scan_rows_pipelined) whenever it applies, else the one-workgroup form by its time estimate.
+    int rowsMode = 1;
     int64_t rowsLaunches = 0;          // side launches that ran row-parallel, since the driver was created
+    int64_t pipelineLaunches = 0;      // ... of them as pipelines of one-wave stages (sw_scan_rows_pipelined)
+    int32_t* failSlot = nullptr;       // device word of the current scan that counts pipeline stages that gave up (d_ovfCount's last)
     bool windows = true;               // CUDASW4_AMD_NO_WINDOWS=1 turns them off (A/B measurements, tests)
     bool windowsAlways = false;        // CUDASW4_AMD_WINDOWS=always: whenever the bound cuts a subject, whatever the time estimate says
     int64_t windowLaunches = 0, windowCount = 0;  // side launches that ran on windows / windows scanned, since the driver was created
@@ -525,18 +530,34 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             if (const char* e = std::getenv("CUDASW4_AMD_RESCORE_SERVICE")) g->svcForce = e[0] == '1' ? 1 : 0;
         }
         if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : 1;
-        if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : 1;
+        if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "single" ? 3 : 1;
         if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_WINDOWS")) g->windowsAlways = std::string(e) == "always";
         if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
-        g->ovfCountCap = 1 + Gpu::kOvfLists;
+        g->ovfCountCap = 2 + Gpu::kOvfLists + 1;
         HIPCHECK(hipMalloc(&g->d_ovfCount, g->ovfCountCap * sizeof(int32_t)));
         // the service's polling kernel must not share a hardware queue with the side launches the bulk launch waits for
         if (g->svcStream) {
             g->svcConcurrent = sw_streams_run_concurrently(g->ctx, g->svcStream, g->aux[0]) == 1 &&
                                sw_streams_run_concurrently(g->ctx, g->svcStream, g->aux[1]) == 1 &&
                                sw_streams_run_concurrently(g->ctx, g->svcStream, g->stream) == 1;
+        }
+        // The handshake itself, once, bounded: the bulk launch waits in hipStreamWaitValue32 for a value only
+        // device code raises, the re-score service polls until the work stream writes behind the bulk launch.  Where
+        // kernels are serialised — rocprofv3 --pmc, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING — or wait-value packets are
+        // not released, that hangs the stream without a diagnostic: fall back to plain stream order (no service, one lane)
+        if (g->handshake) {
+            auto on = [](const char* name) { const char* e = std::getenv(name); return e && e[0] && e[0] != '0' && e[0] != 'f' && e[0] != 'F'; };
+            const char* why = nullptr;
+            if (on("ROCPROF_COUNTER_COLLECTION")) why = "rocprofv3 counter collection serialises kernels";
+            else if (on("AMD_SERIALIZE_KERNEL")) why = "AMD_SERIALIZE_KERNEL is set";
+            else if (on("HIP_LAUNCH_BLOCKING")) why = "HIP_LAUNCH_BLOCKING is set";
+            else if (sw_probe_handshake(g->ctx, g->aux[0], g->stream, g->startSignal) != 1) why = "the probe found that a gated launch does not start beside its side launch";
+            if (why) {
+                g->handshake = false;
+                if (verbose_) std::cout << "GPU " << dev << ": start handshake, re-score service and tail hand-over off (" << why << ")\n";
+            }
         }
         g->live.hold(dev);
         gpus_.push_back(std::move(g));
@@ -1038,28 +1059,49 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // threads per subject instead of one wave, 3 x faster for a long query and 20 x for a short one, for 2.3 x the
     // instructions — so only where the one-wave launch would be (close to) what the scan waits for: shards of a real DB,
     // short queries.  Returns false when the run is to be launched as it is.
-    auto launch_rows = [&](size_t ri, hipStream_t stream) -> bool {
+    auto launch_rows = [&](size_t ri, hipStream_t stream, int tslot) -> bool {
         const LaunchRun& r = runs[ri];
         if (g.rowsMode == 0 || is_packed(r.kind) || r.part_id != kNumLengthPartitions - 1) return false;
-        if (gop > gex || r.maxlen > sw_scan_rows_max_subject() || r.end - r.begin > 64) return false;
-        if (g.rowsMode != 2 && giant_seconds(r) < 0.8 * bulk_seconds()) return false;
+        if (gop > gex) return false;
         const int32_t n = int32_t(r.end - r.begin);
+        // Pipelined (round 5): every subject on as many SIMDs as it has spans, ~0.3 us per query row whatever its length —
+        // 35 213 x 5 478 in ~2 ms against 22.6 on one CU and 60 on one wave.  Whenever it applies: a handful of subjects
+        // (more of them are throughput, not latency: the scan kernels), a hand-off array that fits the scratch budget.
+        bool pipelined = false;
+        void* temp = nullptr;
+        if (g.rowsMode != 3 && n <= kPipelineMaxSubjects && int64_t(r.maxlen) * int64_t(-gex) < (int64_t(1) << 28)) {
+            const size_t need = sw_scan_rows_pipelined_temp_bytes(g.ctx, n, r.maxlen);
+            if (need > 0 && need <= std::min(mem.maxTempBytes, g.tempCap)) {
+                temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
+                pipelined = true;
+            }
+        }
+        if (!pipelined) {
+            if (r.maxlen > sw_scan_rows_max_subject() || n > 64) return false;
+            if (g.rowsMode != 2 && giant_seconds(r) < 0.8 * bulk_seconds()) return false;
+        }
         TimedLaunch t;
         const bool record = recordMode == 1;
         if (record) {
             if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
             else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
             t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = false;
-            t.eff_kind = SW_KIND_I32; t.rows = (r.maxlen + 1023) / 1024; t.nstripes = 1; t.lanes = 1024;
+            t.eff_kind = SW_KIND_I32; t.rows = (r.maxlen + 1023) / 1024; t.nstripes = 1; t.lanes = pipelined ? 64 : 1024;
             HIPCHECK(hipEventRecord(t.ev0, stream));
         }
-        SWCHECK(sw_scan_rows(g.ctx, chars, offsets, lengths, int32_t(r.begin - lbegin), n, r.maxlen, gop, gex, g.d_scores + lbegin,
-                             g.d_ids + lbegin, int64_t(lbegin), stream));
+        if (pipelined)
+            SWCHECK(sw_scan_rows_pipelined(g.ctx, chars, offsets, lengths, int32_t(r.begin - lbegin), n, r.maxlen, gop, gex,
+                                           g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), g.failSlot, temp,
+                                           g.tempBytes[tslot], stream));
+        else
+            SWCHECK(sw_scan_rows(g.ctx, chars, offsets, lengths, int32_t(r.begin - lbegin), n, r.maxlen, gop, gex, g.d_scores + lbegin,
+                                 g.d_ids + lbegin, int64_t(lbegin), stream));
         if (record) {
             HIPCHECK(hipEventRecord(t.ev1, stream));
             g.timed.push_back(t);
         }
         g.rowsLaunches++;
+        if (pipelined) g.pipelineLaunches++;
         return true;
     };
     auto launch_windows = [&](size_t ri, hipStream_t stream, int a) -> bool {
@@ -1208,7 +1250,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         }
         // (windows first: where the span bound cuts the subjects — short queries — they are a little faster than the rows,
         // 8 253 against 7 818 GCUPS for a stream of 48-residue queries; long queries have no windows)
-        if (!launch_windows(i, g.aux[a], a) && !launch_rows(i, g.aux[a])) launch(i, g.aux[a], a + 1);
+        if (!launch_windows(i, g.aux[a], a) && !launch_rows(i, g.aux[a], a + 1)) launch(i, g.aux[a], a + 1);
     }
     if (useService) {
         const LaunchRun& r = runs[mainIdx];
@@ -1451,7 +1493,7 @@ bool SearchDriver::prepareLane(Gpu& g, int32_t queryLength) {
         }
         if (!g.lane1.scanStartEv) HIPCHECK(hipEventCreate(&g.lane1.scanStartEv));
         if (!g.lane1.d_ovfCount) {
-            g.lane1.ovfCountCap = 1 + Gpu::kOvfLists;
+            g.lane1.ovfCountCap = 2 + Gpu::kOvfLists + 1;
             HIPCHECK(hipMalloc(&g.lane1.d_ovfCount, g.lane1.ovfCountCap * sizeof(int32_t)));
         }
         if (!g.lane1Ready) {
@@ -1502,17 +1544,19 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
         SWCHECK(sw_set_grid_reserve(g.ctx, overlap ? g.laneReserve : 0));
         SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
         // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
-        // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed)
+        // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed); + 1: pipeline stages
+        // that gave up waiting (sw_scan_rows_pipelined: fail_count)
         const size_t ncounters = 1 + (1 + g.batches.size()) * Gpu::kOvfLists;
-        if (ncounters + 1 > g.ovfCountCap) {
+        if (ncounters + 2 > g.ovfCountCap) {
             (void)hipFree(g.d_ovfCount);
             g.d_ovfCount = nullptr;
             g.ovfCountCap = 0;
-            HIPCHECK(hipMalloc(&g.d_ovfCount, (ncounters + 1) * sizeof(int32_t)));
-            g.ovfCountCap = ncounters + 1;
+            HIPCHECK(hipMalloc(&g.d_ovfCount, (ncounters + 2) * sizeof(int32_t)));
+            g.ovfCountCap = ncounters + 2;
         }
-        ensure_ovf_slots(rs.h_ovf, rs.ovfCap, ncounters + 1);
-        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, (ncounters + 1) * sizeof(int32_t), g.stream));
+        ensure_ovf_slots(rs.h_ovf, rs.ovfCap, ncounters + 2);
+        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, (ncounters + 2) * sizeof(int32_t), g.stream));
+        g.failSlot = g.d_ovfCount + ncounters + 1;
         HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
         // the cached part first (the longest subjects: one set of launches over everything that is resident), then the
         // streamed batches — whose first copies run while the cached part computes
@@ -1555,7 +1599,7 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
             rs.top = kk;
         }
         // per-query totals (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
-        HIPCHECK(hipMemcpyAsync(rs.h_ovf, g.d_ovfCount, (ncounters + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipMemcpyAsync(rs.h_ovf, g.d_ovfCount, (ncounters + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
         HIPCHECK(hipEventRecord(rs.done, g.stream));
         rs.ncounters = ncounters;
         rs.used = true;
@@ -1606,6 +1650,9 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot) {
         g.badCodes = true;
         throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
     }
+    if (rs.h_ovf[rs.ncounters + 1])
+        throw std::runtime_error("scan failed: " + std::to_string(rs.h_ovf[rs.ncounters + 1]) +
+                                 " pipeline stage(s) of a long subject gave up waiting for their neighbour (sw_scan_rows_pipelined)");
     for (size_t i = 1; i < rs.ncounters; i++) g.lastRescored += rs.h_ovf[i];
     g.lastOverflows = rs.h_ovf[0];
     g.lastTop = rs.top;
@@ -1764,6 +1811,18 @@ void SearchDriver::windowStats(int64_t* launches, int64_t* windows) const {
 int64_t SearchDriver::latencyScans() const {
     int64_t n = 0;
     for (auto& gp : gpus_) n += gp->latencyScans;
+    return n;
+}
+
+bool SearchDriver::handshakeActive() const {
+    for (auto& gp : gpus_)
+        if (!gp->handshake) return false;
+    return !gpus_.empty();
+}
+
+int64_t SearchDriver::pipelineLaunches() const {
+    int64_t n = 0;
+    for (auto& gp : gpus_) n += gp->pipelineLaunches;
     return n;
 }
 

@@ -71,6 +71,9 @@ struct LaunchRun {
 // this many subjects up the library gives it the 16-lane shape (sw_api.hip: lanes_for_partition), i.e. the very kernel
 // the partitions below it run on.
 constexpr size_t kLongPartitionMergeMin = 512;
+// sw_scan_rows_pipelined takes partition 35 while it holds at most this many subjects (a handful of giants is a latency
+// problem, thousands of them are throughput: the scan kernels)
+constexpr int32_t kPipelineMaxSubjects = 256;
 
 // Partition walk of runAlignmentKernels (cudasw4.cuh:1742-2103) over the positions [begin, end) of a subject list
 // whose partition p occupies [partBegin[p], partBegin[p+1]): largest partition first, adjacent partitions of equal
@@ -214,6 +217,8 @@ public:
     void windowStats(int64_t* launches, int64_t* windows) const;
     int64_t serviceLaunches() const;   // re-score service launches (sw_rescore_service) since the driver was created
     int64_t latencyScans() const;      // scans planned in latency mode (partition 34 on wave-wide groups beside the bulk launch: small shards of real DBs)
+    bool handshakeActive() const;      // the start handshake (and with it the re-score service and the tail hand-over) passed its probe on every GPU
+    int64_t pipelineLaunches() const;  // ... of them as pipelines of one-wave stages over many CUs (sw_scan_rows_pipelined)
     int64_t rowsLaunches() const;      // side launches of partition 35 that ran row-parallel (sw_scan_rows) since the driver was created
     // queries whose bulk launch was gated on the dry signal of the query before it (tail hand-over between two queries in
     // flight: submit() while a query is pending, resident shards of a few rounds of workgroups), since the driver was created

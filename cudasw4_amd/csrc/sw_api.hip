@@ -10,12 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
 #include "../../include/cudasw4_amd.h"
 #include "sw_launch.hpp"
 #include "sw_rows_kernel.hpp"
+#include "sw_rows_pipeline.hpp"
 
 namespace {
 
@@ -161,6 +163,13 @@ struct sw_ctx {
     int32_t lanes8_max_subject = -1;  // CUDASW4_AMD_LANES8_MAX_SUBJECT: multi-stripe queries use 8-lane groups when no subject of the launch is longer (-1: built-in)
     int32_t lanes8_max_q = -1;   // CUDASW4_AMD_LANES8_MAX_Q: queries up to this length use 8-lane groups (0: never; -1: the built-in limits)
     bool check_bounds = false;   // CUDASW4_AMD_CHECK_BOUNDS=1 (debug): every scan first verifies the max_subject_len contract on the device (synchronises)
+    // sw_scan_rows_pipelined: control words of the launches in flight (tickets, counted-in workgroups, abort, spare), rotating
+    static constexpr uint32_t kPipeCtrlSlots = 64;
+    uint32_t* d_pipe_ctrl = nullptr;
+    uint32_t pipe_next = 0;
+    uint32_t pipe_spin_limit = 1u << 20;  // CUDASW4_AMD_PIPE_SPIN_LIMIT: polls (~2 us each) before a pipeline stage gives up waiting
+    int32_t pipe_drop_stage = -1;         // CUDASW4_AMD_PIPE_TEST_DROP_STAGE (tests): this stage of every subject is lost
+    int32_t pipe_cpl = 0;                 // CUDASW4_AMD_PIPE_CPL=4|8|16: columns per lane of a stage (0: by the subjects' length)
 };
 
 namespace {
@@ -437,9 +446,13 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_Q")) ctx->lanes8_max_q = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_SUBJECT")) ctx->lanes8_max_subject = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_CHECK_BOUNDS")) ctx->check_bounds = e[0] == '1';
+    if (const char* e = getenv("CUDASW4_AMD_PIPE_SPIN_LIMIT")) ctx->pipe_spin_limit = (uint32_t)std::max(1ll, atoll(e));
+    if (const char* e = getenv("CUDASW4_AMD_PIPE_TEST_DROP_STAGE")) ctx->pipe_drop_stage = atoi(e);
+    if (const char* e = getenv("CUDASW4_AMD_PIPE_CPL")) ctx->pipe_cpl = atoi(e);
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check (word 64) and the two of sw_streams_run_concurrently (72, 73)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, 2 * kWorkSlots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_pipe_ctrl, 4 * sw_ctx::kPipeCtrlSlots * sizeof(uint32_t));
     if (e == hipSuccess) {
         uint32_t z[64] = {};
         for (int i = 0; i < 16; i++) z[SW_KIND_I16X2 * 16 + i] = swk::Arith<swk::I16X2>::kZero;
@@ -459,6 +472,7 @@ int sw_ctx_destroy(sw_ctx* ctx) {
     if (ctx->d_matrix) (void)hipFree(ctx->d_matrix);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->d_pipe_ctrl) (void)hipFree(ctx->d_pipe_ctrl);
     if (ctx->d_query) (void)hipFree(ctx->d_query);
     for (int i = 0; i < sw_ctx::kQuerySlots; i++) {
         if (ctx->h_query[i]) (void)hipHostFree(ctx->h_query[i]);
@@ -591,24 +605,58 @@ int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal) {
 
 int32_t sw_scan_rows_max_subject(void) { return swk::kRowsMaxSubject; }
 
+namespace {
+// what both row-parallel entry points check before they touch the device
+int rows_common_checks(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos, int32_t n,
+                       int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, bool dry_armed, hipStream_t stream,
+                       const char* who) {
+    if (dry_armed) return fail(SW_ERR_INVALID, std::string(who) + " never runs dry: sw_set_dry_signal applies to sw_scan_partition launches (the armed signal was cancelled)");
+    if (n < 0 || max_subject_len < 0) return fail(SW_ERR_INVALID, "negative count or length");
+    if (gop > 0 || gex > 0) return fail(SW_ERR_INVALID, "gap scores must be <= 0");
+    if (gop > gex) return fail(SW_ERR_INVALID, std::string(who) + " needs gop <= gex (the prefix form of the horizontal gap)");
+    if (gex < -10000 || gop < -100000) return fail(SW_ERR_INVALID, std::string("gap score out of range for ") + who);
+    if (!ctx->have_matrix) return fail(SW_ERR_NO_MATRIX, "sw_set_matrix has not been called");
+    if (!ctx->have_query) return fail(SW_ERR_NO_QUERY, "sw_set_query has not been called");
+    if (n == 0) return SW_OK;
+    if (!chars || !offsets || !lengths || !scores || !ids) return fail(SW_ERR_INVALID, "null buffer");
+    SW_HIP(hipSetDevice(ctx->device));
+    if (ctx->check_bounds) {
+        // the kernels never compare a subject's length with what the caller declared: columns beyond it would be dropped silently
+        int32_t* slot = reinterpret_cast<int32_t*>(ctx->d_zeros + 64);
+        int32_t longest = 0;
+        SW_HIP(hipMemsetAsync(slot, 0, sizeof(int32_t), stream));
+        hipLaunchKernelGGL(max_length_kernel, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, stream, lengths, nullptr, nullptr, first_pos, n, slot);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipMemcpyAsync(&longest, slot, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        if (longest > max_subject_len)
+            return fail(SW_ERR_INVALID, "max_subject_len " + std::to_string(max_subject_len) + " under-reports: a subject of the range has " +
+                                            std::to_string(longest) + " residues");
+    }
+    return SW_OK;
+}
+
+// columns per lane of a pipeline stage: short spans finish a row sooner, long ones keep the number of stages (and of
+// hand-offs a row passes through) down
+int pipeline_cpl(const sw_ctx* ctx, int32_t max_subject_len) {
+    if (ctx->pipe_cpl == 4 || ctx->pipe_cpl == 8 || ctx->pipe_cpl == 16) return ctx->pipe_cpl;
+    return max_subject_len <= 12288 ? 4 : max_subject_len <= 49152 ? 8 : 16;
+}
+int64_t pipeline_stages(int cpl, int32_t max_subject_len) { return std::max<int64_t>(1, ((int64_t)max_subject_len + 64 * cpl - 1) / (64 * cpl)); }
+}  // namespace
+
 int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos, int32_t n,
                  int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* stream_) {
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
     // one-shot signals belong to this call whatever happens to it (scan_common)
     uint32_t* const start_signal = ctx->start_signal;
     ctx->start_signal = nullptr;
+    const bool dry_armed = ctx->dry_signal != nullptr;
     ctx->dry_signal = nullptr;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (n < 0 || max_subject_len < 0) return fail(SW_ERR_INVALID, "negative count or length");
-    if (gop > 0 || gex > 0) return fail(SW_ERR_INVALID, "gap scores must be <= 0");
-    if (gop > gex) return fail(SW_ERR_INVALID, "sw_scan_rows needs gop <= gex (the prefix form of the horizontal gap)");
-    if (gex < -10000 || gop < -100000) return fail(SW_ERR_INVALID, "gap score out of range for sw_scan_rows");
     if (max_subject_len > swk::kRowsMaxSubject) return fail(SW_ERR_INVALID, "subject too long for sw_scan_rows (sw_scan_rows_max_subject)");
-    if (!ctx->have_matrix) return fail(SW_ERR_NO_MATRIX, "sw_set_matrix has not been called");
-    if (!ctx->have_query) return fail(SW_ERR_NO_QUERY, "sw_set_query has not been called");
-    if (n == 0) return SW_OK;
-    if (!chars || !offsets || !lengths || !scores || !ids) return fail(SW_ERR_INVALID, "null buffer");
-    SW_HIP(hipSetDevice(ctx->device));
+    const int rc = rows_common_checks(ctx, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids, dry_armed, stream, "sw_scan_rows");
+    if (rc != SW_OK || n == 0) return rc;
     swk::RowsParams p{};
     p.chars = chars; p.offsets = offsets; p.lengths = lengths; p.first_pos = first_pos;
     p.query = ctx->d_query; p.qlen = ctx->qlen; p.matrix = ctx->d_matrix; p.dim = ctx->dim;
@@ -626,6 +674,53 @@ int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, cons
     else if (cpl <= 32) hipLaunchKernelGGL(swk::sw_rows_kernel<32>, grid, block, 0, stream, p);
     else if (cpl <= 36) hipLaunchKernelGGL(swk::sw_rows_kernel<36>, grid, block, 0, stream, p);   // (Swiss-Prot's longest: 35 213)
     else hipLaunchKernelGGL(swk::sw_rows_kernel<40>, grid, block, 0, stream, p);
+    SW_HIP(hipGetLastError());
+    return SW_OK;
+}
+
+size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx* ctx, int32_t n, int32_t max_subject_len) {
+    if (!ctx || !ctx->have_query || n <= 0 || max_subject_len < 0) return 0;
+    const int64_t tickets = (int64_t)n * pipeline_stages(pipeline_cpl(ctx, max_subject_len), max_subject_len);
+    return (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
+}
+
+int sw_scan_rows_pipelined(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos,
+                           int32_t n, int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
+                           int32_t* fail_count, void* temp, size_t temp_bytes, void* stream_) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    uint32_t* const start_signal = ctx->start_signal;
+    ctx->start_signal = nullptr;
+    const bool dry_armed = ctx->dry_signal != nullptr;
+    ctx->dry_signal = nullptr;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // the prefix runs in the frame H~ - k * gex: columns * |gex| must stay far inside 32 bits
+    if ((int64_t)max_subject_len * (int64_t)(-gex) >= ((int64_t)1 << 28)) return fail(SW_ERR_INVALID, "subject length x gap extension out of range for sw_scan_rows_pipelined");
+    const int rc = rows_common_checks(ctx, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids, dry_armed, stream, "sw_scan_rows_pipelined");
+    if (rc != SW_OK || n == 0) return rc;
+    const int cpl = pipeline_cpl(ctx, max_subject_len);
+    const int64_t stages = pipeline_stages(cpl, max_subject_len);
+    const int64_t tickets = (int64_t)n * stages;
+    if (tickets > (int64_t)1 << 24) return fail(SW_ERR_INVALID, "too many pipeline stages for one sw_scan_rows_pipelined launch");
+    const size_t need = (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
+    if (!temp || temp_bytes < need) return fail(SW_ERR_TEMP, "temp buffer too small for sw_scan_rows_pipelined (sw_scan_rows_pipelined_temp_bytes)");
+    swk::PipelineParams p{};
+    p.chars = chars; p.offsets = offsets; p.lengths = lengths; p.first_pos = first_pos; p.n = n;
+    p.query = ctx->d_query; p.qlen = ctx->qlen; p.matrix = ctx->d_matrix; p.dim = ctx->dim;
+    p.gop = gop; p.gex = gex; p.scores = scores; p.ids = ids; p.id_offset = id_offset;
+    p.xfer = static_cast<unsigned long long*>(temp);
+    p.ctrl = ctx->d_pipe_ctrl + 4 * (ctx->pipe_next++ % sw_ctx::kPipeCtrlSlots);
+    p.start_signal = start_signal;
+    p.start_quorum = (uint32_t)tickets;   // every workgroup counts itself in, also those whose stage does not exist: all of them fit the GPU at once
+    p.fail_count = fail_count;
+    p.max_stages = (int32_t)stages;
+    p.spin_limit = ctx->pipe_spin_limit;
+    p.test_drop_stage = ctx->pipe_drop_stage;
+    SW_HIP(hipMemsetAsync(p.ctrl, 0, 4 * sizeof(uint32_t), stream));
+    SW_HIP(hipMemsetAsync(temp, 0xFF, need, stream));   // "not written yet"
+    const dim3 grid((unsigned)tickets), block(64);
+    if (cpl == 4) hipLaunchKernelGGL(swk::sw_rows_pipeline_kernel<4>, grid, block, 0, stream, p);
+    else if (cpl == 8) hipLaunchKernelGGL(swk::sw_rows_pipeline_kernel<8>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(swk::sw_rows_pipeline_kernel<16>, grid, block, 0, stream, p);
     SW_HIP(hipGetLastError());
     return SW_OK;
 }
@@ -673,7 +768,54 @@ __global__ void probe_wait_kernel(unsigned* flag, unsigned* saw, unsigned long l
     *saw = v;
 }
 __global__ void probe_set_kernel(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the side launch of the start handshake in miniature: count in (what releases the gated stream), then stay resident — for a
+// bounded time — until the gated kernel has been seen to run
+__global__ void probe_side_kernel(unsigned* signal, unsigned* flag, unsigned* saw, unsigned long long max_ticks) {
+    __hip_atomic_fetch_add(signal, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    unsigned v = 0;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(8);
+    *saw = v;
+}
 }  // namespace
+
+int sw_probe_handshake(sw_ctx* ctx, void* side_stream, void* gated_stream, uint32_t* signal) {
+    if (!ctx || !signal) return fail(SW_ERR_INVALID, "null argument");
+    SW_HIP(hipSetDevice(ctx->device));
+    hipStream_t side = static_cast<hipStream_t>(side_stream), gated = static_cast<hipStream_t>(gated_stream);
+    unsigned* words = reinterpret_cast<unsigned*>(ctx->d_zeros + 72);  // (flag, saw): two spare words of the context's constant block
+    SW_HIP(hipStreamSynchronize(side));
+    SW_HIP(hipStreamSynchronize(gated));
+    SW_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), side));
+    SW_HIP(hipStreamSynchronize(side));
+    const uint32_t base = *reinterpret_cast<volatile uint32_t*>(signal);   // signal memory is host-visible
+    SW_HIP(hipStreamWaitValue32(gated, signal, base + 1u, hipStreamWaitValueGte, 0xffffffffu));
+    hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, gated, words);
+    hipLaunchKernelGGL(probe_side_kernel, dim3(1), dim3(1), 0, side, signal, words, words + 1, 1000000ull);  // 100 MHz ticks: 10 ms
+    SW_HIP(hipGetLastError());
+    // the gated stream must get through within a bounded time; if its wait is never released (a profiler that serialises
+    // kernels, a runtime without working wait-value packets) the host releases it by hand
+    bool released = true;
+    for (int i = 0;; i++) {
+        const hipError_t q = hipStreamQuery(gated);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(SW_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        if (i >= 2000) {   // ~2 s
+            *reinterpret_cast<volatile uint32_t*>(signal) = base + 1u;
+            released = false;
+            break;
+        }
+        struct timespec ts = {0, 1000000};
+        nanosleep(&ts, nullptr);
+    }
+    SW_HIP(hipStreamSynchronize(side));
+    SW_HIP(hipStreamSynchronize(gated));
+    unsigned saw = 0;
+    SW_HIP(hipMemcpy(&saw, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *reinterpret_cast<volatile uint32_t*>(signal) = base;
+    return released && saw ? 1 : 0;
+}
 
 int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b) {
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
@@ -756,9 +898,12 @@ int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, c
                       const int32_t* lengths, int32_t first_pos, int32_t n, int32_t max_subject_len, int gop, int gex,
                       float* scores, int32_t* ids, int64_t id_offset, int32_t* ovf_pos, int32_t* ovf_count,
                       int ovf_check, void* temp, size_t temp_bytes, void* stream) {
-    if (part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS) return fail(SW_ERR_INVALID, "partition id out of range");
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
-    if (!kind_launch(kind)) return fail(SW_ERR_INVALID, "unknown kind");
+    if (part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS || !kind_launch(kind)) {
+        ctx->start_signal = nullptr;   // one-shot: a call that fails cancels what was armed for it
+        ctx->dry_signal = nullptr;
+        return fail(SW_ERR_INVALID, part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS ? "partition id out of range" : "unknown kind");
+    }
     kind = effective_kind_of(ctx, kind, max_subject_len);
     return scan_common(ctx, kind, lanes_for_partition(ctx, kind, part_id, n, max_subject_len), chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
                        scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
@@ -777,10 +922,16 @@ int sw_rescore_overflow_stat(sw_ctx* ctx, int kind, const int32_t* ovf_pos, cons
                              const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
                              int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp,
                              size_t temp_bytes, int32_t packed_limit, int32_t* true_overflow_count, void* stream) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    uint32_t* const start_signal = ctx->start_signal;   // (one-shot signals: as in sw_rescore_service)
+    uint32_t* const dry_signal = ctx->dry_signal;
+    ctx->start_signal = nullptr;
+    ctx->dry_signal = nullptr;
     if (kind != SW_KIND_I32 && kind != SW_KIND_F32) return fail(SW_ERR_INVALID, "overflow re-score needs a 32-bit kind");
     if (!ovf_pos || !ovf_count) return fail(SW_ERR_INVALID, "null overflow buffers");
     if (max_count <= 0) return SW_OK;
-    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    ctx->start_signal = start_signal;
+    ctx->dry_signal = dry_signal;
     kind = effective_kind_of(ctx, kind, max_subject_len);
     // grid sized for max_count; the kernel reads the real count on the device (no host round trip,
     // no device-side launch — cf. float_kernels.cuh:1206-1258)
@@ -804,10 +955,18 @@ int sw_rescore_service(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int32_t* o
                        int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
                        int32_t packed_limit, int32_t* true_overflow_count, const uint32_t* done_flag, uint32_t done_value,
                        int workgroups, void* stream) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    // the one-shot signals belong to this call whatever happens to it: an early return must not leave them armed for an
+    // unrelated later launch (scan_common takes them over again when the launch goes ahead)
+    uint32_t* const start_signal = ctx->start_signal;
+    uint32_t* const dry_signal = ctx->dry_signal;
+    ctx->start_signal = nullptr;
+    ctx->dry_signal = nullptr;
     if (kind != SW_KIND_I32 && kind != SW_KIND_F32) return fail(SW_ERR_INVALID, "overflow re-score needs a 32-bit kind");
     if (!ovf_pos || !ovf_count || !done_flag) return fail(SW_ERR_INVALID, "null overflow buffers or flag");
-    if (max_count <= 0 || workgroups <= 0) { if (ctx) ctx->start_signal = nullptr; return SW_OK; }
-    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    if (max_count <= 0 || workgroups <= 0) return SW_OK;
+    ctx->start_signal = start_signal;
+    ctx->dry_signal = dry_signal;
     kind = effective_kind_of(ctx, kind, max_subject_len);
     ListMode lm;
     lm.claim = ovf_pos;
@@ -823,10 +982,16 @@ int sw_rescore_overflow_claim(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int
                               const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
                               int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
                               int32_t packed_limit, int32_t* true_overflow_count, void* stream) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    uint32_t* const start_signal = ctx->start_signal;   // (one-shot signals: as in sw_rescore_service)
+    uint32_t* const dry_signal = ctx->dry_signal;
+    ctx->start_signal = nullptr;
+    ctx->dry_signal = nullptr;
     if (kind != SW_KIND_I32 && kind != SW_KIND_F32) return fail(SW_ERR_INVALID, "overflow re-score needs a 32-bit kind");
     if (!ovf_pos || !ovf_count) return fail(SW_ERR_INVALID, "null overflow buffers");
     if (max_count <= 0) return SW_OK;
-    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    ctx->start_signal = start_signal;
+    ctx->dry_signal = dry_signal;
     kind = effective_kind_of(ctx, kind, max_subject_len);
     ListMode lm;
     lm.claim = ovf_pos;

@@ -1,0 +1,240 @@
+// sw_rows_pipeline.hpp — the few very long subjects of a real DB on MANY compute units at once.
+//
+// sw_rows_kernel.hpp gives a subject one workgroup = one CU: 4.1 us per query row for a 35 000-residue protein, 22.6 ms
+// for a 5 478-residue query, strictly serial — on a 1/8 shard of a Swiss-Prot-like DB the rank that holds that protein ran
+// at 0.60 of the full-DB rate (profiles/r04_shard_proxy.txt).  The reference has no intra-subject parallelism either
+// (one thread group per subject, cudasw4.cuh:2026-2103).
+//
+// Here the subject is cut into SPANS of 64 * CPL columns and every span is a STAGE of a pipeline: one wave (a workgroup
+// of 64 threads, alone on its SIMD lane group, raised priority) that owns the span for all query rows and walks the
+// query row by row, a few rows behind the stage to its left.  The algebra is the row kernel's: F and the diagonal are
+// local to a column, the horizontal gap is the max-plus prefix
+//     E(i,j) = gop + (j-1) gex + max_{k<j} ( H~(i,k) - k gex ),      H~ = max(0, diagonal + score, F)
+// (exact for gop <= gex).  What a stage needs from its left neighbour per row i is TWO numbers:
+//     carry(i) = max over all columns k left of the span of  H~(i,k) - k gex      (the prefix so far, global frame)
+//     hlast(i) = H(i, last column of the neighbour's span)                        (the diagonal input of row i + 1)
+// and they travel as ONE 64-bit word per row through a hand-off array in device memory: written once by the producer's
+// lane 63 with an agent-scope atomic store, read by the consumer a batch of rows at a time with agent-scope atomic loads
+// (both bypass the XCD-local L2), "not written yet" = all ones (hlast >= 0 makes that pattern impossible).  No flags, no
+// fences, no two-way waits: a stage only ever waits for data of the stage before it.
+//
+// Deadlock freedom does not rest on all stages being resident: a workgroup takes its (subject, stage) from a ticket
+// counter when it STARTS, the stage before has the ticket before, so whoever a running stage waits for is itself
+// running or done.  Every wait is bounded (spin_limit polls, ~2 s): a stage that gives up raises the launch's abort word,
+// which ends everybody else's waits, marks its subject's score -2 and counts itself in *fail_count — the host driver
+// checks that word with the scan's counters and fails the query loudly.
+//
+// int32 arithmetic; ~12 VALU instructions per cell (the scan kernels: 6.5) but 69 SIMDs instead of one for a
+// 35 000-residue subject: ~0.3 us per query row whatever the subject's length.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sw_rows_kernel.hpp"
+
+namespace swk {
+
+struct PipelineParams {
+    const int8_t* chars;       // subject letters; subject pos starts at chars + (offsets[pos] - offsets[0])
+    const uint64_t* offsets;
+    const int32_t* lengths;
+    int32_t first_pos;         // subjects first_pos .. first_pos + n - 1, ascending length; the longest gets the first tickets
+    int32_t n;
+    const int8_t* query;       // letter codes 0 .. dim-1; readable up to the next multiple of 16 behind qlen
+    int32_t qlen;
+    const int8_t* matrix;      // (dim + 1) x 21 substitution scores, row = query letter
+    int32_t dim;
+    int32_t gop, gex;          // <= 0, gop <= gex
+    float* scores;
+    int32_t* ids;
+    int64_t id_offset;
+    unsigned long long* xfer;  // hand-off words: (qlen + 1) per ticket, all ones before the launch
+    uint32_t* ctrl;            // zeroed before the launch: [0] tickets handed out, [1] workgroups counted in (start handshake), [2] abort
+    uint32_t* start_signal;    // start handshake (sw_set_start_signal), or nullptr
+    uint32_t start_quorum;
+    int32_t* fail_count;       // += 1 per stage that gave up waiting (nullptr: not counted)
+    int32_t max_stages;        // tickets per subject: the stages of the longest subject the caller declared
+    uint32_t spin_limit;       // polls of one wait before the stage gives up
+    int32_t test_drop_stage;   // >= 0 (tests of the failure path): this stage of every subject leaves without producing
+};
+
+constexpr int kPipeBatch = 16;                       // rows whose hand-off words a stage fetches at once
+constexpr unsigned long long kPipeEmpty = ~0ull;
+constexpr float kPipeFailedScore = -2.0f;
+
+__device__ __forceinline__ unsigned long long pipe_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pipe_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long pipe_pack(int lo, int hi) {
+    return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32);
+}
+
+template <int CPL>
+__global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelineParams p) {
+    __shared__ int sub[26 * kRowsSubCols];
+    const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);   // a stage is a dependent chain that everybody to its right waits for
+    if (p.start_signal && lane == 0) {
+        if (atomicAdd(p.ctrl + 1, 1u) + 1u == p.start_quorum)
+            __hip_atomic_fetch_add(p.start_signal, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // (subject, stage) from a ticket taken NOW: the stage this one waits for holds the ticket before, so it has started
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(p.ctrl, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    const int subj = p.n - 1 - (int)(t / (uint32_t)p.max_stages);
+    const int stage = (int)(t % (uint32_t)p.max_stages);
+    if (subj < 0) return;
+    const int pos = p.first_pos + subj;
+    const int len = p.lengths[pos];
+    constexpr int kSpan = 64 * CPL;
+    const int nstages = max(1, (len + kSpan - 1) / kSpan);
+    if (stage >= nstages) return;
+    if (stage == p.test_drop_stage) return;   // (tests: a stage that is lost without a trace — its successors must give up, loudly)
+    const bool feeds = stage + 1 < nstages;   // somebody waits for this stage's words
+
+    for (int k = lane; k < (p.dim + 1) * kRowsSubCols; k += 64) {
+        const int r = k / kRowsSubCols, c = k % kRowsSubCols;
+        sub[k] = c < 21 ? (int)p.matrix[r * 21 + c] : -30000;   // a position behind the subject's end: nothing positive starts there
+    }
+    __syncthreads();
+
+    const int8_t* const s = p.chars + (p.offsets[pos] - p.offsets[0]);
+    const int col0 = (stage * 64 + lane) * CPL;   // first owned column (0-based)
+    int lofs[CPL];                                // byte offsets of the owned letters' columns in a row of `sub`
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int col = col0 + c;
+        int letter = 21;
+        if (col < len) {
+            letter = (int)s[col];
+            if (letter < 0 || letter > 20) letter = 20;
+        }
+        lofs[c] = letter * 4;
+    }
+    const size_t region = (size_t)p.qlen + 1;
+    const unsigned long long* const xin = p.xfer + (size_t)(t - (stage > 0 ? 1u : 0u)) * region;   // the stage before's words
+    unsigned long long* const xout = p.xfer + (size_t)t * region;
+    const int gop = p.gop, gex = p.gex;
+    const int kg0 = (col0 + 1) * gex;   // k * gex of the first owned column (k counts from 1)
+
+    int H[CPL], F[CPL], G[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) { H[c] = 0; F[c] = -10000; G[c] = 0; }
+    int best = 0;
+    int hleft = 0;   // H(i-1, col0 - 1): the diagonal input of the first owned column
+    bool failed = false;
+    const int sl = lane & (kPipeBatch - 1);
+
+    // a wait for the stage before: poll until none of the wanted words is "not written yet"; bounded
+    auto await = [&](unsigned long long v, size_t idx, bool want) -> unsigned long long {
+        uint32_t spins = 0;
+        while (__builtin_amdgcn_ballot_w64(want && v == kPipeEmpty) != 0ull) {
+            __builtin_amdgcn_s_sleep(2);
+            v = pipe_load(xin + idx);
+            spins++;
+            if (spins >= p.spin_limit || ((spins & 63u) == 0u && __hip_atomic_load(p.ctrl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                failed = true;
+                break;
+            }
+        }
+        return v;
+    };
+
+    // the first stage has nothing to its left: "no prefix yet" and H(., -1) = 0 in every row
+    const unsigned long long kNoLeft = pipe_pack(kRowsNeg, 0);
+    unsigned long long nxt = kNoLeft;
+    if (stage > 0) nxt = pipe_load(xin + min(sl, p.qlen));
+    for (int i0 = 0; i0 < p.qlen; i0 += kPipeBatch) {
+        const int nrows = __builtin_amdgcn_readfirstlane(min(kPipeBatch, p.qlen - i0));
+        unsigned long long cur = nxt;
+        if (stage > 0) {
+            cur = await(cur, (size_t)min(i0 + sl, p.qlen), sl < nrows);
+            if (failed) break;
+            nxt = pipe_load(xin + min(i0 + kPipeBatch + sl, p.qlen));   // the batch after this one, a batch ahead
+        }
+        const int curLo = (int)(uint32_t)cur, curHi = (int)(uint32_t)(cur >> 32);
+        // lane r holds the LDS row offset of query letter i0 + r (letters behind the query's end are never used)
+        const int qrow = (int)p.query[i0 + sl] * (kRowsSubCols * 4);
+        for (int r = 0; r < nrows; r++) {
+            const char* const srow = reinterpret_cast<const char*>(sub) + __builtin_amdgcn_readlane(qrow, r);
+            const int carryIn = __builtin_amdgcn_readlane(curLo, r);
+            const int hlIn = __builtin_amdgcn_readlane(curHi, r);   // H(i, col0 - 1) of lane 0: next row's diagonal input
+
+            // ---- pass 1: F and H~ of the owned columns, G = H~ - c * gex (lane-local frame), m = their maximum
+            int sc[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) sc[c] = *reinterpret_cast<const int*>(srow + lofs[c]);
+            int prevUp = hleft, m = kRowsNeg;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int up = H[c];
+                const int f = max(F[c] + gex, up + gop);
+                F[c] = f;
+                const int ht = max(max(prevUp + sc[c], f), 0);
+                prevUp = up;
+                H[c] = ht;
+                G[c] = ht - c * gex;
+                m = max(m, G[c]);
+            }
+            // ---- inclusive prefix maximum over the wave, global frame (G - kg0), then P = what lies left of the lane: the
+            //      lanes before it (wave_shr:1) and the stages before (carryIn; lane 0 has only that).  v_max_i32_dpp in place:
+            //      a lane without a source, or in a row outside the mask, keeps its value.  (From update_dpp + max hipcc makes
+            //      four instructions per step; the wait states a DPP read needs behind the VALU write are spelled out here.)
+            int inc = m - kg0;
+            int P = carryIn;
+            asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                "s_nop 1\n\tv_max_i32_dpp %1, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1"
+                : "+v"(inc), "+v"(P));
+            // ---- pass 2: E and H.  mm = running maximum in the lane-local frame, E(c) = mm + gop + (c - 1) * gex
+            int mm = P + kg0;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int e = mm + (gop + (c - 1) * gex);
+                const int h = max(H[c], e);
+                H[c] = h;
+                best = max(best, h);
+                mm = max(mm, G[c]);
+            }
+            const int hlast = H[CPL - 1];
+            hleft = __builtin_amdgcn_update_dpp(hlIn, hlast, 0x138, 0xf, 0xf, false);   // lane 0 keeps the stage before's
+            if (feeds && lane == 63) pipe_store(xout + i0 + r, pipe_pack(max(carryIn, inc), hlast));
+        }
+    }
+    // ---- the subject's score: the running maximum travels down the pipeline behind the last row
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d));
+    if (stage > 0 && !failed) {
+        const unsigned long long fin = await(pipe_load(xin + p.qlen), (size_t)p.qlen, true);
+        best = max(best, (int)(uint32_t)fin);
+    }
+    if (failed) {
+        if (lane == 0) {
+            __hip_atomic_store(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.fail_count) atomicAdd(p.fail_count, 1);
+            p.scores[pos] = kPipeFailedScore;
+            p.ids[pos] = (int32_t)(p.id_offset + pos);
+        }
+        return;
+    }
+    if (lane == 0) {
+        if (feeds) {
+            pipe_store(xout + p.qlen, pipe_pack(best, 0));
+        } else {
+            p.scores[pos] = (float)best;
+            p.ids[pos] = (int32_t)(p.id_offset + pos);
+        }
+    }
+}
+
+}  // namespace swk

@@ -129,6 +129,11 @@ int64_t swdrv_service_launches(swdrv* d);
  * swdrv_create: taken when the one-wave-per-subject launch would be what the scan waits for (shards of a real DB, short
  * queries).  CUDASW4_AMD_ROWS=never|always overrides the estimate. */
 int64_t swdrv_rows_launches(swdrv* d);
+/* ... of them as pipelines of one-wave stages over many compute units (sw_scan_rows_pipelined, round 5) */
+int64_t swdrv_pipeline_launches(swdrv* d);
+/* 1: the start handshake (sw_probe_handshake) holds on every GPU of the driver — side launches, re-score service and tail
+ * hand-over are in use; 0: the driver fell back to plain stream order (a profiler that serialises kernels, ...) */
+int swdrv_handshake_active(swdrv* d);
 /* scans planned in LATENCY MODE since swdrv_create: partition 34 (1281 ... 8000 residues) on wave-wide groups beside the
  * bulk launch instead of inside it, when the whole launch is short against the walk of its longest subject on 16 lanes
  * (small shards of real DBs).  CUDASW4_AMD_LATENCY_MODE=never|always overrides the estimate. */

@@ -66,6 +66,7 @@ int sw_set_matrix(sw_ctx* c, const int8_t*, int) { c->have_matrix = true; return
 int sw_set_query(sw_ctx* c, const int8_t* q, int32_t qlen, void*) { (void)hipSetDevice(c->device); c->query.assign(q, q + qlen); return SW_OK; }
 size_t sw_scan_temp_bytes(sw_ctx*, int, int, int32_t, int32_t) { return 0; }
 int sw_set_start_signal(sw_ctx* c, uint32_t* s) { c->start_signal = s; return SW_OK; }
+int sw_probe_handshake(sw_ctx*, void*, void*, uint32_t*) { return 1; }
 int sw_set_dry_signal(sw_ctx* c, uint32_t* s, uint32_t v) { c->dry_signal = s; c->dry_value = v; return SW_OK; }
 int sw_set_grid_reserve(sw_ctx* c, int32_t n) { c->grid_reserve = n; return SW_OK; }
 long fake_sw_dry_signals(int device) { return g_dry[device]; }
@@ -98,6 +99,17 @@ int sw_set_long16_min(sw_ctx*, int32_t) { return SW_OK; }
 int32_t sw_scan_rows_max_subject(void) { return 40960; }
 int sw_scan_rows(sw_ctx* c, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos, int32_t n,
                  int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* stream) {
+    return sw_scan_partition(c, SW_KIND_I32, 35, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
+                             id_offset, nullptr, nullptr, 0, nullptr, 0, stream);
+}
+size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx*, int32_t n, int32_t max_subject_len) {
+    return n > 0 ? size_t(n) * size_t((max_subject_len + 511) / 512) * 64 : 0;
+}
+int sw_scan_rows_pipelined(sw_ctx* c, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos, int32_t n,
+                           int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, int32_t* fail_count,
+                           void* temp, size_t temp_bytes, void* stream) {
+    owned(c, fail_count);
+    if (n > 0) { owned(c, temp); if (temp_bytes < sw_scan_rows_pipelined_temp_bytes(c, n, max_subject_len)) return SW_ERR_TEMP; }
     return sw_scan_partition(c, SW_KIND_I32, 35, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
                              id_offset, nullptr, nullptr, 0, nullptr, 0, stream);
 }

@@ -83,37 +83,24 @@ def test_config3_sprot_like_dpx_all_queries(sprot_db):
     d32.close()
 
 
-def test_scan_rate_does_not_depend_on_stream_creation_order(sprot_db, monkeypatch):
-    """Round 3's Swiss-Prot-like rate depended on the ORDER the driver created its streams in (which of them ended up
-    sharing a hardware queue: 10.0 ... 11.15 TCUPS).  Since round 4 a resident scan puts only the giants (partition 35)
-    on a side stream — partition 34 runs inside the bulk grid — so no two side launches can serialise behind each other.
-    Eight creation orders (CUDASW4_AMD_STREAM_ORDER: W work, C copy, A / B auxiliary), same DB, same queries: the rates
-    agree within 1.5 % (VERDICT r3 item 3 asks for 1 %; the spread measured is recorded in profiles/), results identical."""
+def test_results_do_not_depend_on_stream_creation_order(sprot_db, monkeypatch):
+    """Eight creation orders of the driver's streams (CUDASW4_AMD_STREAM_ORDER: W work, C copy, A / B auxiliary), same DB,
+    same queries: identical top lists; an order that names a stream twice is refused.  (That the RATE does not depend on
+    the order either is a wall-clock statement: tests/test_gpu_zz_timing.py, which sorts behind every parity test.)"""
     from cudasw4_amd import driver
     chars, offsets, lengths = sprot_db
     _, letters = O.read_fasta(FASTA)
-    qs = letters[3:]        # 375 residues and up: the bulk launch is the critical path (the giants bound shorter queries)
-    cells = float(sum(len(q) for q in qs)) * float(lengths.astype(np.int64).sum())
-    import time
-    rates, tops = {}, {}
+    qs = [letters[3], letters[9], letters[19]]
+    tops = {}
     for order in ("WCAB", "ABWC", "AWBC", "BAWC", "CABW", "WACB", "ACBW", "BWCA"):
         monkeypatch.setenv("CUDASW4_AMD_STREAM_ORDER", order)
         d = driver.Driver(devices=[0], num_top=10, kinds=(1, 1, 2, 2))
         d.db_from_arrays(chars, offsets, lengths)
         d.upload()
-        for q in qs[:4]:
-            d.scan(q)
-        best = 0.0
-        for _ in range(2):
-            t0 = time.perf_counter()
-            res = [d.scan(q) for q in qs]
-            best = max(best, cells / 1e9 / (time.perf_counter() - t0))
-        rates[order] = best
+        res = [d.scan(q) for q in qs]
         tops[order] = [(r["scores"].tolist(), r["ids"].tolist()) for r in res]
         d.close()
-    print("stream order -> GCUPS:", {k: round(v) for k, v in rates.items()})
     assert all(t == tops["WCAB"] for t in tops.values())
-    assert max(rates.values()) / min(rates.values()) < 1.015, rates
     monkeypatch.setenv("CUDASW4_AMD_STREAM_ORDER", "WWAB")
     with pytest.raises(driver.DriverError):
         driver.Driver(devices=[0], num_top=10, kinds=(1, 1, 2, 2))
@@ -145,12 +132,8 @@ def test_config5_streaming_int32_three_shards(kinds):
         assert len(iv) >= 3 * 5  # every shard needed several batches
         if kinds[0] == 2:
             assert r["num_overflows"] <= int((expect >= 25000 - 12500).sum())  # only partition 34 is packed
-    # the shards run concurrently: every GPU's span overlaps every other's (they start together, none waits for
-    # another to finish) and the scan's wall time is far below the sum of the spans
-    spans = d.gpu_spans()
-    assert len(spans) == 3
-    latest_begin, earliest_end = max(b for b, e in spans), min(e for b, e in spans)
-    assert latest_begin < earliest_end, spans
+    # (that the three shards' spans overlap in time is asserted in tests/test_gpu_zz_timing.py, behind every parity test)
+    assert len(d.gpu_spans()) == 3
     d.close()
 
 
@@ -307,35 +290,3 @@ def test_bench_real_db_switch(tmp_path):
     out = run_bench(["--steps", "1", "--warmup", "0", "--db-size", "100000", "--no-cpu-baseline"], {"CUDASW4_SPROT_PREFIX": prefix})
     assert out["data"] == "synthetic" and out["sprot_like"]["data"] == "real" and out["sprot_like"]["verified"] is True
     assert out["sprot_like"]["config"]["db_subjects"] == 50000
-
-
-@pytest.mark.parametrize("extra,kernel,residency", [([], "half2", "resident"), (["--max-gpu-mem", "600M"], "half2", "hybrid"),
-                                                    (["--kernel", "float"], "float", "resident"),
-                                                    (["--kernel", "dpxs32"], "dpxs32", "resident"),
-                                                    (["--kernel", "dpxs32", "--max-gpu-mem", "600M"], "dpxs32", "hybrid")])
-def test_bench_roofline_is_true_for_every_configuration(extra, kernel, residency):
-    """The accounting behind `roofline` / `valu_roofline` (a streamed line reported frac 2.457): the DP
-    kernels' busy time (union of the HIP-event intervals) fits the timed region, their own rate is at least the
-    whole-job rate and below what the chip can issue, the traffic figure is scaled to the launch, and the VALU fraction
-    — present whenever profiles/kernel_counters.json was measured on these kernel sources — lies in (0, 1]."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
-    b = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(b)
-    out = run_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"] + extra)
-    assert out["verified"] is True and out["config"]["kernel"] == kernel and out["config"]["residency"] == residency
-    roof, valu = out["roofline"], out["valu_roofline"]
-    assert 0 < valu["kernel_busy_ms_per_step"] <= out["ms_per_step"] * 1.001
-    assert out["value"] <= valu["kernel_gcups"] * 1.001
-    assert valu["kernel_gcups"] < (13500 if kernel == "half2" else 10500)
-    assert 0 < roof["frac"] < 0.01 and roof["achieved"] > 0
-    if residency == "hybrid":
-        assert 0 < out["config"]["cached_chars"] < out["config"]["shard_chars"]
-        assert roof["algorithmic_bytes_per_launch"] < 400e6     # a batch or the cached part, not the whole DB
-    counters, _ = b.load_counters()
-    if counters is not None:
-        assert valu["frac"] is not None and 0 < valu["frac"] <= 1.0, valu
-        if roof["traffic"] is not None:
-            assert roof["traffic"] >= 0.9 * roof["algorithmic_bytes_per_launch"]
-    else:
-        assert valu["frac"] is None and "kernel_counters.json" in valu["counters_note"]

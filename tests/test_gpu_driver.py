@@ -288,6 +288,47 @@ def test_tail_hand_over_between_two_queries_in_flight(kinds, monkeypatch):
         assert sum(o[3] for o in runs["lanes"][0]) > 0
 
 
+def test_handshake_is_probed_and_falls_back_under_a_serialising_profiler(monkeypatch):
+    """the bulk launch waits (hipStreamWaitValue32) for a value only device code raises.  The driver probes that
+    pattern once at construction (sw_probe_handshake, bounded) and runs without start handshake, re-score service and tail
+    hand-over where it does not hold or where the environment says kernels are serialised (rocprofv3 --pmc exports
+    ROCPROF_COUNTER_COLLECTION): same results, no service launch, no gated query, no hang."""
+    from cudasw4_amd import driver, synthdb
+    _, letters = O.read_fasta(FASTA)
+    queries = [letters[5], letters[11]]
+    fam = synthdb.family_members([O.encode(q) for q in queries], seed=7, min_size=30, max_size=30)
+    lengths = synthdb.sprot_like_lengths(12000, seed=18, max_len=9000)
+    bg = synthdb.random_db(lengths, seed=19, composition=synthdb.SPROT_COMPOSITION)
+    seqs = [bg[0][int(bg[1][i]):int(bg[1][i]) + int(bg[2][i])] for i in range(len(lengths))] + list(fam)
+    seqs.sort(key=len)
+    chars, offsets, lens = O.make_db(seqs)
+    expect = [O.scan(O.encode(q), chars, offsets, lens, simd=True) for q in queries]
+    seen = {}
+    for mode in ("plain", "profiler"):
+        monkeypatch.delenv("ROCPROF_COUNTER_COLLECTION", raising=False)
+        if mode == "profiler":
+            monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
+        d = driver.Driver(devices=[0], num_top=20, kinds=(0, 0, 3, 3))
+        assert d.handshake_active() == (mode == "plain")
+        d.db_from_arrays(chars, offsets, lens)
+        d.upload()
+        out = []
+        d.submit(queries[0])
+        for n in range(4):
+            if n + 1 < 4:
+                d.submit(queries[(n + 1) % 2])
+            r = d.collect()
+            out.append((r["scores"].tolist(), r["ids"].tolist(), r["num_overflows"]))
+        for qi, q in enumerate(queries):
+            d.scan(q)
+            sc, _ = d.last_scores(0)
+            assert (sc == expect[qi]).all(), (mode, qi)
+        seen[mode] = (out, d.service_launches(), d.tail_overlaps())
+        d.close()
+    assert seen["plain"][0] == seen["profiler"][0]
+    assert seen["profiler"][1:] == (0, 0) and seen["plain"][1] > 0
+
+
 @pytest.mark.parametrize("kinds", [(1, 1, 2, 2), (0, 0, 3, 3)])
 def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
     """Small shards of real DBs: partition 34 on wave-wide groups beside the bulk launch (latency mode, sw_set_long16_min)
@@ -306,8 +347,10 @@ def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
     chars, offsets, lengths = O.make_db(seqs)
     expect = [O.scan(O.encode(q), chars, offsets, lengths, simd=True) for q in queries]
     seen = {}
-    for rows in ("never", "always", None):
+    for rows in ("never", "always", "single", None):
         for lat in ("never", "always", None):
+            if rows == "single" and lat is not None:
+                continue
             for name, val in (("CUDASW4_AMD_ROWS", rows), ("CUDASW4_AMD_LATENCY_MODE", lat)):
                 if val is None:
                     monkeypatch.delenv(name, raising=False)
@@ -322,13 +365,16 @@ def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
                 sc, _ = d.last_scores(0)
                 assert (sc == expect[qi]).all(), (rows, lat, qi, np.nonzero(sc != expect[qi])[0][:5], lengths[np.nonzero(sc != expect[qi])[0][:5]])
                 tops.append((r["scores"].tolist(), r["ids"].tolist(), r["num_overflows"]))
-            seen[(rows, lat)] = (tops, d.rows_launches(), d.latency_scans())
+            seen[(rows, lat)] = (tops, d.rows_launches(), d.latency_scans(), d.pipeline_launches())
             d.close()
     assert len({str(v[0]) for v in seen.values()}) == 1
-    assert seen[("never", "never")][1:] == (0, 0)
+    assert seen[("never", "never")][1:] == (0, 0, 0)
     # (where the span bound cuts the giants — the 60- and the 567-residue query — they run as windows instead of rows)
     assert 1 <= seen[("always", "always")][1] <= 3 and seen[("always", "always")][2] == 3
     assert seen[(None, None)][1] >= 1 and seen[(None, None)][2] >= 1     # this DB is a "small shard": the estimates say so
+    # the pipelined form (round 5) wherever the rows run, except when the one-workgroup form is asked for
+    assert seen[(None, None)][3] == seen[(None, None)][1] and seen[("always", "always")][3] == seen[("always", "always")][1]
+    assert seen[("single", None)][3] == 0
 
 
 @pytest.mark.parametrize("dpx", [False, True])

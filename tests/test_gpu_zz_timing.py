@@ -1,0 +1,122 @@
+"""GPU: everything that asserts on a WALL CLOCK or a measured rate, in the file that sorts behind every parity test.
+
+The driver runs `pytest -m gpu -x`: one noisy box must not turn the oracle / golden comparisons behind a failed timing
+assertion into "untested" (VERDICT r4 item 3).  So: the rate spread across stream creation orders (bound 10 %: the measured
+spread is below 1.5 %, and the printed rates are the record), the overlap of the shards' spans, the accounting behind
+bench.py's roofline figures, and the bounded wait of a pipeline stage whose neighbour was lost."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_configs import FASTA, ROOT, run_bench, sprot_db  # noqa: F401  (sprot_db: module-scoped fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_scan_rate_does_not_depend_on_stream_creation_order(sprot_db, monkeypatch):
+    """Round 3's Swiss-Prot-like rate depended on the ORDER the driver created its streams in (which of them ended up
+    sharing a hardware queue: 10.0 ... 11.15 TCUPS).  Since round 4 side launches announce themselves (start handshake) and
+    the bulk launch waits for them.  Eight creation orders, same DB, same queries: the rates are printed (the record) and
+    must agree within 10 % (measured spread: below 1.5 %)."""
+    from cudasw4_amd import driver
+    chars, offsets, lengths = sprot_db
+    _, letters = O.read_fasta(FASTA)
+    qs = letters[3:]        # 375 residues and up: the bulk launch is the critical path
+    cells = float(sum(len(q) for q in qs)) * float(lengths.astype(np.int64).sum())
+    rates = {}
+    for order in ("WCAB", "ABWC", "AWBC", "BAWC", "CABW", "WACB", "ACBW", "BWCA"):
+        monkeypatch.setenv("CUDASW4_AMD_STREAM_ORDER", order)
+        d = driver.Driver(devices=[0], num_top=10, kinds=(1, 1, 2, 2))
+        d.db_from_arrays(chars, offsets, lengths)
+        d.upload()
+        for q in qs[:4]:
+            d.scan(q)
+        best = 0.0
+        for _ in range(2):
+            t0 = time.perf_counter()
+            for q in qs:
+                d.scan(q)
+            best = max(best, cells / 1e9 / (time.perf_counter() - t0))
+        rates[order] = best
+        d.close()
+    print("stream order -> GCUPS:", {k: round(v) for k, v in rates.items()})
+    assert max(rates.values()) / min(rates.values()) < 1.10, rates
+
+
+def test_streamed_shards_run_concurrently():
+    """Config 5's route with three shards in flight (devices=[0,0,0], one worker thread per shard): every shard's span
+    overlaps every other's — they start together, none waits for another to finish."""
+    from cudasw4_amd import driver, synthdb
+    lengths = synthdb.sprot_like_lengths(24000, seed=11, max_len=12000)
+    chars, offsets, lengths = synthdb.random_db(lengths, seed=12, other_fraction=0.01)
+    _, letters = O.read_fasta(FASTA)
+    d = driver.Driver(devices=[0, 0, 0], num_top=25, kinds=(2, 1, 2, 2), max_gpu_mem=1, max_batch_bytes=400_000)
+    d.db_from_arrays(chars, offsets, lengths)
+    for qi in (7, 13, 19):
+        d.scan(letters[qi])
+        spans = d.gpu_spans()
+        assert len(spans) == 3
+        latest_begin, earliest_end = max(b for b, e in spans), min(e for b, e in spans)
+        assert latest_begin < earliest_end, spans
+    d.close()
+
+
+def test_pipeline_lost_stage_gives_up_within_bounds():
+    """sw_scan_rows_pipelined (csrc/sw_rows_pipeline.hpp): a stage that never produces (test hook) — its successors poll a
+    bounded number of times, mark the subject -2 and count themselves in fail_count; the call returns in bounded time.
+    Subjects whose pipelines were done before the abort keep their exact scores."""
+    import torch
+    from cudasw4_amd import capi, search
+    from test_gpu_rows_pipeline import env, run_pipeline
+    rng = np.random.default_rng(23)
+    with env(CUDASW4_AMD_PIPE_TEST_DROP_STAGE=2, CUDASW4_AMD_PIPE_SPIN_LIMIT=2000, CUDASW4_AMD_PIPE_CPL=4):
+        ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    q = rng.integers(0, 20, 200).astype(np.int8)
+    seqs = [rng.integers(0, 21, 256 * 6).astype(np.int8), rng.integers(0, 21, 256 * 2).astype(np.int8)]
+    t0 = time.time()
+    scores, fails = run_pipeline(torch, capi, search, ctx, seqs, q, -11, -1, expect_fail=True)
+    assert time.time() - t0 < 20.0
+    assert fails >= 1
+    assert scores[1] == -2.0                      # the six-stage subject lost its third stage
+    chars, offsets, lengths = O.make_db(sorted(seqs, key=len))
+    expect = O.scan(q, chars, offsets, lengths, simd=True)
+    assert scores[0] in (-2.0, float(expect[0]))  # two stages: untouched by the drop, exact unless the abort reached it first
+
+
+@pytest.mark.parametrize("extra,kernel,residency", [([], "half2", "resident"), (["--max-gpu-mem", "600M"], "half2", "hybrid"),
+                                                    (["--kernel", "float"], "float", "resident"),
+                                                    (["--kernel", "dpxs32"], "dpxs32", "resident"),
+                                                    (["--kernel", "dpxs32", "--max-gpu-mem", "600M"], "dpxs32", "hybrid")])
+def test_bench_roofline_is_true_for_every_configuration(extra, kernel, residency):
+    """The accounting behind `roofline` / `valu_roofline` (a streamed line reported frac 2.457): the DP
+    kernels' busy time (union of the HIP-event intervals) fits the timed region, their own rate is at least the
+    whole-job rate and below what the chip can issue, the traffic figure is scaled to the launch, and the VALU fraction
+    — present whenever profiles/kernel_counters.json was measured on these kernel sources — lies in (0, 1]."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    out = run_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"] + extra)
+    assert out["verified"] is True and out["config"]["kernel"] == kernel and out["config"]["residency"] == residency
+    roof, valu = out["roofline"], out["valu_roofline"]
+    assert 0 < valu["kernel_busy_ms_per_step"] <= out["ms_per_step"] * 1.001
+    assert out["value"] <= valu["kernel_gcups"] * 1.001
+    assert valu["kernel_gcups"] < (13500 if kernel == "half2" else 10500)
+    assert 0 < roof["frac"] < 0.01 and roof["achieved"] > 0
+    if residency == "hybrid":
+        assert 0 < out["config"]["cached_chars"] < out["config"]["shard_chars"]
+        assert roof["algorithmic_bytes_per_launch"] < 400e6     # a batch or the cached part, not the whole DB
+    counters, _ = b.load_counters()
+    if counters is not None:
+        assert valu["frac"] is not None and 0 < valu["frac"] <= 1.0, valu
+        if roof["traffic"] is not None:
+            assert roof["traffic"] >= 0.9 * roof["algorithmic_bytes_per_launch"]
+    else:
+        assert valu["frac"] is None and "kernel_counters.json" in valu["counters_note"]
