@@ -27,7 +27,8 @@ EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "s
            "sw_window_overlap", "sw_reduce_windows", "sw_rescore_service", "sw_rescore_overflow_claim",
            "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_grid_reserve",
            "sw_scan_rows", "sw_scan_rows_max_subject", "sw_set_long16_min", "sw_scan_rows_pipelined",
-           "sw_scan_rows_pipelined_temp_bytes", "sw_probe_handshake"]
+           "sw_scan_rows_pipelined_temp_bytes", "sw_probe_handshake", "sw_launch_vgpr_slot",
+           "sw_set_rows_pipeline_slot", "sw_rescore_overflow_pipelined", "sw_rescore_overflow_pipelined_temp_bytes"]
 
 
 class SwError(RuntimeError):
@@ -70,6 +71,12 @@ def _load():
     L.sw_check_letter_codes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     L.sw_set_start_signal.argtypes = [vp, vp]
     L.sw_probe_handshake.argtypes = [vp, vp, vp, vp]
+    L.sw_rescore_overflow_claim.argtypes = [vp, ctypes.c_int, vp, vp, i32, vp, vp, vp, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp, sz, i32, vp, vp]
+    L.sw_rescore_overflow_pipelined_temp_bytes.restype = sz
+    L.sw_rescore_overflow_pipelined_temp_bytes.argtypes = [vp, i32]
+    L.sw_rescore_overflow_pipelined.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp, i32, vp, vp, sz, vp]
+    L.sw_launch_vgpr_slot.argtypes = [vp, ctypes.c_int, ctypes.c_int, i32, i32]
+    L.sw_set_rows_pipeline_slot.argtypes = [vp, ctypes.c_int]
     L.sw_set_dry_signal.argtypes = [vp, vp, ctypes.c_uint32]
     L.sw_set_grid_reserve.argtypes = [vp, i32]
     L.sw_set_long16_min.argtypes = [vp, i32]
@@ -78,7 +85,7 @@ def _load():
     L.sw_scan_rows.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp]
     L.sw_scan_rows_pipelined_temp_bytes.restype = sz
     L.sw_scan_rows_pipelined_temp_bytes.argtypes = [vp, i32, i32]
-    L.sw_scan_rows_pipelined.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp, vp, sz, vp]
+    L.sw_scan_rows_pipelined.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp, vp, vp, i32, vp, sz, vp]
     L.sw_window_overlap.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.sw_window_overlap.restype = i32
     L.sw_reduce_windows.argtypes = [vp, vp, vp, vp, i32, vp, vp, ctypes.c_int64, vp]
@@ -158,14 +165,36 @@ class Context:
         check(lib.sw_scan_rows(self.handle, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
                                id_offset, stream))
 
+    def launch_vgpr_slot(self, kind, part_id, n, max_subject_len):
+        return int(lib.sw_launch_vgpr_slot(self.handle, kind, part_id, n, max_subject_len))
+
+    def set_rows_pipeline_slot(self, vgprs):
+        check(lib.sw_set_rows_pipeline_slot(self.handle, vgprs))
+
     def scan_rows_pipelined_temp_bytes(self, n, max_subject_len):
         return int(lib.sw_scan_rows_pipelined_temp_bytes(self.handle, n, max_subject_len))
 
     def scan_rows_pipelined(self, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids, id_offset=0,
-                            fail_count=0, temp=0, temp_bytes=0, stream=0):
+                            fail_count=0, temp=0, temp_bytes=0, stream=0, over_limit_count=0, over_limit_count2=0, packed_limit=0):
         """Very long subjects as pipelines of one-wave stages across many CUs (sw_scan_rows_pipelined)."""
         check(lib.sw_scan_rows_pipelined(self.handle, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores,
-                                         ids, id_offset, fail_count, temp, temp_bytes, stream))
+                                         ids, id_offset, fail_count, over_limit_count, over_limit_count2, packed_limit, temp,
+                                         temp_bytes, stream))
+
+    def rescore_overflow_pipelined_temp_bytes(self, max_subject_len):
+        return int(lib.sw_rescore_overflow_pipelined_temp_bytes(self.handle, max_subject_len))
+
+    def rescore_overflow_pipelined(self, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len, min_subject_len,
+                                   gop, gex, scores, ids, id_offset, fail_count, packed_limit, true_count, temp, temp_bytes, stream=0):
+        check(lib.sw_rescore_overflow_pipelined(self.handle, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len,
+                                                min_subject_len, gop, gex, scores, ids, id_offset, fail_count, packed_limit,
+                                                true_count, temp, temp_bytes, stream))
+
+    def rescore_overflow_claim(self, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len, gop, gex,
+                               scores, ids, id_offset, temp, temp_bytes, packed_limit, true_count, stream=0):
+        check(lib.sw_rescore_overflow_claim(self.handle, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths,
+                                            max_subject_len, gop, gex, scores, ids, id_offset, temp, temp_bytes, packed_limit,
+                                            true_count, stream))
 
     def rescore_overflow(self, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, max_subject_len, gop, gex,
                          scores, ids, id_offset=0, temp=0, temp_bytes=0, stream=0):

@@ -253,8 +253,12 @@ struct SearchDriver::Gpu {
     // pipelined form (sw_scan_rows_pipelined) whenever it applies, else the one-workgroup form by its time estimate.
     int rowsMode = 1;
     int64_t rowsLaunches = 0;          // side launches that ran row-parallel, since the driver was created
+    double pipelineShare = kPipelineWalkShare;  // CUDASW4_AMD_PIPELINE_SHARE (A/B measurements)
+    double pipelineRescoreShare = kPipelineRescoreShare;  // CUDASW4_AMD_PIPELINE_RESCORE_SHARE (A/B measurements; >= 100: never)
+    int64_t pipelineRescores = 0;      // re-score launches whose long subjects went ahead pipelined
     int64_t pipelineLaunches = 0;      // ... of them as pipelines of one-wave stages (sw_scan_rows_pipelined)
-    int32_t* failSlot = nullptr;       // device word of the current scan that counts pipeline stages that gave up (d_ovfCount's last)
+    int32_t* failSlot = nullptr;       // device word of the current scan that counts pipeline stages that gave up (d_ovfCount's last but one)
+    int32_t* pipeOverSlot = nullptr;   // ... and the one that counts pipelined subjects of packed partitions at or above the packed limit
     bool windows = true;               // CUDASW4_AMD_NO_WINDOWS=1 turns them off (A/B measurements, tests)
     bool windowsAlways = false;        // CUDASW4_AMD_WINDOWS=always: whenever the bound cuts a subject, whatever the time estimate says
     int64_t windowLaunches = 0, windowCount = 0;  // side launches that ran on windows / windows scanned, since the driver was created
@@ -531,11 +535,13 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         }
         if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : 1;
         if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "single" ? 3 : 1;
+        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE")) g->pipelineShare = std::max(0.01, std::atof(e));
+        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_RESCORE_SHARE")) g->pipelineRescoreShare = std::max(0.001, std::atof(e));
         if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_WINDOWS")) g->windowsAlways = std::string(e) == "always";
         if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
-        g->ovfCountCap = 2 + Gpu::kOvfLists + 1;
+        g->ovfCountCap = 3 + Gpu::kOvfLists + 1;
         HIPCHECK(hipMalloc(&g->d_ovfCount, g->ovfCountCap * sizeof(int32_t)));
         // the service's polling kernel must not share a hardware queue with the side launches the bulk launch waits for
         if (g->svcStream) {
@@ -968,8 +974,52 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // launch is shorter than that (71 000 Swiss-Prot-like subjects: 15 ms of work, measured 50 ms).  Then the partition
     // keeps a launch of its own on wave-wide groups (a subject done 3 x sooner, sw_set_long16_min) beside the bulk launch:
     // 71 250-subject shard, 20 queries, 224 -> 192 ms per pass (tools/shard_proxy.sh).  CUDASW4_AMD_LATENCY_MODE=never|always.
+    // Pipelined subjects (round 5; include/cudasw4_amd.h: sw_scan_rows_pipelined).  A subject is ONE alignment group's walk,
+    // stripe after stripe of the query, whatever the GPU's size — and possibly a second, slower walk when a packed launch
+    // flags it for the 32-bit re-score.  On a whole DB those walks hide beside the bulk launch; on a shard (what each of N
+    // GPUs gets) the bulk launch shrinks and they do not: a 1/8 Swiss-Prot-like shard scans a 5 478-residue query in 15 ms,
+    // while an 8 000-residue subject of partition 34 walks for 14 ms on a wave-wide group and a 5 500-residue relative of the
+    // query is re-scored for 16 ms behind it.  So the LONGEST subjects of the range — every subject whose lone walk would
+    // take more than kPipelineWalkShare of the bulk launch's estimated time, at most kPipelineMaxSubjects — leave the scan
+    // launches: [cut, lend) runs as pipelines of one-wave stages over many SIMDs (~0.3 us per query row whatever the
+    // subject's length, exact 32-bit scores, nothing to re-score), partition by partition (each part on an auxiliary stream).
+    size_t cut = lend;
+    // (CUDASW4_AMD_WINDOWS=always: the giants are wanted as windows — tests of that path)
+    const bool pipelineOk = (g.rowsMode == 1 || g.rowsMode == 2) && gop <= gex && lend > lbegin && !g.windowsAlways;
+    // a wave-wide group's step of R rows per lane: ~(6.5 R + 19) instructions at ~6 cycles each beside a busy grid
+    const double qrows64 = std::ceil(double(g.qlen) / 64.0);
+    const double colSeconds = std::ceil(qrows64 / 8.0) * (6.5 * std::min(qrows64, 8.0) + 19.0) * 6.0 / 2.4e9;
+    const double bulkSeconds = double(g.localOffsets[lend] - g.localOffsets[lbegin]) * double(g.qlen) / 10e12;
+    if (pipelineOk) {
+        constexpr int kSmallLong = kNumLengthPartitions - 2;
+        double maxWalk = g.pipelineShare * bulkSeconds / colSeconds;
+        if (g.rowsMode == 2) maxWalk = 8000.0;   // "always": every subject of partition 35, whatever the estimate says
+        const size_t lo = std::max(lbegin, std::min(lend, g.localBegin[kSmallLong]));   // partitions 34 and 35 only
+        size_t a = lo, b = lend;   // first position whose subject is longer than maxWalk (ascending lengths)
+        while (a < b) {
+            const size_t mid = a + (b - a) / 2;
+            if (double(db.length(size_t(g.toGlobal(int64_t(mid))))) > maxWalk) b = mid; else a = mid + 1;
+        }
+        cut = std::max(a, lend - std::min<size_t>(lend - lo, size_t(kPipelineMaxSubjects)));
+        if (int64_t(db.length(size_t(g.toGlobal(int64_t(lend - 1))))) * int64_t(-gex) >= (int64_t(1) << 28)) cut = lend;
+    }
+    // the parts of [cut, lend), longest partition first; a part whose hand-off array does not fit the scratch budget stays
+    // with the scan launches (and so does everything below it)
+    struct PipePart { size_t begin, end; int part_id; int32_t maxlen; size_t need; };
+    std::vector<PipePart> pipeParts;
+    for (int p = kNumLengthPartitions - 1; p >= kNumLengthPartitions - 2 && cut < lend; p--) {
+        const size_t b = std::max(cut, g.localBegin[p]), e = std::min(lend, g.localBegin[p + 1]);
+        if (e <= b) continue;
+        const int32_t maxlen = int32_t(db.length(size_t(g.toGlobal(int64_t(e - 1)))));
+        const size_t need = sw_scan_rows_pipelined_temp_bytes(g.ctx, int32_t(e - b), maxlen);
+        if (need == 0 || need > std::min(mem.maxTempBytes, g.tempCap) || pipeParts.size() >= size_t(GpuT::kAux)) { cut = e; break; }
+        pipeParts.push_back(PipePart{b, e, p, maxlen, need});
+    }
+    if (pipeParts.empty()) cut = lend;
+    else cut = pipeParts.back().begin;
+    lend = cut;   // what the scan launches below cover
     bool latencyMode = g.latencyMode == 2;
-    if (g.latencyMode == 1 && slot < 0) {
+    if (g.latencyMode == 1 && slot < 0 && lend > lbegin) {
         constexpr int kSmallLong = kNumLengthPartitions - 2;
         const size_t b34 = std::max(lbegin, g.localBegin[kSmallLong]), e34 = std::min(lend, g.localBegin[kSmallLong + 1]);
         if (e34 > b34 && e34 - b34 >= kLongPartitionMergeMin) {
@@ -996,6 +1046,17 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     size_t mainIdx = 0;
     for (size_t i = 1; i < runs.size(); i++)
         if (runs[i].end - runs[i].begin > runs[mainIdx].end - runs[mainIdx].begin) mainIdx = i;
+    // a pipeline stage (the long subjects above, the long entries of the re-score lists below) takes exactly the register-file
+    // slot of a wave of the bulk launch it runs beside, so that it leaves no hole behind in which no wave of that persistent
+    // grid fits (include/cudasw4_amd.h: sw_launch_vgpr_slot)
+    if (pipelineOk) {
+        int vslot = 0;
+        if (!runs.empty()) {
+            const LaunchRun& m = runs[mainIdx];
+            vslot = sw_launch_vgpr_slot(g.ctx, int(m.kind), m.part_id, int32_t(m.end - m.begin), m.maxlen);
+        }
+        SWCHECK(sw_set_rows_pipeline_slot(g.ctx, vslot));
+    }
     // Re-score service for the bulk run's overflow list (Gpu::svcStream): resident chars only (a staging buffer would have
     // to wait for it), a packed bulk run, and a query / subject size at which re-scoring one subject takes about as long as
     // a launch does at all (5 * 10^5 cells)
@@ -1008,7 +1069,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         const LaunchRun& r = runs[mainIdx];
         HIPCHECK(hipMemsetAsync(g.d_ovfPos + r.begin, 0xFF, (r.end - r.begin) * sizeof(int32_t), work));
     }
-    if (runs.size() > 1 || useService) HIPCHECK(hipEventRecord(fork, work));
+    if (runs.size() > 1 || useService || !pipeParts.empty()) HIPCHECK(hipEventRecord(fork, work));
     std::vector<int> ovfList(runs.size(), -1);
     int numLists = 0;
     for (size_t i = 0; i < runs.size(); i++)
@@ -1059,50 +1120,59 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // threads per subject instead of one wave, 3 x faster for a long query and 20 x for a short one, for 2.3 x the
     // instructions — so only where the one-wave launch would be (close to) what the scan waits for: shards of a real DB,
     // short queries.  Returns false when the run is to be launched as it is.
-    auto launch_rows = [&](size_t ri, hipStream_t stream, int tslot) -> bool {
+    auto launch_rows = [&](size_t ri, hipStream_t stream) -> bool {
         const LaunchRun& r = runs[ri];
-        if (g.rowsMode == 0 || is_packed(r.kind) || r.part_id != kNumLengthPartitions - 1) return false;
-        if (gop > gex) return false;
+        // (round 5: the subjects whose walk would matter have left the scan launches as pipelines — `cut` above; what is left
+        // here is CUDASW4_AMD_ROWS=single, the one-workgroup form of round 4 by its time estimate, kept for A/B measurements)
+        if (g.rowsMode != 3 || is_packed(r.kind) || r.part_id != kNumLengthPartitions - 1) return false;
+        if (gop > gex || r.maxlen > sw_scan_rows_max_subject() || r.end - r.begin > 64) return false;
+        if (giant_seconds(r) < 0.8 * bulk_seconds()) return false;
         const int32_t n = int32_t(r.end - r.begin);
-        // Pipelined (round 5): every subject on as many SIMDs as it has spans, ~0.3 us per query row whatever its length —
-        // 35 213 x 5 478 in ~2 ms against 22.6 on one CU and 60 on one wave.  Whenever it applies: a handful of subjects
-        // (more of them are throughput, not latency: the scan kernels), a hand-off array that fits the scratch budget.
-        bool pipelined = false;
-        void* temp = nullptr;
-        if (g.rowsMode != 3 && n <= kPipelineMaxSubjects && int64_t(r.maxlen) * int64_t(-gex) < (int64_t(1) << 28)) {
-            const size_t need = sw_scan_rows_pipelined_temp_bytes(g.ctx, n, r.maxlen);
-            if (need > 0 && need <= std::min(mem.maxTempBytes, g.tempCap)) {
-                temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
-                pipelined = true;
-            }
-        }
-        if (!pipelined) {
-            if (r.maxlen > sw_scan_rows_max_subject() || n > 64) return false;
-            if (g.rowsMode != 2 && giant_seconds(r) < 0.8 * bulk_seconds()) return false;
-        }
         TimedLaunch t;
         const bool record = recordMode == 1;
         if (record) {
             if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
             else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
             t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = false;
-            t.eff_kind = SW_KIND_I32; t.rows = (r.maxlen + 1023) / 1024; t.nstripes = 1; t.lanes = pipelined ? 64 : 1024;
+            t.eff_kind = SW_KIND_I32; t.rows = (r.maxlen + 1023) / 1024; t.nstripes = 1; t.lanes = 1024;
             HIPCHECK(hipEventRecord(t.ev0, stream));
         }
-        if (pipelined)
-            SWCHECK(sw_scan_rows_pipelined(g.ctx, chars, offsets, lengths, int32_t(r.begin - lbegin), n, r.maxlen, gop, gex,
-                                           g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), g.failSlot, temp,
-                                           g.tempBytes[tslot], stream));
-        else
-            SWCHECK(sw_scan_rows(g.ctx, chars, offsets, lengths, int32_t(r.begin - lbegin), n, r.maxlen, gop, gex, g.d_scores + lbegin,
-                                 g.d_ids + lbegin, int64_t(lbegin), stream));
+        SWCHECK(sw_scan_rows(g.ctx, chars, offsets, lengths, int32_t(r.begin - lbegin), n, r.maxlen, gop, gex, g.d_scores + lbegin,
+                             g.d_ids + lbegin, int64_t(lbegin), stream));
         if (record) {
             HIPCHECK(hipEventRecord(t.ev1, stream));
             g.timed.push_back(t);
         }
         g.rowsLaunches++;
-        if (pipelined) g.pipelineLaunches++;
         return true;
+    };
+    // one part of the pipelined subjects on an auxiliary stream
+    auto launch_pipeline = [&](const PipePart& pp, hipStream_t stream, int tslot) {
+        const int32_t n = int32_t(pp.end - pp.begin);
+        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], pp.need, std::min(mem.maxTempBytes, g.tempCap));
+        // the reference's statistic counts the subjects whose exact score reaches the packed kind's limit — also where no
+        // packed launch ever saw them
+        const KernelType pk = kt.for_partition(pp.part_id);
+        const int32_t limit = pk == KernelType::Half2 ? SW_MAX_ACC_F16 : pk == KernelType::DPXs16 ? SW_MAX_ACC_I16 : 0;
+        TimedLaunch t;
+        const bool record = recordMode == 1;
+        if (record) {
+            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
+            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
+            t.kind = int(pk); t.part_id = pp.part_id; t.qlen = g.qlen; t.lbegin = pp.begin; t.lend = pp.end; t.rescore = false;
+            t.eff_kind = SW_KIND_I32; t.rows = (pp.maxlen + 1023) / 1024; t.nstripes = 1; t.lanes = 64;
+            HIPCHECK(hipEventRecord(t.ev0, stream));
+        }
+        SWCHECK(sw_scan_rows_pipelined(g.ctx, chars, offsets, lengths, int32_t(pp.begin - lbegin), n, pp.maxlen, gop, gex,
+                                       g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), g.failSlot,
+                                       limit > 0 ? g.d_ovfCount : nullptr, limit > 0 ? g.pipeOverSlot : nullptr, limit, temp,
+                                       g.tempBytes[tslot], stream));
+        if (record) {
+            HIPCHECK(hipEventRecord(t.ev1, stream));
+            g.timed.push_back(t);
+        }
+        g.rowsLaunches++;
+        g.pipelineLaunches++;
     };
     auto launch_windows = [&](size_t ri, hipStream_t stream, int a) -> bool {
         const LaunchRun& r = runs[ri];
@@ -1211,7 +1281,27 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
             SWCHECK(sw_plan_launch(g.ctx, int(kt.overflowType), -1, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
             HIPCHECK(hipEventRecord(t.ev0, stream));
         }
-        if (useService && ri == mainIdx)   // what the service has not taken
+        // The long subjects of the list first, pipelined (include/cudasw4_amd.h: sw_rescore_overflow_pipelined): a flagged
+        // subject is one group's walk — 16 ms for a 5 500-residue relative of a 5 478-residue query, behind the launch
+        // that flagged it — and on a shard that walk outlasts the bulk launch.  Entries whose walk would take more than
+        // kPipelineRescoreShare of the bulk launch's estimated time; the ordinary launch behind claims what is left.
+        bool picked = false;
+        if (pipelineOk && g.rowsMode != 3) {
+            const double minLen = std::max(256.0, g.pipelineRescoreShare * bulkSeconds / colSeconds);
+            const size_t need2 = double(r.maxlen) >= minLen && int64_t(r.maxlen) * int64_t(-gex) < (int64_t(1) << 28)
+                                     ? sw_rescore_overflow_pipelined_temp_bytes(g.ctx, r.maxlen) : 0;
+            if (need2 > 0 && need2 <= std::min(mem.maxTempBytes, g.tempCap)) {
+                temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], std::max(need, need2), std::min(mem.maxTempBytes, g.tempCap));
+                SWCHECK(sw_rescore_overflow_pipelined(g.ctx, g.d_ovfPos + r.begin, counters + ovfList[ri], n, chars, offsets, lengths,
+                                                      r.maxlen, int32_t(minLen), gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
+                                                      int64_t(lbegin), g.failSlot,
+                                                      r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16, g.d_ovfCount,
+                                                      temp, g.tempBytes[tslot], stream));
+                picked = true;
+                g.pipelineRescores++;
+            }
+        }
+        if ((useService && ri == mainIdx) || picked)   // what the service / the pipelined launch has not taken
             SWCHECK(sw_rescore_overflow_claim(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[ri], n,
                                               chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
                                               int64_t(lbegin), temp, g.tempBytes[tslot],
@@ -1237,6 +1327,17 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     bool auxBusy[GpuT::kAux] = {};
     std::vector<int> streamOf(runs.size(), -1);  // auxiliary stream of a run, -1: work stream
     bool anySide = false;
+    for (const PipePart& pp : pipeParts) {
+        const int a = auxNext++ % GpuT::kAux;
+        if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], fork, 0));
+        auxBusy[a] = true;
+        if (g.handshake && !runs.empty()) {
+            SWCHECK(sw_set_start_signal(g.ctx, g.startSignal));
+            g.sideLaunches++;
+            anySide = true;
+        }
+        launch_pipeline(pp, g.aux[a], a + 1);
+    }
     for (size_t i = 0; i < runs.size(); i++) {
         if (i == mainIdx || (shareLast && ovfList[i] == GpuT::kOvfLists - 1)) continue;
         const int a = auxNext++ % GpuT::kAux;
@@ -1250,7 +1351,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         }
         // (windows first: where the span bound cuts the subjects — short queries — they are a little faster than the rows,
         // 8 253 against 7 818 GCUPS for a stream of 48-residue queries; long queries have no windows)
-        if (!launch_windows(i, g.aux[a], a) && !launch_rows(i, g.aux[a], a + 1)) launch(i, g.aux[a], a + 1);
+        if (!launch_windows(i, g.aux[a], a) && !launch_rows(i, g.aux[a])) launch(i, g.aux[a], a + 1);
     }
     if (useService) {
         const LaunchRun& r = runs[mainIdx];
@@ -1493,7 +1594,7 @@ bool SearchDriver::prepareLane(Gpu& g, int32_t queryLength) {
         }
         if (!g.lane1.scanStartEv) HIPCHECK(hipEventCreate(&g.lane1.scanStartEv));
         if (!g.lane1.d_ovfCount) {
-            g.lane1.ovfCountCap = 2 + Gpu::kOvfLists + 1;
+            g.lane1.ovfCountCap = 3 + Gpu::kOvfLists + 1;
             HIPCHECK(hipMalloc(&g.lane1.d_ovfCount, g.lane1.ovfCountCap * sizeof(int32_t)));
         }
         if (!g.lane1Ready) {
@@ -1547,16 +1648,17 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
         // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed); + 1: pipeline stages
         // that gave up waiting (sw_scan_rows_pipelined: fail_count)
         const size_t ncounters = 1 + (1 + g.batches.size()) * Gpu::kOvfLists;
-        if (ncounters + 2 > g.ovfCountCap) {
+        if (ncounters + 3 > g.ovfCountCap) {
             (void)hipFree(g.d_ovfCount);
             g.d_ovfCount = nullptr;
             g.ovfCountCap = 0;
-            HIPCHECK(hipMalloc(&g.d_ovfCount, (ncounters + 2) * sizeof(int32_t)));
-            g.ovfCountCap = ncounters + 2;
+            HIPCHECK(hipMalloc(&g.d_ovfCount, (ncounters + 3) * sizeof(int32_t)));
+            g.ovfCountCap = ncounters + 3;
         }
-        ensure_ovf_slots(rs.h_ovf, rs.ovfCap, ncounters + 2);
-        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, (ncounters + 2) * sizeof(int32_t), g.stream));
+        ensure_ovf_slots(rs.h_ovf, rs.ovfCap, ncounters + 3);
+        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, (ncounters + 3) * sizeof(int32_t), g.stream));
         g.failSlot = g.d_ovfCount + ncounters + 1;
+        g.pipeOverSlot = g.d_ovfCount + ncounters + 2;   // (+ 1: pipelined subjects of packed partitions at or above the packed limit)
         HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
         // the cached part first (the longest subjects: one set of launches over everything that is resident), then the
         // streamed batches — whose first copies run while the cached part computes
@@ -1599,7 +1701,7 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
             rs.top = kk;
         }
         // per-query totals (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
-        HIPCHECK(hipMemcpyAsync(rs.h_ovf, g.d_ovfCount, (ncounters + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipMemcpyAsync(rs.h_ovf, g.d_ovfCount, (ncounters + 3) * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
         HIPCHECK(hipEventRecord(rs.done, g.stream));
         rs.ncounters = ncounters;
         rs.used = true;
@@ -1654,6 +1756,7 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot) {
         throw std::runtime_error("scan failed: " + std::to_string(rs.h_ovf[rs.ncounters + 1]) +
                                  " pipeline stage(s) of a long subject gave up waiting for their neighbour (sw_scan_rows_pipelined)");
     for (size_t i = 1; i < rs.ncounters; i++) g.lastRescored += rs.h_ovf[i];
+    g.lastRescored += rs.h_ovf[rs.ncounters + 2];   // pipelined subjects a packed launch would have flagged: scored in 32 bits as well
     g.lastOverflows = rs.h_ovf[0];
     g.lastTop = rs.top;
     g.quietScans = g.lastRescored > 0 ? 0 : std::min(g.quietScans + 1, 1000);

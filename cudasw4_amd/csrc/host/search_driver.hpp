@@ -71,9 +71,13 @@ struct LaunchRun {
 // this many subjects up the library gives it the 16-lane shape (sw_api.hip: lanes_for_partition), i.e. the very kernel
 // the partitions below it run on.
 constexpr size_t kLongPartitionMergeMin = 512;
-// sw_scan_rows_pipelined takes partition 35 while it holds at most this many subjects (a handful of giants is a latency
-// problem, thousands of them are throughput: the scan kernels)
+// sw_scan_rows_pipelined takes the longest subjects of partitions 34 / 35 — those whose lone walk on an alignment group
+// would take more than kPipelineWalkShare of the bulk launch's estimated time — but at most this many (a handful of long
+// subjects is a latency problem, thousands of them are throughput: the scan kernels)
 constexpr int32_t kPipelineMaxSubjects = 256;
+constexpr double kPipelineWalkShare = 0.5;
+// ... and the flagged subjects of an overflow list whose 32-bit re-score walk would take more than this share of it
+constexpr double kPipelineRescoreShare = 0.1;
 
 // Partition walk of runAlignmentKernels (cudasw4.cuh:1742-2103) over the positions [begin, end) of a subject list
 // whose partition p occupies [partBegin[p], partBegin[p+1]): largest partition first, adjacent partitions of equal

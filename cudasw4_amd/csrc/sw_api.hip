@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
@@ -170,6 +171,7 @@ struct sw_ctx {
     uint32_t pipe_spin_limit = 1u << 20;  // CUDASW4_AMD_PIPE_SPIN_LIMIT: polls (~2 us each) before a pipeline stage gives up waiting
     int32_t pipe_drop_stage = -1;         // CUDASW4_AMD_PIPE_TEST_DROP_STAGE (tests): this stage of every subject is lost
     int32_t pipe_cpl = 0;                 // CUDASW4_AMD_PIPE_CPL=4|8|16: columns per lane of a stage (0: by the subjects' length)
+    int32_t pipe_slot = 0;                // sw_set_rows_pipeline_slot: VGPRs a stage occupies (128 / 168 / 256; 0: what it needs)
 };
 
 namespace {
@@ -636,11 +638,26 @@ int rows_common_checks(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets
     return SW_OK;
 }
 
-// columns per lane of a pipeline stage: short spans finish a row sooner, long ones keep the number of stages (and of
-// hand-offs a row passes through) down
-int pipeline_cpl(const sw_ctx* ctx, int32_t max_subject_len) {
+// Columns per lane of a pipeline stage.  Narrow spans finish a row sooner, wide ones keep the number of stages — and of
+// hand-offs the first row passes through before the last stage starts — down.  Measured on MI355X (tools/giants_bench.py,
+// profiles/r05_giants_bench.txt): a row takes 0.26 / 0.33 / 0.50 us at 4 / 8 / 16 columns per lane, a hand-off 3.6 / 5.0 / 8 us
+// (the consumer starts a batch of rows when the producer has finished it), so the launch takes about
+// qlen * row + stages * hand-off: the width that minimises that for the current query and the longest subject.
+int pipeline_cpl(const sw_ctx* ctx, int32_t n, int32_t max_subject_len) {
     if (ctx->pipe_cpl == 4 || ctx->pipe_cpl == 8 || ctx->pipe_cpl == 16) return ctx->pipe_cpl;
-    return max_subject_len <= 12288 ? 4 : max_subject_len <= 49152 ? 8 : 16;
+    static const double kRowUs[3] = {0.26, 0.33, 0.50}, kHopUs[3] = {3.6, 5.0, 8.0};
+    int best = 16;
+    double bestT = 1e300;
+    for (int k = 0; k < 3; k++) {
+        const int cpl = 4 << k;
+        const double stages = std::max(1.0, std::ceil((double)max_subject_len / (64.0 * cpl)));
+        // every stage displaces a wave of the launch it runs beside for as long as it lives, and narrow spans spend more
+        // instructions per cell: many subjects at once take wide spans (at most ~3 stages per 4 SIMDs of an MI355X)
+        if (cpl < 16 && (double)std::max(n, 1) * stages > 768.0) continue;
+        const double t = (double)std::max(ctx->qlen, 1) * kRowUs[k] + stages * kHopUs[k];
+        if (t < bestT) { bestT = t; best = cpl; }
+    }
+    return best;
 }
 int64_t pipeline_stages(int cpl, int32_t max_subject_len) { return std::max<int64_t>(1, ((int64_t)max_subject_len + 64 * cpl - 1) / (64 * cpl)); }
 }  // namespace
@@ -680,13 +697,70 @@ int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, cons
 
 size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx* ctx, int32_t n, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || n <= 0 || max_subject_len < 0) return 0;
-    const int64_t tickets = (int64_t)n * pipeline_stages(pipeline_cpl(ctx, max_subject_len), max_subject_len);
+    const int64_t tickets = (int64_t)n * pipeline_stages(pipeline_cpl(ctx, n, max_subject_len), max_subject_len);
     return (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
 }
 
+namespace {
+// the launch both pipelined entry points share: `tickets` workgroups of one wave, hand-off words at `xfer`
+int launch_pipeline(sw_ctx* ctx, swk::PipelineParams& p, int cpl, int64_t stages, int64_t tickets, uint32_t* start_signal, void* xfer,
+                    hipStream_t stream) {
+    const size_t need = (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
+    p.query = ctx->d_query; p.qlen = ctx->qlen; p.matrix = ctx->d_matrix; p.dim = ctx->dim;
+    p.xfer = static_cast<unsigned long long*>(xfer);
+    p.ctrl = ctx->d_pipe_ctrl + 4 * (ctx->pipe_next++ % sw_ctx::kPipeCtrlSlots);
+    p.start_signal = start_signal;
+    p.start_quorum = (uint32_t)tickets;   // every workgroup counts itself in, also those whose stage does not exist: all of them fit the GPU at once
+    p.max_stages = (int32_t)stages;
+    p.spin_limit = ctx->pipe_spin_limit;
+    p.test_drop_stage = ctx->pipe_drop_stage;
+    SW_HIP(hipMemsetAsync(p.ctrl, 0, 4 * sizeof(uint32_t), stream));
+    SW_HIP(hipMemsetAsync(xfer, 0xFF, need, stream));   // "not written yet"
+    const dim3 grid((unsigned)tickets), block(64);
+    const int slot = ctx->pipe_slot;
+#define SW_PIPE_LAUNCH(CPL)                                                                                              \
+    do {                                                                                                                 \
+        if (slot == 128) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 128>), grid, block, 0, stream, p);        \
+        else if (slot == 168) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 168>), grid, block, 0, stream, p);   \
+        else if (slot == 256) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 256>), grid, block, 0, stream, p);   \
+        else hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 0>), grid, block, 0, stream, p);                      \
+    } while (0)
+    if (cpl == 4) SW_PIPE_LAUNCH(4);
+    else if (cpl == 8) SW_PIPE_LAUNCH(8);
+    else SW_PIPE_LAUNCH(16);
+#undef SW_PIPE_LAUNCH
+    SW_HIP(hipGetLastError());
+    return SW_OK;
+}
+
+// Re-score lists: the entries whose subject is at least min_len residues long (at most `cap` of them) move to a list of
+// their own, which the pipelined launch takes; in the original list they are marked taken (compare-and-swap: a re-score
+// service may still be claiming entries), so that the ordinary re-score launch behind — in claim mode — skips them.
+__global__ void __launch_bounds__(256) pipeline_pick_kernel(int32_t* list, const int32_t* count_ptr, int32_t max_count, const int32_t* lengths,
+                                                            int32_t min_len, int32_t cap, int32_t* out_pos, int32_t* out_count) {
+    __shared__ int k;
+    if (threadIdx.x == 0) k = 0;
+    __syncthreads();
+    const int32_t cnt = min(*count_ptr, max_count);
+    for (int32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const int32_t v = __hip_atomic_load(list + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v < 0 || lengths[v] < min_len) continue;
+        const int slot = atomicAdd(&k, 1);
+        if (slot >= cap) continue;   // (the counter overshoots; what does not fit stays with the ordinary launch)
+        if (atomicCAS(list + i, v, swk::kListTaken) == v) out_pos[slot] = v;
+        else out_pos[slot] = -1;     // somebody else took it in between: an empty slot (the pipelined kernel skips it)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *out_count = min(k, cap);
+}
+constexpr int32_t kPipeRescoreCap = 64;   // entries of one re-score list that can run pipelined
+size_t pipe_rescore_header_bytes() { return 256 + (size_t)kPipeRescoreCap * sizeof(int32_t); }
+}  // namespace
+
 int sw_scan_rows_pipelined(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos,
                            int32_t n, int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
-                           int32_t* fail_count, void* temp, size_t temp_bytes, void* stream_) {
+                           int32_t* fail_count, int32_t* over_limit_count, int32_t* over_limit_count2, int32_t packed_limit,
+                           void* temp, size_t temp_bytes, void* stream_) {
     if (!ctx) return fail(SW_ERR_INVALID, "null context");
     uint32_t* const start_signal = ctx->start_signal;
     ctx->start_signal = nullptr;
@@ -697,7 +771,7 @@ int sw_scan_rows_pipelined(sw_ctx* ctx, const int8_t* chars, const uint64_t* off
     if ((int64_t)max_subject_len * (int64_t)(-gex) >= ((int64_t)1 << 28)) return fail(SW_ERR_INVALID, "subject length x gap extension out of range for sw_scan_rows_pipelined");
     const int rc = rows_common_checks(ctx, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids, dry_armed, stream, "sw_scan_rows_pipelined");
     if (rc != SW_OK || n == 0) return rc;
-    const int cpl = pipeline_cpl(ctx, max_subject_len);
+    const int cpl = pipeline_cpl(ctx, n, max_subject_len);
     const int64_t stages = pipeline_stages(cpl, max_subject_len);
     const int64_t tickets = (int64_t)n * stages;
     if (tickets > (int64_t)1 << 24) return fail(SW_ERR_INVALID, "too many pipeline stages for one sw_scan_rows_pipelined launch");
@@ -705,24 +779,49 @@ int sw_scan_rows_pipelined(sw_ctx* ctx, const int8_t* chars, const uint64_t* off
     if (!temp || temp_bytes < need) return fail(SW_ERR_TEMP, "temp buffer too small for sw_scan_rows_pipelined (sw_scan_rows_pipelined_temp_bytes)");
     swk::PipelineParams p{};
     p.chars = chars; p.offsets = offsets; p.lengths = lengths; p.first_pos = first_pos; p.n = n;
-    p.query = ctx->d_query; p.qlen = ctx->qlen; p.matrix = ctx->d_matrix; p.dim = ctx->dim;
     p.gop = gop; p.gex = gex; p.scores = scores; p.ids = ids; p.id_offset = id_offset;
-    p.xfer = static_cast<unsigned long long*>(temp);
-    p.ctrl = ctx->d_pipe_ctrl + 4 * (ctx->pipe_next++ % sw_ctx::kPipeCtrlSlots);
-    p.start_signal = start_signal;
-    p.start_quorum = (uint32_t)tickets;   // every workgroup counts itself in, also those whose stage does not exist: all of them fit the GPU at once
     p.fail_count = fail_count;
-    p.max_stages = (int32_t)stages;
-    p.spin_limit = ctx->pipe_spin_limit;
-    p.test_drop_stage = ctx->pipe_drop_stage;
-    SW_HIP(hipMemsetAsync(p.ctrl, 0, 4 * sizeof(uint32_t), stream));
-    SW_HIP(hipMemsetAsync(temp, 0xFF, need, stream));   // "not written yet"
-    const dim3 grid((unsigned)tickets), block(64);
-    if (cpl == 4) hipLaunchKernelGGL(swk::sw_rows_pipeline_kernel<4>, grid, block, 0, stream, p);
-    else if (cpl == 8) hipLaunchKernelGGL(swk::sw_rows_pipeline_kernel<8>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(swk::sw_rows_pipeline_kernel<16>, grid, block, 0, stream, p);
+    p.stat_count = over_limit_count; p.stat_count2 = over_limit_count2; p.stat_limit = packed_limit;
+    return launch_pipeline(ctx, p, cpl, stages, tickets, start_signal, temp, stream);
+}
+
+size_t sw_rescore_overflow_pipelined_temp_bytes(sw_ctx* ctx, int32_t max_subject_len) {
+    if (!ctx || !ctx->have_query || max_subject_len < 0) return 0;
+    const int64_t tickets = (int64_t)kPipeRescoreCap * pipeline_stages(pipeline_cpl(ctx, kPipeRescoreCap, max_subject_len), max_subject_len);
+    return pipe_rescore_header_bytes() + (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
+}
+
+int sw_rescore_overflow_pipelined(sw_ctx* ctx, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count, const int8_t* chars,
+                                  const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len, int32_t min_subject_len,
+                                  int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, int32_t* fail_count,
+                                  int32_t packed_limit, int32_t* true_overflow_count, void* temp, size_t temp_bytes, void* stream_) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    ctx->start_signal = nullptr;   // (these launches run behind the launch that filled their list: no handshake)
+    const bool dry_armed = ctx->dry_signal != nullptr;
+    ctx->dry_signal = nullptr;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!ovf_pos || !ovf_count) return fail(SW_ERR_INVALID, "null overflow buffers");
+    if (max_count <= 0) return SW_OK;
+    if ((int64_t)max_subject_len * (int64_t)(-gex) >= ((int64_t)1 << 28)) return fail(SW_ERR_INVALID, "subject length x gap extension out of range for sw_rescore_overflow_pipelined");
+    const int rc = rows_common_checks(ctx, chars, offsets, lengths, 0, 1, max_subject_len, gop, gex, scores, ids, dry_armed, stream, "sw_rescore_overflow_pipelined");
+    if (rc != SW_OK) return rc;
+    const int cpl = pipeline_cpl(ctx, kPipeRescoreCap, max_subject_len);
+    const int64_t stages = pipeline_stages(cpl, max_subject_len);
+    const int64_t tickets = (int64_t)kPipeRescoreCap * stages;
+    const size_t need = sw_rescore_overflow_pipelined_temp_bytes(ctx, max_subject_len);
+    if (!temp || temp_bytes < need) return fail(SW_ERR_TEMP, "temp buffer too small for sw_rescore_overflow_pipelined");
+    int32_t* out_count = static_cast<int32_t*>(temp);
+    int32_t* out_pos = reinterpret_cast<int32_t*>(static_cast<char*>(temp) + 256);
+    hipLaunchKernelGGL(pipeline_pick_kernel, dim3(1), dim3(256), 0, stream, ovf_pos, ovf_count, max_count, lengths, std::max(min_subject_len, 1),
+                       kPipeRescoreCap, out_pos, out_count);
     SW_HIP(hipGetLastError());
-    return SW_OK;
+    swk::PipelineParams p{};
+    p.chars = chars; p.offsets = offsets; p.lengths = lengths; p.first_pos = 0; p.n = kPipeRescoreCap;
+    p.positions = out_pos; p.count_ptr = out_count;
+    p.gop = gop; p.gex = gex; p.scores = scores; p.ids = ids; p.id_offset = id_offset;
+    p.fail_count = fail_count;
+    p.stat_count = true_overflow_count; p.stat_count2 = nullptr; p.stat_limit = packed_limit;
+    return launch_pipeline(ctx, p, cpl, stages, tickets, nullptr, static_cast<char*>(temp) + pipe_rescore_header_bytes(), stream);
 }
 
 int sw_set_dry_signal(sw_ctx* ctx, uint32_t* signal, uint32_t value) {
@@ -879,6 +978,22 @@ int sw_plan_launch(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_su
     if (rows_per_lane) *rows_per_lane = pl.rows;
     if (nstripes) *nstripes = pl.nstripes;
     if (lanes) *lanes = ln;
+    return SW_OK;
+}
+
+int sw_launch_vgpr_slot(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
+    if (!ctx || !kind_launch(kind) || !ctx->have_query || part_id >= SW_NUM_LENGTH_PARTITIONS || max_subject_len < 0) return 0;
+    kind = effective_kind_of(ctx, kind, max_subject_len);
+    const int ln = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, kind, part_id, n, max_subject_len);
+    const QueryPlan pl = plan_query(kind, ctx->qlen, ln);
+    if (pl.rows <= 0) return 0;
+    return swk::vgpr_slot_of(kind, pl.rows, ln, pl.nstripes > 1);
+}
+
+int sw_set_rows_pipeline_slot(sw_ctx* ctx, int vgprs) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    if (vgprs != 0 && vgprs != 128 && vgprs != 168 && vgprs != 256) return fail(SW_ERR_INVALID, "a register-file slot is 128, 168 or 256 VGPRs (0: as few as the stage needs)");
+    ctx->pipe_slot = vgprs;
     return SW_OK;
 }
 

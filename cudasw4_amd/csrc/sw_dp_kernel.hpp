@@ -847,12 +847,12 @@ constexpr int border_region_words(int lcap) { return Border<LANES>::blocks(lcap)
 #ifndef SWK_F32_WAVES3_MAX_R_MULTI
 #define SWK_F32_WAVES3_MAX_R_MULTI 48
 #endif
-template <int KIND, int R, int LANES, bool MULTI>
-constexpr int min_waves() {
+constexpr int min_waves_of(int KIND, int R, int LANES, bool MULTI) {
+    const bool packed = KIND == F16X2 || KIND == I16X2;
     // packed kinds: 2 waves/SIMD (256 VGPRs) for the tall kernels; up to SWK_WAVES3_MAX_R rows a third wave is asked for
     // (168 VGPRs): two waves cover each other's wait states only ~92 % of the time, three reach the issue peak
-    if (Arith<KIND>::kPacked && LANES <= 16 && MULTI && R <= SWK_WAVES3_MAX_R_MULTI) return 3;
-    if (Arith<KIND>::kPacked) return (LANES <= 16 && !MULTI && R <= SWK_WAVES4_MAX_R) ? 4 : (LANES <= 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
+    if (packed && LANES <= 16 && MULTI && R <= SWK_WAVES3_MAX_R_MULTI) return 3;
+    if (packed) return (LANES <= 16 && !MULTI && R <= SWK_WAVES4_MAX_R) ? 4 : (LANES <= 16 && !MULTI && R <= SWK_WAVES3_MAX_R) ? 3 : 2;
     if (SWK_MIN_WAVES_SCALAR > 0) return SWK_MIN_WAVES_SCALAR;
     // int32 above 32 rows per lane: two waves per SIMD (the registers of the taller stripes; its add/max3 mix cannot
     // co-issue anyway).  Up to 32 rows the third wave is worth more than the spills it causes in the multi-stripe kernels
@@ -862,6 +862,10 @@ constexpr int min_waves() {
     // 4 would spill the multi-stripe R = 14..16 kernels; the wave-wide shape's 43 KB tiles cap it at 3 anyway
     return (R <= 16 && !MULTI && LANES <= 16) ? 4 : 3;
 }
+template <int KIND, int R, int LANES, bool MULTI>
+constexpr int min_waves() { return min_waves_of(KIND, R, LANES, MULTI); }
+// the vector registers a wave of that kernel may take: its slot in a SIMD's 512-entry register file (allocated in eights)
+constexpr int vgpr_slot_of(int KIND, int R, int LANES, bool MULTI) { return (512 / min_waves_of(KIND, R, LANES, MULTI)) & ~7; }
 
 template <int KIND, int R, int LANES, bool MULTI, bool OFFS = false>
 __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())) sw_scan_kernel(const ScanParams p) {
@@ -887,6 +891,10 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         if (atomicAdd(p.work_counter + 1, 1u) + 1u == p.start_quorum)
             __hip_atomic_fetch_add(p.start_signal, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // A re-score launch is the tail of its scan: a handful of subjects, each one group's walk, started BEHIND the bulk grid
+    // whose older waves win the SIMD's arbitration — measured 0.27 us per step of a wave-wide fp32 group against 0.14 for
+    // the same kernel launched ahead of the bulk grid.  Raised priority gives the walk its issue slots.
+    if (p.positions) __builtin_amdgcn_s_setprio(2);
     const bool service = p.service != 0;  // uniform
     const int n = (p.count_ptr && !service) ? *p.count_ptr : p.n;  // service: the list's capacity; its length is polled per batch
     constexpr int kSubjPerBatch = kGroups * A::kSubjects;

@@ -24,6 +24,18 @@
 // which ends everybody else's waits, marks its subject's score -2 and counts itself in *fail_count — the host driver
 // checks that word with the scan's counters and fails the query loudly.
 //
+// A stage must not leave a hole behind.  The bulk launch that starts beside this one is a PERSISTENT grid: its waves are
+// placed once and stay to the end of the scan, and both the vector registers of a SIMD and the LDS of a CU are allocated as
+// contiguous ranges.  The first form of this kernel (2.3 KB of LDS for the substitution table, 56 VGPRs) ran 2 ms and cost
+// the bulk launch 8 ... 35 % of its WHOLE duration (profiles/r05_pipeline_fragmentation.txt): behind the small allocations
+// the bulk waves sat at odd offsets, and when the stages had left, the 56-register / 2.5 KB holes they left at the start of
+// the register file / of the LDS were useless to the 168- or 256-register, 51 ... 63 KB workgroups still queued — three
+// waves per SIMD became two (or two one) for the rest of the scan.  So a stage uses NO LDS (the substitution table lives in
+// 26 VGPRs, one query letter per register, one subject letter per lane, and is read with ds_bpermute, which needs no
+// allocation), and it occupies exactly one register-file SLOT of the launch it runs beside (SLOT = 128, 168 or 256
+// VGPRs = what a wave of a four-, three- or two-waves-per-SIMD scan kernel takes): when it leaves, a queued wave of that
+// launch fits the hole exactly.
+//
 // int32 arithmetic; ~12 VALU instructions per cell (the scan kernels: 6.5) but 69 SIMDs instead of one for a
 // 35 000-residue subject: ~0.3 us per query row whatever the subject's length.
 #pragma once
@@ -41,6 +53,8 @@ struct PipelineParams {
     const int32_t* lengths;
     int32_t first_pos;         // subjects first_pos .. first_pos + n - 1, ascending length; the longest gets the first tickets
     int32_t n;
+    const int32_t* positions;  // optional list of subject positions instead (a re-score list), n = its capacity ...
+    const int32_t* count_ptr;  // ... and its length on the device
     const int8_t* query;       // letter codes 0 .. dim-1; readable up to the next multiple of 16 behind qlen
     int32_t qlen;
     const int8_t* matrix;      // (dim + 1) x 21 substitution scores, row = query letter
@@ -54,6 +68,9 @@ struct PipelineParams {
     uint32_t* start_signal;    // start handshake (sw_set_start_signal), or nullptr
     uint32_t start_quorum;
     int32_t* fail_count;       // += 1 per stage that gave up waiting (nullptr: not counted)
+    int32_t* stat_count;       // optional: += 1 (and stat_count2 likewise) per subject whose score is >= stat_limit — the
+    int32_t* stat_count2;      // reference's overflow statistic for subjects of a packed partition (half2_kernels.cuh:1087-1109)
+    int32_t stat_limit;
     int32_t max_stages;        // tickets per subject: the stages of the longest subject the caller declared
     uint32_t spin_limit;       // polls of one wait before the stage gives up
     int32_t test_drop_stage;   // >= 0 (tests of the failure path): this stage of every subject leaves without producing
@@ -73,9 +90,14 @@ __device__ __forceinline__ unsigned long long pipe_pack(int lo, int hi) {
     return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32);
 }
 
-template <int CPL>
+constexpr int kPipeTableRows = 26;   // query letters (<= 25) + the padding row
+
+template <int CPL, int SLOT>
 __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelineParams p) {
-    __shared__ int sub[26 * kRowsSubCols];
+    // the wave's register allocation is what the highest register it names says: claim the whole slot
+    if constexpr (SLOT == 128) asm volatile("v_mov_b32 v127, 0" ::: "v127");
+    if constexpr (SLOT == 168) asm volatile("v_mov_b32 v167, 0" ::: "v167");
+    if constexpr (SLOT == 256) asm volatile("v_mov_b32 v255, 0" ::: "v255");
     const int lane = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);   // a stage is a dependent chain that everybody to its right waits for
     if (p.start_signal && lane == 0) {
@@ -86,10 +108,18 @@ __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelinePara
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(p.ctrl, 1u);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    const int subj = p.n - 1 - (int)(t / (uint32_t)p.max_stages);
     const int stage = (int)(t % (uint32_t)p.max_stages);
-    if (subj < 0) return;
-    const int pos = p.first_pos + subj;
+    int pos;
+    if (p.positions) {
+        const int subj = (int)(t / (uint32_t)p.max_stages);
+        if (subj >= min(*p.count_ptr, p.n)) return;
+        pos = p.positions[subj];
+        if (pos < 0) return;   // (an entry somebody else took while the list was picked)
+    } else {
+        const int subj = p.n - 1 - (int)(t / (uint32_t)p.max_stages);
+        if (subj < 0) return;
+        pos = p.first_pos + subj;
+    }
     const int len = p.lengths[pos];
     constexpr int kSpan = 64 * CPL;
     const int nstages = max(1, (len + kSpan - 1) / kSpan);
@@ -97,15 +127,15 @@ __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelinePara
     if (stage == p.test_drop_stage) return;   // (tests: a stage that is lost without a trace — its successors must give up, loudly)
     const bool feeds = stage + 1 < nstages;   // somebody waits for this stage's words
 
-    for (int k = lane; k < (p.dim + 1) * kRowsSubCols; k += 64) {
-        const int r = k / kRowsSubCols, c = k % kRowsSubCols;
-        sub[k] = c < 21 ? (int)p.matrix[r * 21 + c] : -30000;   // a position behind the subject's end: nothing positive starts there
-    }
-    __syncthreads();
+    // substitution scores: register q holds query letter q's row, lane j the score against subject letter j; "letter" 21 =
+    // a position behind the subject's end scores -30000 against everything, so nothing positive ever starts there
+    int tbl[kPipeTableRows];
+#pragma unroll
+    for (int q = 0; q < kPipeTableRows; q++) tbl[q] = (q <= p.dim && lane < 21) ? (int)p.matrix[q * 21 + lane] : -30000;
 
     const int8_t* const s = p.chars + (p.offsets[pos] - p.offsets[0]);
     const int col0 = (stage * 64 + lane) * CPL;   // first owned column (0-based)
-    int lofs[CPL];                                // byte offsets of the owned letters' columns in a row of `sub`
+    int lofs[CPL];                                // 4 x the owned letters: the ds_bpermute address of their lane in a table register
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int col = col0 + c;
@@ -158,17 +188,17 @@ __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelinePara
             nxt = pipe_load(xin + min(i0 + kPipeBatch + sl, p.qlen));   // the batch after this one, a batch ahead
         }
         const int curLo = (int)(uint32_t)cur, curHi = (int)(uint32_t)(cur >> 32);
-        // lane r holds the LDS row offset of query letter i0 + r (letters behind the query's end are never used)
-        const int qrow = (int)p.query[i0 + sl] * (kRowsSubCols * 4);
+        // lane r holds query letter i0 + r (letters behind the query's end are never used)
+        const int qvec = (int)p.query[i0 + sl];
         for (int r = 0; r < nrows; r++) {
-            const char* const srow = reinterpret_cast<const char*>(sub) + __builtin_amdgcn_readlane(qrow, r);
+            const int rowv = tbl[__builtin_amdgcn_readlane(qvec, r)];   // (a uniform index into registers: v_movrels)
             const int carryIn = __builtin_amdgcn_readlane(curLo, r);
             const int hlIn = __builtin_amdgcn_readlane(curHi, r);   // H(i, col0 - 1) of lane 0: next row's diagonal input
 
             // ---- pass 1: F and H~ of the owned columns, G = H~ - c * gex (lane-local frame), m = their maximum
             int sc[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; c++) sc[c] = *reinterpret_cast<const int*>(srow + lofs[c]);
+            for (int c = 0; c < CPL; c++) sc[c] = __builtin_amdgcn_ds_bpermute(lofs[c], rowv);
             int prevUp = hleft, m = kRowsNeg;
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
@@ -233,6 +263,8 @@ __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelinePara
         } else {
             p.scores[pos] = (float)best;
             p.ids[pos] = (int32_t)(p.id_offset + pos);
+            if (p.stat_count && best >= p.stat_limit) atomicAdd(p.stat_count, 1);
+            if (p.stat_count2 && best >= p.stat_limit) atomicAdd(p.stat_count2, 1);
         }
     }
 }

@@ -232,12 +232,44 @@ int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, cons
  *   fail_count         optional device word (zeroed by the caller): += 1 for every stage that gave up waiting for its
  *                      neighbour.  Cannot happen on a healthy device (a stage only waits for a workgroup that started
  *                      before it), but every wait is bounded all the same (CUDASW4_AMD_PIPE_SPIN_LIMIT polls, default
- *                      2^20 ~ 2 s); the subject's score is then -2 and the caller must treat the scan as failed. */
+ *                      2^20 ~ 2 s); the subject's score is then -2 and the caller must treat the scan as failed.
+ *   over_limit_count / over_limit_count2 / packed_limit
+ *                      optional device words: each += 1 per subject whose score is >= packed_limit — for subjects of a
+ *                      partition that would otherwise run on a packed kind, the reference's overflow statistic
+ *                      (half2_kernels.cuh:1087-1109; cf. sw_rescore_overflow_stat) and the caller's count of subjects
+ *                      scored in 32 bits. */
+/* The 32-bit re-score of the LONG subjects of an overflow list, pipelined (round 5).  A flagged subject is one alignment
+ * group's walk in sw_rescore_overflow* — 16 ms for a 5 500-residue relative of a 5 478-residue query, behind the launch
+ * that flagged it: on a shard of a real DB that is longer than the whole bulk launch.  This call moves the entries of the
+ * list whose subject has at least min_subject_len residues (at most 64 of them) to a list of its own inside `temp`, marks
+ * them taken in the original list (compare-and-swap, the protocol of sw_rescore_service / sw_rescore_overflow_claim) and
+ * scores them with the stages of sw_scan_rows_pipelined (same contract: gop <= gex, max_subject_len covers the list's
+ * subjects and max_subject_len * |gex| < 2^28).  Call it on the stream BEHIND the launch that filled the list and IN FRONT
+ * of sw_rescore_overflow_claim, which then re-scores what is left.  true_overflow_count / packed_limit as in
+ * sw_rescore_overflow_stat; fail_count as in sw_scan_rows_pipelined; temp_bytes at least
+ * sw_rescore_overflow_pipelined_temp_bytes(ctx, max_subject_len) for the current query. */
+size_t sw_rescore_overflow_pipelined_temp_bytes(sw_ctx* ctx, int32_t max_subject_len);
+int sw_rescore_overflow_pipelined(sw_ctx* ctx, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count, const int8_t* chars,
+                                  const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
+                                  int32_t min_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
+                                  int32_t* fail_count, int32_t packed_limit, int32_t* true_overflow_count, void* temp,
+                                  size_t temp_bytes, void* stream);
+
+/* A pipelined launch that runs BESIDE a persistent scan launch must not leave holes behind: a SIMD's vector registers are
+ * allocated as contiguous ranges, the scan launch's waves stay where they were placed to the end of the scan, and a hole
+ * smaller than one of its waves at the start of the register file costs it a wave per SIMD for its whole duration
+ * (measured: 8 ... 35 % of the bulk launch's rate for a pipelined launch of 2 ms).  sw_launch_vgpr_slot says how many
+ * VGPRs a wave of the launch sw_scan_partition (part_id >= 0) / sw_rescore_overflow (part_id = -1) would make for the
+ * current query may take (128, 168 or 256; 0: unknown); sw_set_rows_pipeline_slot (sticky) makes every stage of the
+ * following sw_scan_rows_pipelined launches occupy exactly that many, so that a queued wave of the scan launch fits the
+ * hole a stage leaves (0, the default: as few as the stage needs).  The stages use no LDS for the same reason. */
+int sw_launch_vgpr_slot(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len);
+int sw_set_rows_pipeline_slot(sw_ctx* ctx, int vgprs);
 size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx* ctx, int32_t n, int32_t max_subject_len);
 int sw_scan_rows_pipelined(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
                            int32_t first_pos, int32_t n, int32_t max_subject_len, int gop, int gex, float* scores,
-                           int32_t* ids, int64_t id_offset, int32_t* fail_count, void* temp, size_t temp_bytes,
-                           void* stream);
+                           int32_t* ids, int64_t id_offset, int32_t* fail_count, int32_t* over_limit_count,
+                           int32_t* over_limit_count2, int32_t packed_limit, void* temp, size_t temp_bytes, void* stream);
 
 /* Sticky: partition 34 (1281 ... 8000 residues) runs on 16-lane groups from `subjects` subjects of a launch up and on
  * wave-wide groups below (default 512; < 0: back to the default).  Wave-wide groups finish ONE subject 3 x sooner at 60 %

@@ -67,6 +67,8 @@ int sw_set_query(sw_ctx* c, const int8_t* q, int32_t qlen, void*) { (void)hipSet
 size_t sw_scan_temp_bytes(sw_ctx*, int, int, int32_t, int32_t) { return 0; }
 int sw_set_start_signal(sw_ctx* c, uint32_t* s) { c->start_signal = s; return SW_OK; }
 int sw_probe_handshake(sw_ctx*, void*, void*, uint32_t*) { return 1; }
+int sw_launch_vgpr_slot(sw_ctx*, int, int, int32_t, int32_t) { return 168; }
+int sw_set_rows_pipeline_slot(sw_ctx*, int) { return SW_OK; }
 int sw_set_dry_signal(sw_ctx* c, uint32_t* s, uint32_t v) { c->dry_signal = s; c->dry_value = v; return SW_OK; }
 int sw_set_grid_reserve(sw_ctx* c, int32_t n) { c->grid_reserve = n; return SW_OK; }
 long fake_sw_dry_signals(int device) { return g_dry[device]; }
@@ -107,11 +109,16 @@ size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx*, int32_t n, int32_t max_subject
 }
 int sw_scan_rows_pipelined(sw_ctx* c, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos, int32_t n,
                            int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, int32_t* fail_count,
-                           void* temp, size_t temp_bytes, void* stream) {
-    owned(c, fail_count);
+                           int32_t* over1, int32_t* over2, int32_t packed_limit, void* temp, size_t temp_bytes, void* stream) {
+    owned(c, fail_count); owned(c, over1); owned(c, over2);
     if (n > 0) { owned(c, temp); if (temp_bytes < sw_scan_rows_pipelined_temp_bytes(c, n, max_subject_len)) return SW_ERR_TEMP; }
-    return sw_scan_partition(c, SW_KIND_I32, 35, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
-                             id_offset, nullptr, nullptr, 0, nullptr, 0, stream);
+    const int rc = sw_scan_partition(c, SW_KIND_I32, 35, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
+                                     id_offset, nullptr, nullptr, 0, nullptr, 0, stream);
+    // what a packed launch of the fake would have flagged (kFakeLimit stands for the packed kind's limit here)
+    if (rc == SW_OK && packed_limit > 0)
+        for (int32_t i = 0; i < n; i++)
+            if (scores[first_pos + i] >= float(kFakeLimit)) { if (over1) (*over1)++; if (over2) (*over2)++; }
+    return rc;
 }
 int sw_rescore_overflow_stat(sw_ctx* c, int, const int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
                              const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t, int, int,
@@ -172,6 +179,12 @@ int sw_rescore_overflow_claim(sw_ctx* c, int kind, int32_t* ovf_pos, const int32
                               const uint64_t* offsets, const int32_t* lengths, int32_t m, int gop, int gex, float* scores, int32_t* ids,
                               int64_t id_offset, void* t, size_t tb, int32_t lim, int32_t* cnt, void* s) {
     return sw_rescore_overflow_stat(c, kind, ovf_pos, ovf_count, max_count, chars, offsets, lengths, m, gop, gex, scores, ids, id_offset, t, tb, lim, cnt, s);
+}
+size_t sw_rescore_overflow_pipelined_temp_bytes(sw_ctx*, int32_t) { return 64; }
+int sw_rescore_overflow_pipelined(sw_ctx* c, int32_t* ovf_pos, const int32_t* ovf_count, int32_t, const int8_t*, const uint64_t*, const int32_t*, int32_t,
+                                  int32_t, int, int, float*, int32_t*, int64_t, int32_t* fail_count, int32_t, int32_t* cnt, void* temp, size_t, void*) {
+    owned(c, ovf_pos); owned(c, ovf_count); owned(c, fail_count); owned(c, cnt); owned(c, temp);
+    return SW_OK;   // (the fake leaves every entry to the claim launch behind)
 }
 int sw_streams_run_concurrently(sw_ctx*, void*, void*) { return 1; }
 int32_t sw_window_overlap(sw_ctx*, int, int) { return -1; }   // the fake's scores are no alignment scores: never cut

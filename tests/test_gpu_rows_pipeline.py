@@ -122,4 +122,61 @@ def test_pipeline_argument_errors():
     with pytest.raises(capi.SwError):
         ctx.scan_rows_pipelined(1, 1, 1, 0, 1, 1 << 30, -11, -1, 1, 1, 0, 0, 1, 1 << 20)   # length x gex out of range
     ctx.scan_rows_pipelined(0, 0, 0, 0, 0, 100, -11, -1, 0, 0)                             # empty launch
-    assert ctx.scan_rows_pipelined_temp_bytes(2, 35213) == 2 * 69 * 11 * 8
+    assert ctx.scan_rows_pipelined_temp_bytes(2, 35213) == 2 * 35 * 11 * 8     # 10 rows: 16 columns per lane, 35 stages
+
+
+@pytest.mark.parametrize("kind", ["f32", "i32"])
+def test_pipelined_rescore_takes_the_long_entries_of_an_overflow_list(kind):
+    """sw_rescore_overflow_pipelined: the entries of a re-score list whose subject has at least min_subject_len residues are
+    scored by pipeline stages and marked taken; sw_rescore_overflow_claim behind it scores the rest.  Together: every listed
+    subject's exact score (== oracle), nobody scored twice (entries all taken afterwards), unlisted subjects untouched, the
+    reference's overflow statistic counts every listed subject at or above the packed limit exactly once."""
+    torch, capi, search = gpu_modules()
+    rng = np.random.default_rng(41)
+    ctx = capi.Context(0)
+    ctx.set_matrix(O.blosum21(62))
+    q = rng.integers(0, 20, 700).astype(np.int8)
+    seqs = [rng.integers(0, 21, int(l)).astype(np.int8) for l in rng.integers(40, 900, 60)]
+    seqs += relatives(rng, q, 8, 1300, 6000) + [rng.integers(0, 21, int(l)).astype(np.int8) for l in (2500, 4100, 7999)]
+    seqs = sorted(seqs, key=len)
+    chars, offsets, lengths = O.make_db(seqs)
+    db = search.DeviceDB.from_arrays(chars, offsets, lengths, device=0)
+    n = len(seqs)
+    ctx.set_query(q)
+    expect = O.scan(q, chars, offsets, lengths, simd=True)
+    listed = np.array(sorted(set(rng.choice(n, 30, replace=False).tolist() + list(range(n - 11, n)))), dtype=np.int32)
+    rng.shuffle(listed)
+    cap = n
+    lst = torch.full((cap,), 12345, dtype=torch.int32, device="cuda")     # entries behind the count are never read
+    lst[:len(listed)] = torch.from_numpy(listed).cuda()
+    count = torch.tensor([len(listed)], dtype=torch.int32, device="cuda")
+    scores = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+    ids = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    fails = torch.zeros(1, dtype=torch.int32, device="cuda")
+    over = torch.zeros(1, dtype=torch.int32, device="cuda")
+    maxlen = int(lengths.max())
+    tb = ctx.rescore_overflow_pipelined_temp_bytes(maxlen)
+    k = capi.KIND_F32 if kind == "f32" else capi.KIND_I32
+    tb2 = ctx.scan_temp_bytes(k, -1, cap, maxlen)
+    temp = torch.empty(max(tb, tb2, 256), dtype=torch.uint8, device="cuda")
+    limit = 2048
+    ctx.rescore_overflow_pipelined(lst.data_ptr(), count.data_ptr(), cap, db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(),
+                                   maxlen, 1300, -11, -1, scores.data_ptr(), ids.data_ptr(), 500, fails.data_ptr(), limit, over.data_ptr(),
+                                   temp.data_ptr(), temp.numel())
+    torch.cuda.synchronize()
+    after_pick = lst.cpu().numpy()[:len(listed)]
+    long_listed = lengths[listed] >= 1300
+    assert (after_pick[long_listed] == -2).all() and (after_pick[~long_listed] == listed[~long_listed]).all()
+    got = scores.cpu().numpy()
+    assert (got[listed[long_listed]] == expect[listed[long_listed]]).all() and (got[listed[~long_listed]] == -7).all()
+    ctx.rescore_overflow_claim(k, lst.data_ptr(), count.data_ptr(), cap, db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(),
+                               maxlen, -11, -1, scores.data_ptr(), ids.data_ptr(), 500, temp.data_ptr(), temp.numel(), limit, over.data_ptr())
+    torch.cuda.synchronize()
+    assert int(fails.item()) == 0
+    got, gid = scores.cpu().numpy(), ids.cpu().numpy()
+    mask = np.zeros(n, dtype=bool)
+    mask[listed] = True
+    assert (got[mask] == expect[mask]).all() and (got[~mask] == -7).all()
+    assert (gid[mask] == 500 + np.nonzero(mask)[0]).all() and (gid[~mask] == -7).all()
+    assert (lst.cpu().numpy()[:len(listed)] == -2).all()
+    assert int(over.item()) == int((expect[mask] >= limit).sum()) > 0
