@@ -318,6 +318,12 @@ struct SearchDriver::Gpu {
     } lane1;
     static constexpr int kLaneReserve = 0;
     int laneReserve = kLaneReserve;    // CUDASW4_AMD_LANE_RESERVE (A/B measurements)
+    // ... but with two queries in flight AND side work (pipelined subjects, side launches, their re-scores) a few slots are
+    // worth keeping: whatever is enqueued while the other lane's persistent grid holds every register of every SIMD — a
+    // re-score launch, the stages of the next query's long subjects, even a one-workgroup helper kernel — is dispatched
+    // only as that grid drains, and the query it belongs to completes that much later (1/4 and 1/8 Swiss-Prot-like shards:
+    // +3 ... +4 % with 32 of ~768 slots, profiles/r05_shard_proxy.txt).  CUDASW4_AMD_SIDE_RESERVE.
+    int sideReserve = 32;
     bool laneGate = true;              // CUDASW4_AMD_TAIL_GATE=0: second lane without the dry-signal gate (A/B measurements)
     static constexpr size_t kLaneMaxRounds = 20;
     static constexpr double kLaneMaxSeconds = 0.008;   // ... or scans of at most this long, at 10 TCUPS
@@ -530,6 +536,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             }
             if (const char* e = std::getenv("CUDASW4_AMD_TAIL_OVERLAP")) g->laneForce = e[0] == '1' ? 1 : 0;
             if (const char* e = std::getenv("CUDASW4_AMD_LANE_RESERVE")) g->laneReserve = std::max(0, std::atoi(e));
+            if (const char* e = std::getenv("CUDASW4_AMD_SIDE_RESERVE")) g->sideReserve = std::max(0, std::atoi(e));
             if (const char* e = std::getenv("CUDASW4_AMD_TAIL_GATE")) g->laneGate = !(e[0] == '0');
             if (const char* e = std::getenv("CUDASW4_AMD_RESCORE_SERVICE")) g->svcForce = e[0] == '1' ? 1 : 0;
         }
@@ -1371,6 +1378,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         g.svcUsed = true;
         g.serviceLaunches++;
     }
+    if (g.laneActive) SWCHECK(sw_set_grid_reserve(g.ctx, (!pipeParts.empty() || runs.size() > 1) ? std::max(g.laneReserve, g.sideReserve) : g.laneReserve));
     // the bulk launch goes in only after the side launches hold their workgroup slots
     if (anySide) HIPCHECK(hipStreamWaitValue32(work, g.startSignal, g.sideLaunches, hipStreamWaitValueGte, 0xffffffffu));
     // ... and, when the query before is still running on the other lane, only when that one's work counter has run dry
