@@ -28,7 +28,7 @@ EXPORTS = ["sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "s
            "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_grid_reserve",
            "sw_scan_rows", "sw_scan_rows_max_subject", "sw_set_long16_min", "sw_scan_rows_pipelined",
            "sw_scan_rows_pipelined_temp_bytes", "sw_probe_handshake", "sw_launch_vgpr_slot",
-           "sw_set_rows_pipeline_slot", "sw_rescore_overflow_pipelined", "sw_rescore_overflow_pipelined_temp_bytes"]
+           "sw_set_rows_pipeline_slot", "sw_rescore_overflow_pipelined", "sw_rescore_overflow_pipelined_temp_bytes", "sw_measure_valu_rate"]
 
 
 class SwError(RuntimeError):
@@ -75,6 +75,7 @@ def _load():
     L.sw_rescore_overflow_pipelined_temp_bytes.restype = sz
     L.sw_rescore_overflow_pipelined_temp_bytes.argtypes = [vp, i32]
     L.sw_rescore_overflow_pipelined.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp, i32, vp, vp, sz, vp]
+    L.sw_measure_valu_rate.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.sw_launch_vgpr_slot.argtypes = [vp, ctypes.c_int, ctypes.c_int, i32, i32]
     L.sw_set_rows_pipeline_slot.argtypes = [vp, ctypes.c_int]
     L.sw_set_dry_signal.argtypes = [vp, vp, ctypes.c_uint32]
@@ -164,6 +165,12 @@ class Context:
         """The row-parallel scan of very long subjects (sw_scan_rows): one 1024-thread workgroup per subject."""
         check(lib.sw_scan_rows(self.handle, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
                                id_offset, stream))
+
+    def measure_valu_rate(self, mix, millis=50):
+        """-> (lane-instructions per second the device issues of that instruction mix, shader clock in Hz seen by the waves)"""
+        r, hz = ctypes.c_double(), ctypes.c_double()
+        check(lib.sw_measure_valu_rate(self.handle, mix, millis, ctypes.byref(r), ctypes.byref(hz)))
+        return r.value, hz.value
 
     def launch_vgpr_slot(self, kind, part_id, n, max_subject_len):
         return int(lib.sw_launch_vgpr_slot(self.handle, kind, part_id, n, max_subject_len))

@@ -417,6 +417,37 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
 
 }  // namespace
 
+namespace {
+// Issue-rate micro-runs (tools/ubench/valu_rate.hip, mix_rate.hip in-process): `iters` iterations of 32 independent
+// instructions of the kind's inner-loop mix on every lane of 16 waves per CU; every wave also reports how many shader-clock
+// ticks (s_memtime) went by per 100 MHz tick (s_memrealtime): the clock the chip actually held during the run.
+#define SW_REP8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define SW_OP_PK_MAX3(i) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define SW_OP_ADD_F32(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define SW_OP_MAX3_F32(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define SW_OP_ADD_U32(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define SW_OP_MAX3_I32(i) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+template <int MIX>
+__global__ void __launch_bounds__(256) valu_rate_kernel(unsigned* out, unsigned long long* clocks, unsigned seed, int iters) {
+    unsigned a[8];
+    unsigned b = seed + threadIdx.x, c = seed * 3u + 1u;
+    for (int i = 0; i < 8; i++) a[i] = seed + i + threadIdx.x;
+    const unsigned long long t0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; it++) {
+        if constexpr (MIX == 0) { SW_REP8(SW_OP_PK_MAX3) SW_REP8(SW_OP_PK_MAX3) SW_REP8(SW_OP_PK_MAX3) SW_REP8(SW_OP_PK_MAX3) }
+        // fp32 kind: 4 v_add_f32 : 3.5 v_max3_f32 per cell = 16 : 14 + 2 to fill the 32
+        if constexpr (MIX == 1) { SW_REP8(SW_OP_ADD_F32) SW_REP8(SW_OP_MAX3_F32) SW_REP8(SW_OP_ADD_F32) SW_OP_MAX3_F32(0) SW_OP_MAX3_F32(1) SW_OP_MAX3_F32(2) SW_OP_MAX3_F32(3) SW_OP_MAX3_F32(4) SW_OP_MAX3_F32(5) SW_OP_ADD_F32(6) SW_OP_ADD_F32(7) }
+        // int32 kind: 2.25 v_add_u32 : 3.5 v_max3_i32 per cell ~ 12 : 20
+        if constexpr (MIX == 2) { SW_REP8(SW_OP_MAX3_I32) SW_REP8(SW_OP_ADD_U32) SW_REP8(SW_OP_MAX3_I32) SW_OP_ADD_U32(0) SW_OP_ADD_U32(1) SW_OP_ADD_U32(2) SW_OP_ADD_U32(3) SW_OP_MAX3_I32(4) SW_OP_MAX3_I32(5) SW_OP_MAX3_I32(6) SW_OP_MAX3_I32(7) }
+    }
+    const unsigned long long t1 = clock64(), w1 = wall_clock64();
+    unsigned r = 0;
+    for (int i = 0; i < 8; i++) r ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = w1 - w0; }
+}
+}  // namespace
+
 extern "C" {
 
 const char* sw_version(void) { return "cudasw4_amd 0.2 (gfx950)"; }
@@ -933,6 +964,54 @@ int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b) {
     SW_HIP(hipMemcpyAsync(&saw, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream_a)));
     SW_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream_a)));
     return saw ? 1 : 0;
+}
+
+int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_per_s, double* shader_hz) {
+    if (!ctx || mix < 0 || mix > 2) return fail(SW_ERR_INVALID, "null context or unknown instruction mix");
+    SW_HIP(hipSetDevice(ctx->device));
+    const int grid = std::max(1, ctx->num_cus) * 4;   // 16 waves per CU: four per SIMD
+    unsigned* out = nullptr;
+    unsigned long long* clocks = nullptr;
+    SW_HIP(hipMalloc(&out, (size_t)grid * 256 * sizeof(unsigned)));
+    if (hipMalloc(&clocks, (size_t)grid * 2 * sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(out); return fail(SW_ERR_HIP, "hipMalloc"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    auto run = [&](int iters, float* ms) -> hipError_t {
+        hipError_t e = hipEventRecord(e0, nullptr);
+        if (e != hipSuccess) return e;
+        if (mix == 0) hipLaunchKernelGGL(valu_rate_kernel<0>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
+        else if (mix == 1) hipLaunchKernelGGL(valu_rate_kernel<1>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
+        else hipLaunchKernelGGL(valu_rate_kernel<2>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+        return e;
+    };
+    float ms = 0.0f;
+    int iters = 4096;
+    if (err == hipSuccess) err = run(iters, &ms);          // warm-up and calibration
+    if (err == hipSuccess && ms > 0.0f) {
+        iters = (int)std::min(1.0e7, std::max(1024.0, iters * (double)std::max(millis, 1) / ms));
+        err = run(iters, &ms);
+    }
+    double hz = 0.0;
+    if (err == hipSuccess) {
+        std::vector<unsigned long long> h((size_t)grid * 2);
+        err = hipMemcpy(h.data(), clocks, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double ticks = 0.0, wall = 0.0;
+        for (int i = 0; i < grid; i++) { ticks += (double)h[2 * i]; wall += (double)h[2 * i + 1]; }
+        if (wall > 0.0) hz = ticks / wall * 100.0e6;   // s_memrealtime counts at 100 MHz
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    (void)hipFree(clocks);
+    if (err != hipSuccess) return fail(SW_ERR_HIP, std::string("sw_measure_valu_rate: ") + hipGetErrorString(err));
+    if (lane_instr_per_s) *lane_instr_per_s = ms > 0.0f ? (double)grid * 256.0 * 32.0 * (double)iters / (ms * 1e-3) : 0.0;
+    if (shader_hz) *shader_hz = hz;
+    return SW_OK;
 }
 
 int32_t sw_window_overlap(sw_ctx* ctx, int gop, int gex) {

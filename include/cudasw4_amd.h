@@ -192,6 +192,15 @@ int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b);
  * has n == 0 (nothing is enqueued, nothing will fire: do not wait for it). */
 int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
 
+/* Measurement aid for the roofline of this path (bench.py): a ~millis ms micro-run of the instruction mix
+ * that bounds a kind's inner loop on every SIMD of the device — mix 0: v_pk_maximum3_f16 (the VOP3P issue rate of the packed
+ * kinds), 1: the fp32 kind's 4 : 3.5 v_add_f32 : v_max3_f32 mix (co-issue), 2: the int32 kind's 2.25 : 3.5 v_add_u32 :
+ * v_max3_i32 mix.  *lane_instr_per_s = lane-instructions per second the device issued (waves x 64 x instructions / HIP-event
+ * time): the VALU peak a kernel of that kind is priced against, at the clock the chip actually holds under that load;
+ * *shader_hz = shader-clock ticks per second seen by the waves themselves (s_memtime against the 100 MHz s_memrealtime; 0 if
+ * the counters do not allow it).  Runs on the null stream and synchronises. */
+int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_per_s, double* shader_hz);
+
 /* The handshake in miniature, for callers that are about to rely on it: a one-thread kernel on side_stream
  * adds 1 to *signal and stays resident for at most 10 ms; gated_stream waits for that value
  * (hipStreamWaitValue32) and then runs a kernel the side kernel looks for.  1: the gated kernel started BESIDE the side
