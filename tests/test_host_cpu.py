@@ -444,9 +444,9 @@ def test_residency_plan_hybrid_and_batches():
 
 def test_residency_plan_budgets_the_scratch_of_every_stream():
     """the limit must cover the stripe-border scratch of EVERY stream that can hold one (work, second work, two
-    auxiliary streams — all live in a hybrid scan), not one buffer: cached chars + 3 staging buffers + 4 scratch buffers at
-    their cap + the per-subject arrays + the safety margin stay inside --maxGpuMem (from 4.3 GiB up, where the quarter of the
-    limit covers the 256 MiB floor per buffer)."""
+    auxiliary streams, the re-score service — kTempStreams = 5), not one buffer: cached chars + 3 staging buffers + 5 scratch
+    buffers at their cap + the per-subject arrays + the safety margin stay inside --maxGpuMem (from 5 GiB up, where the quarter
+    of the limit covers the 256 MiB floor of all five)."""
     from cudasw4_amd import driver
     n = 200000
     lengths = np.full(n, 400, dtype=np.int64)
@@ -459,7 +459,7 @@ def test_residency_plan_budgets_the_scratch_of_every_stream():
         assert r["cache_begin"] > 0 and r["batches"]
         tps = r["temp_per_stream"]
         assert tps >= min(max_temp or (4 << 30), 256 << 20) and tps <= (max_temp or (4 << 30))
-        used = meta + (256 << 20) + r["cache_bytes"] + 64 + 3 * (r["batch_bytes"] + 64) + 4 * tps
+        used = meta + (256 << 20) + r["cache_bytes"] + 64 + 3 * (r["batch_bytes"] + 64) + 5 * tps
         assert used <= limit, (limit_gb, max_temp, used - limit)
     # resident with memory to spare: every buffer may grow to --maxTempBytes
     small = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
