@@ -873,7 +873,7 @@ ResidencyPlan plan_residency(const std::vector<uint64_t>& localOffsets, int32_t 
     // workgroups a multi-stripe launch keeps in flight, sw_api.hip: scan_common).
     const size_t allTemp = memory.maxTempBytes > SIZE_MAX / size_t(kTempStreams) ? SIZE_MAX : memory.maxTempBytes * size_t(kTempStreams);
     // (kTempStreams x the 256 MiB floor below = 1.25 GiB: with that cap the floor is INSIDE the budget whenever a quarter of
-    // the limit reaches it, i.e. from a 5 GiB limit up — ADVICE r4: with a 1 GiB cap the five buffers could outgrow the
+    // the limit (behind the safety margin) reaches it, i.e. from a 5.25 GiB limit up — ADVICE r4: with a 1 GiB cap the five buffers could outgrow the
     // budget by the whole safety margin at every limit)
     const size_t fixed = std::min({allTemp, (size_t(5) << 30) / 4, limit / 4});
     const size_t avail = limit - fixed;
@@ -886,7 +886,7 @@ ResidencyPlan plan_residency(const std::vector<uint64_t>& localOffsets, int32_t 
         rp.tempPerStream = std::min(memory.maxTempBytes, std::max(spare / size_t(kTempStreams), std::min(memory.maxTempBytes, size_t(256) << 20)));
         return rp;
     }
-    // never below 256 MiB (or --maxTempBytes) per buffer: under limits below 5 GiB (a quarter of which is less than five
+    // never below 256 MiB (or --maxTempBytes) per buffer: under limits below 5.25 GiB (a quarter of which is less than five
     // such buffers) the limit may be exceeded by the difference — only when all five streams hold a multi-stripe scratch at
     // once; the buffers grow on demand — like the reference takes a limit below its safety margin as it is
     // (cudasw4.cuh:1020-1026).  The second lane's result arrays are outside this plan: prepareLane allocates them only with

@@ -445,16 +445,16 @@ def test_residency_plan_hybrid_and_batches():
 def test_residency_plan_budgets_the_scratch_of_every_stream():
     """the limit must cover the stripe-border scratch of EVERY stream that can hold one (work, second work, two
     auxiliary streams, the re-score service — kTempStreams = 5), not one buffer: cached chars + 3 staging buffers + 5 scratch
-    buffers at their cap + the per-subject arrays + the safety margin stay inside --maxGpuMem (from 5 GiB up, where the quarter
-    of the limit covers the 256 MiB floor of all five)."""
+    buffers at their cap + the per-subject arrays + the safety margin stay inside --maxGpuMem (from 5.25 GiB up, where the quarter
+    of the limit behind the safety margin covers the 256 MiB floor of all five)."""
     from cudasw4_amd import driver
     n = 200000
     lengths = np.full(n, 400, dtype=np.int64)
     off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
     off = (off * 2000).astype(np.uint64)   # 160 GB of chars: far above every limit below
     meta = 24 * n + 8
-    for limit_gb, max_temp in ((5, 0), (6, 0), (16, 0), (16, 64 << 20), (64, 0)):
-        limit = (limit_gb << 30) + meta
+    for limit_gb, max_temp in ((5.25, 0), (6, 0), (16, 0), (16, 64 << 20), (64, 0)):
+        limit = int(limit_gb * (1 << 30)) + meta
         r = driver.plan_residency(off, 800000, max_gpu_mem=limit, max_batch_bytes=128 << 20, max_temp_bytes=max_temp)
         assert r["cache_begin"] > 0 and r["batches"]
         tps = r["temp_per_stream"]
