@@ -53,7 +53,7 @@ KIND_BY_NAME = {"half2": 0, "dpxs16": 1, "dpxs32": 2, "float": 3}
 DTYPE_BY_KIND = {0: "f16x2", 1: "i16x2", 2: "i32", 3: "f32"}
 # (the sources of the kernels the PMC constants are about: sw_scan_kernel and its launcher; sw_rows_kernel.hpp — the
 # row-parallel kernel of the longest subjects — is not counted by them)
-KERNEL_SOURCES = ["cudasw4_amd/csrc/sw_dp_kernel.hpp", "cudasw4_amd/csrc/sw_launch.hpp", "cudasw4_amd/csrc/sw_api.hip",
+KERNEL_SOURCES = ["cudasw4_amd/csrc/sw_dp_kernel.hpp", "cudasw4_amd/csrc/sw_stream_kernel.hpp", "cudasw4_amd/csrc/sw_launch.hpp", "cudasw4_amd/csrc/sw_api.hip",
                   "cudasw4_amd/csrc/Makefile"]
 
 
@@ -62,14 +62,14 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["peak", "sprot-like", "uniref50-like"], default="peak")
+    ap.add_argument("--workload", choices=["peak", "sprot-like", "uniref50-like", "trembl-like"], default="peak")
     ap.add_argument("--queries", default=None, help="comma-separated indices into allqueries.fasta (default: all 20)")
     ap.add_argument("--shards-per-gpu", type=int, default=1,
                     help="in-process shards per rank, all on this rank's GPU (one worker thread, context and stream set each): the "
                          "shape of an N-GPU node on one device")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: shard ONE DB over the ranks (strong, default) or give every rank its own DB (weak)")
-    ap.add_argument("--db-size", type=int, default=None, help="subjects of the DB (peak: 1000000, sprot-like: 570000, uniref50-like: 60000000)")
+    ap.add_argument("--db-size", type=int, default=None, help="subjects of the DB (peak: 1000000, sprot-like: 570000, uniref50-like: 60000000, trembl-like: 250000000)")
     ap.add_argument("--db-length", type=int, default=512, help="peak: pseudo-DB subject length")
     ap.add_argument("--kernel", choices=sorted(KIND_BY_NAME) + ["dpx"], default=None,
                     help="kernel configuration (peak default: half2; sprot-like default: dpx = DPXs16/DPXs16/DPXs32/DPXs32)")
@@ -625,13 +625,15 @@ def measure(env, args, workload, want_cpu):
             drv.open_db(args.db_prefix, prefetch=True)
             data = "real"
             label = "DB %s" % args.db_prefix
-        elif args.workload == "uniref50-like":
-            num = args.db_size or synthdb.UNIREF50_SEQUENCES
+        elif args.workload in ("uniref50-like", "trembl-like"):
+            # trembl-like: BASELINE config 5 at its own size (runtremblbenchmark.sh:21: ~2.5e8 sequences, 9e10 residues) —
+            # the same generator, 2.5e8 sequences: 96 GB of chars, ids within 12 % of INT32_MAX
+            num = args.db_size or (synthdb.TREMBL_SEQUENCES if args.workload == "trembl-like" else synthdb.UNIREF50_SEQUENCES)
             t_gen = time.perf_counter()
             host_db = synthdb.uniref50_like(num, torch_device=torch.device("cuda", local_rank))
             drv.set_shard(rank, world, 0) if strong else drv.set_shard(0, 1, rank * num)
             drv.db_from_arrays(*host_db)
-            label = "UniRef50-sized synthetic DB (Swiss-Prot length histogram and composition, independent residues; generated and loaded in %.0f s)" % (
+            label = ("TrEMBL-sized" if args.workload == "trembl-like" else "UniRef50-sized") + " synthetic DB (Swiss-Prot length histogram and composition, independent residues; generated and loaded in %.0f s)" % (
                 time.perf_counter() - t_gen)
         else:
             num = args.db_size or synthdb.SPROT_SEQUENCES

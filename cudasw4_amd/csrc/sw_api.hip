@@ -171,6 +171,7 @@ struct sw_ctx {
     uint32_t pipe_spin_limit = 1u << 20;  // CUDASW4_AMD_PIPE_SPIN_LIMIT: polls (~2 us each) before a pipeline stage gives up waiting
     int32_t pipe_drop_stage = -1;         // CUDASW4_AMD_PIPE_TEST_DROP_STAGE (tests): this stage of every subject is lost
     int32_t pipe_cpl = 0;                 // CUDASW4_AMD_PIPE_CPL=4|8|16: columns per lane of a stage (0: by the subjects' length)
+    int32_t stream_slots = 0;             // CUDASW4_AMD_STREAM=2..4: batches whose subjects stream through the lanes back to back (sw_stream_kernel.hpp; default off: measured +1 ... +3 % on uniform DBs for single-stripe queries, -0 ... -14 % on small ragged shards, profiles/r05_stream_kernel.txt)
     int32_t pipe_slot = 0;                // sw_set_rows_pipeline_slot: VGPRs a stage occupies (128 / 168 / 256; 0: what it needs)
 };
 
@@ -388,6 +389,18 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
             default: p.renorm_word = swk::Arith<swk::F32>::encode_gap(lower); break;
         }
     }
+    if (offs && !multi && lanes == 16 && ctx->stream_slots > 1 && !positions && !list.claim && list.service_workgroups == 0) {
+        // streamed subjects (sw_stream_kernel.hpp): the zero levels a lane takes on at a slot border, a * (lanes - 4 + j)
+        p.stream_slots = ctx->stream_slots;
+        for (int j = 0; j < 16; j++) {
+            switch (kind) {
+                case SW_KIND_F16X2: p.sw_levels[j] = swk::Arith<swk::F16X2>::zero_at(a, lanes - 4 + j); break;
+                case SW_KIND_I16X2: p.sw_levels[j] = swk::Arith<swk::I16X2>::zero_at(a, lanes - 4 + j); break;
+                case SW_KIND_I32: p.sw_levels[j] = swk::Arith<swk::I32>::zero_at(a, lanes - 4 + j); break;
+                default: p.sw_levels[j] = swk::Arith<swk::F32>::zero_at(a, lanes - 4 + j); break;
+            }
+        }
+    }
     p.scores = scores; p.ids = ids; p.id_offset = id_offset;
     p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;
     p.scratch = nullptr; p.lcap = 0; p.zeros = ctx->d_zeros + kind * 16;
@@ -482,6 +495,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_PIPE_SPIN_LIMIT")) ctx->pipe_spin_limit = (uint32_t)std::max(1ll, atoll(e));
     if (const char* e = getenv("CUDASW4_AMD_PIPE_TEST_DROP_STAGE")) ctx->pipe_drop_stage = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_PIPE_CPL")) ctx->pipe_cpl = atoi(e);
+    if (const char* e = getenv("CUDASW4_AMD_STREAM")) ctx->stream_slots = std::max(0, std::min(4, atoi(e)));
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check (word 64) and the two of sw_streams_run_concurrently (72, 73)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, 2 * kWorkSlots * sizeof(uint32_t));

@@ -408,6 +408,11 @@ struct ScanParams {
     // from the start.  nullptr: none.
     u32* dry_signal;
     u32 dry_value;
+    // Streamed subjects (sw_stream_kernel.hpp): batches a workgroup may claim at once (<= 1: one batch at a time) and the
+    // zero levels a lane takes on when it switches to the next slot's subject: sw_levels[j] = the level a * (LANES - 4 + j)
+    // in the kind's encoding (Arith::zero_at)
+    int32_t stream_slots;
+    u32 sw_levels[16];
 };
 
 constexpr int32_t kListEmpty = -1, kListTaken = -2;

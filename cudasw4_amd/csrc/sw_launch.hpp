@@ -6,6 +6,7 @@
 #include <atomic>
 
 #include "sw_dp_kernel.hpp"
+#include "sw_stream_kernel.hpp"
 
 namespace swk {
 
@@ -111,6 +112,12 @@ hipError_t launch_scan_ro(bool multi, int grid, int reserve, hipStream_t stream,
                 return hipErrorInvalidValue;
             }
         } else {
+            // single-stripe queries, column-offset recurrence with windows, short groups, a plain subject range: the subjects
+            // of up to p.stream_slots batches stream through the lanes back to back (sw_stream_kernel.hpp)
+            if constexpr (OFFS && Arith<KIND>::kWindow && LANES == 16) {
+                if (p.stream_slots > 1 && !p.positions && !p.claim && !p.service && !p.count_ptr)
+                    return launch_scan_k(sw_stream_kernel<KIND, R, LANES>, grid, reserve, stream, p);
+            }
             return launch_scan_k(sw_scan_kernel<KIND, R, LANES, false, OFFS>, grid, reserve, stream, p);
         }
     }

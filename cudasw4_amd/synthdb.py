@@ -17,6 +17,7 @@ import numpy as np
 
 SPROT_SEQUENCES = 570_000      # UniProtKB/Swiss-Prot order of magnitude
 SPROT_MAX_LENGTH = 35_213      # titin
+TREMBL_SEQUENCES = 250_000_000   # UniProtKB/TrEMBL order of magnitude (runtremblbenchmark.sh: 57 GB gzipped FASTA): ~9.6e10 residues here
 UNIREF50_SEQUENCES = 60_000_000  # UniRef50 order of magnitude (rununiref50benchmark.sh: 12 GB gzipped FASTA): ~2.3e10 residues here
 
 # amino-acid composition of UniProtKB/Swiss-Prot (release statistics, per cent) in the code order of ConvertAA_20

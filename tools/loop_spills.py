@@ -10,7 +10,7 @@ import sys
 def kernels(path):
     cur, name = [], None
     for l in open(path):
-        m = re.match(r"^(_ZN3swk14sw_scan_kernel\S+):", l)
+        m = re.match(r"^(_ZN3swk1[46]sw_(?:scan|stream)_kernel\S+):", l)
         if m:
             if name:
                 yield name, cur
