@@ -71,8 +71,8 @@ void processQueryFile(const std::string& file, const ProgramOptions& o, SearchDr
     const char* pipe = std::getenv("CUDASW4_AMD_PIPELINE");
     // how many queries may be pending once a query of this length has been submitted
     auto max_in_flight = [&](size_t queryLength) {
-        const bool two = pipe ? pipe[0] == '1' : driver.prefersTwoInFlight(int32_t(std::min<size_t>(queryLength, size_t(INT32_MAX))));
-        return two ? SearchDriver::kMaxInFlight : 1;
+        if (pipe) return pipe[0] == '1' ? 2 : 1;
+        return driver.preferredInFlight(int32_t(std::min<size_t>(queryLength, size_t(INT32_MAX))));
     };
     if (!interactive) driver.totalTimerStart();
     auto finish_oldest = [&]() {

@@ -324,6 +324,12 @@ int64_t swdrv_rows_launches(swdrv* d) {
     return n;
 }
 
+int swdrv_preferred_in_flight(swdrv* d, int32_t query_length) {
+    int n = 1;
+    (void)guarded([&] { n = d->driver->preferredInFlight(query_length); });
+    return n;
+}
+
 int swdrv_handshake_active(swdrv* d) {
     int n = -1;
     (void)guarded([&] { n = d->driver->handshakeActive() ? 1 : 0; });

@@ -254,6 +254,7 @@ struct SearchDriver::Gpu {
     int rowsMode = 1;
     int64_t rowsLaunches = 0;          // side launches that ran row-parallel, since the driver was created
     double pipelineShare = kPipelineWalkShare;  // CUDASW4_AMD_PIPELINE_SHARE (A/B measurements)
+    double pipelineMinBulkSeconds = 0.002;
     double pipelineRescoreShare = kPipelineRescoreShare;  // CUDASW4_AMD_PIPELINE_RESCORE_SHARE (A/B measurements; >= 100: never)
     int64_t pipelineRescores = 0;      // re-score launches whose long subjects went ahead pipelined
     int64_t pipelineLaunches = 0;      // ... of them as pipelines of one-wave stages (sw_scan_rows_pipelined)
@@ -543,6 +544,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : 1;
         if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "single" ? 3 : 1;
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE")) g->pipelineShare = std::max(0.01, std::atof(e));
+        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_MIN_BULK_MS")) g->pipelineMinBulkSeconds = std::max(0.0, std::atof(e)) * 1e-3;
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_RESCORE_SHARE")) g->pipelineRescoreShare = std::max(0.001, std::atof(e));
         if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_WINDOWS")) g->windowsAlways = std::string(e) == "always";
@@ -998,11 +1000,12 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // subject's length, exact 32-bit scores, nothing to re-score), partition by partition (each part on an auxiliary stream).
     size_t cut = lend;
     // (CUDASW4_AMD_WINDOWS=always: the giants are wanted as windows — tests of that path)
-    const bool pipelineOk = (g.rowsMode == 1 || g.rowsMode == 2) && gop <= gex && lend > lbegin && !g.windowsAlways;
+    const bool pipelineWanted = (g.rowsMode == 1 || g.rowsMode == 2) && gop <= gex && lend > lbegin && !g.windowsAlways;
     // a wave-wide group's step of R rows per lane: ~(6.5 R + 19) instructions at ~6 cycles each beside a busy grid
     const double qrows64 = std::ceil(double(g.qlen) / 64.0);
     const double colSeconds = std::ceil(qrows64 / 8.0) * (6.5 * std::min(qrows64, 8.0) + 19.0) * 6.0 / 2.4e9;
     const double bulkSeconds = double(g.localOffsets[lend] - g.localOffsets[lbegin]) * double(g.qlen) / 10e12;
+    const bool pipelineOk = pipelineWanted;
     if (pipelineOk) {
         constexpr int kSmallLong = kNumLengthPartitions - 2;
         double maxWalk = g.pipelineShare * bulkSeconds / colSeconds;
@@ -1027,6 +1030,16 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         const size_t need = sw_scan_rows_pipelined_temp_bytes(g.ctx, int32_t(e - b), maxlen);
         if (need == 0 || need > std::min(mem.maxTempBytes, g.tempCap) || pipeParts.size() >= size_t(GpuT::kAux)) { cut = e; break; }
         pipeParts.push_back(PipePart{b, e, p, maxlen, need});
+    }
+    // ... but not hundreds of stages for a scan of a millisecond or two: each stage is a one-wave workgroup that wants a slot
+    // of its own, with two queries in flight they find slots only as the query before drains, and the bulk launch behind
+    // their handshake starts late — a stream of 48-residue queries on the whole Swiss-Prot-like DB (19 giants, 665 stages):
+    // 7 085 GCUPS against 7 759 with the windows of round 4, which cut the giants for exactly these queries; the 70 ... 190
+    // stages of a 1/8 shard are worth it at any length (9 571 against 9 070 GCUPS over the 20 queries)
+    if (g.rowsMode != 2 && bulkSeconds < g.pipelineMinBulkSeconds) {
+        size_t stages = 0;
+        for (const PipePart& pp : pipeParts) stages += (pp.end - pp.begin) * size_t((pp.maxlen + 1023) / 1024);
+        if (stages > 256) pipeParts.clear();
     }
     if (pipeParts.empty()) cut = lend;
     else cut = pipeParts.back().begin;
@@ -1591,6 +1604,14 @@ bool SearchDriver::prefersTwoInFlight(int32_t queryLength) const {
     for (auto& gp : gpus_)
         if (laneEligible(*gp, queryLength)) return true;
     return false;
+}
+
+int SearchDriver::preferredInFlight(int32_t queryLength) const {
+    // Two where the tail hand-over applies.  More than two (kMaxInFlight allows four) was measured for scans of under 2 ms
+    // and is SLOWER: a stream of 48-residue queries on the Swiss-Prot-like DB 7 672 -> 7 175 GCUPS, the 1/8 shard's 20
+    // queries 9 571 -> 9 167 — the third query's side launches and helper kernels queue up behind two persistent grids
+    // that hold every slot (profiles/r05_short_queries.txt).
+    return prefersTwoInFlight(queryLength) ? 2 : 1;
 }
 
 bool SearchDriver::prepareLane(Gpu& g, int32_t queryLength) {

@@ -184,7 +184,7 @@ public:
     // without waiting for it; collect() waits for the OLDEST submitted query and merges its results.  At most
     // kMaxInFlight queries may be pending; scan() == submit() + collect().  Results are identical either way: the
     // queries of one driver still run one after the other on each GPU.
-    static constexpr int kMaxInFlight = 2;
+    static constexpr int kMaxInFlight = 4;
     void submit(const char* query, int32_t queryLength);
     ScanResult collect();
     int inFlight() const { return int(pendingCount_); }
@@ -231,6 +231,10 @@ public:
     // GPU's shard qualifies for the tail hand-over (after setDatabase) — by its size, or because a query of queryLength
     // residues (0: not considered) is scanned in a few milliseconds
     bool prefersTwoInFlight(int32_t queryLength = 0) const;
+    // how many queries a caller with a query file should keep pending once a query of this length has been submitted: 1
+    // (one at a time, like the reference) or 2 where the tail hand-over applies (more than two in flight was measured for very
+    // short scans and is slower: search_driver.cpp)
+    int preferredInFlight(int32_t queryLength) const;
     // every score of the last scan on `gpu` (the CUDASW_DEBUG_CHECK_CORRECTNESS view, cudasw4.cuh:728-756) with
     // the global id of each position; both arrays hold numLocal(gpu) entries
     void lastScores(int gpu, float* scores, int64_t* ids);

@@ -172,6 +172,7 @@ struct sw_ctx {
     int32_t pipe_drop_stage = -1;         // CUDASW4_AMD_PIPE_TEST_DROP_STAGE (tests): this stage of every subject is lost
     int32_t pipe_cpl = 0;                 // CUDASW4_AMD_PIPE_CPL=4|8|16: columns per lane of a stage (0: by the subjects' length)
     int32_t stream_slots = 0;             // CUDASW4_AMD_STREAM=2..4: batches whose subjects stream through the lanes back to back (sw_stream_kernel.hpp; default off: measured +1 ... +3 % on uniform DBs for single-stripe queries, -0 ... -14 % on small ragged shards, profiles/r05_stream_kernel.txt)
+    int32_t pipe_quorum = 0;              // CUDASW4_AMD_PIPE_QUORUM (0: all tickets)
     int32_t pipe_slot = 0;                // sw_set_rows_pipeline_slot: VGPRs a stage occupies (128 / 168 / 256; 0: what it needs)
 };
 
@@ -495,6 +496,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_PIPE_SPIN_LIMIT")) ctx->pipe_spin_limit = (uint32_t)std::max(1ll, atoll(e));
     if (const char* e = getenv("CUDASW4_AMD_PIPE_TEST_DROP_STAGE")) ctx->pipe_drop_stage = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_PIPE_CPL")) ctx->pipe_cpl = atoi(e);
+    if (const char* e = getenv("CUDASW4_AMD_PIPE_QUORUM")) ctx->pipe_quorum = std::max(0, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_STREAM")) ctx->stream_slots = std::max(0, std::min(4, atoi(e)));
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check (word 64) and the two of sw_streams_run_concurrently (72, 73)
@@ -755,7 +757,9 @@ int launch_pipeline(sw_ctx* ctx, swk::PipelineParams& p, int cpl, int64_t stages
     p.xfer = static_cast<unsigned long long*>(xfer);
     p.ctrl = ctx->d_pipe_ctrl + 4 * (ctx->pipe_next++ % sw_ctx::kPipeCtrlSlots);
     p.start_signal = start_signal;
-    p.start_quorum = (uint32_t)tickets;   // every workgroup counts itself in, also those whose stage does not exist: all of them fit the GPU at once
+    // every workgroup counts itself in, also those whose stage does not exist: all of them fit the GPU at once
+    // (CUDASW4_AMD_PIPE_QUORUM=n: the handshake fires after the first n, for measurements)
+    p.start_quorum = (uint32_t)(ctx->pipe_quorum > 0 ? std::min<int64_t>(tickets, ctx->pipe_quorum) : tickets);
     p.max_stages = (int32_t)stages;
     p.spin_limit = ctx->pipe_spin_limit;
     p.test_drop_stage = ctx->pipe_drop_stage;

@@ -22,7 +22,7 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
            "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency", "swdrv_numa_node", "swdrv_device_of",
            "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats", "swdrv_service_launches",
-           "swdrv_tail_overlaps", "swdrv_prefers_two_in_flight", "swdrv_rows_launches", "swdrv_pipeline_launches", "swdrv_handshake_active",
+           "swdrv_tail_overlaps", "swdrv_prefers_two_in_flight", "swdrv_rows_launches", "swdrv_pipeline_launches", "swdrv_handshake_active", "swdrv_preferred_in_flight",
            "swdrv_latency_scans", "swdrv_plan_runs_mode"]
 
 
@@ -101,6 +101,8 @@ def _load():
     L.swdrv_rows_launches.argtypes = [vp]
     L.swdrv_pipeline_launches.restype = ctypes.c_int64
     L.swdrv_pipeline_launches.argtypes = [vp]
+    L.swdrv_preferred_in_flight.restype = ctypes.c_int
+    L.swdrv_preferred_in_flight.argtypes = [vp, ctypes.c_int32]
     L.swdrv_handshake_active.restype = ctypes.c_int
     L.swdrv_handshake_active.argtypes = [vp]
     L.swdrv_tail_overlaps.restype = ctypes.c_int64
@@ -440,7 +442,7 @@ class Driver:
         out = []
         for q in queries:
             self.submit(q)
-            if lib.swdrv_in_flight(self.handle) >= 2:
+            while lib.swdrv_in_flight(self.handle) >= max(2, int(lib.swdrv_preferred_in_flight(self.handle, len(q)))):
                 out.append(self.collect())
         while lib.swdrv_in_flight(self.handle) > 0:
             out.append(self.collect())
@@ -454,7 +456,7 @@ class Driver:
         out = []
         for q in queries:
             self.submit(q)
-            limit = 2 if self.prefers_two_in_flight(len(q)) else 1
+            limit = int(lib.swdrv_preferred_in_flight(self.handle, len(q)))
             while lib.swdrv_in_flight(self.handle) >= limit:
                 out.append(self.collect())
         while lib.swdrv_in_flight(self.handle) > 0:

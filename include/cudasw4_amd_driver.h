@@ -134,6 +134,9 @@ int64_t swdrv_pipeline_launches(swdrv* d);
 /* 1: the start handshake (sw_probe_handshake) holds on every GPU of the driver — side launches, re-score service and tail
  * hand-over are in use; 0: the driver fell back to plain stream order (a profiler that serialises kernels, ...) */
 int swdrv_handshake_active(swdrv* d);
+/* queries a caller with a query file should keep pending once a query of this length has been submitted: 1, or 2 where the tail
+ * hand-over applies (up to SearchDriver::kMaxInFlight = 4 may be pending; more than two was measured and is slower) */
+int swdrv_preferred_in_flight(swdrv* d, int32_t query_length);
 /* scans planned in LATENCY MODE since swdrv_create: partition 34 (1281 ... 8000 residues) on wave-wide groups beside the
  * bulk launch instead of inside it, when the whole launch is short against the walk of its longest subject on 16 lanes
  * (small shards of real DBs).  CUDASW4_AMD_LATENCY_MODE=never|always overrides the estimate. */

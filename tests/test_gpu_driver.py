@@ -347,6 +347,8 @@ def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
     chars, offsets, lengths = O.make_db(seqs)
     expect = [O.scan(O.encode(q), chars, offsets, lengths, simd=True) for q in queries]
     seen = {}
+    # (this DB's scans take well under 2 ms: without this switch the driver would not start hundreds of stages for them)
+    monkeypatch.setenv("CUDASW4_AMD_PIPELINE_MIN_BULK_MS", "0")
     for rows in ("never", "always", "single", None):
         for lat in ("never", "always", None):
             if rows == "single" and lat is not None:
