@@ -1037,9 +1037,13 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // 7 085 GCUPS against 7 759 with the windows of round 4, which cut the giants for exactly these queries; the 70 ... 190
     // stages of a 1/8 shard are worth it at any length (9 571 against 9 070 GCUPS over the 20 queries)
     if (g.rowsMode != 2 && bulkSeconds < g.pipelineMinBulkSeconds) {
-        size_t stages = 0;
-        for (const PipePart& pp : pipeParts) stages += (pp.end - pp.begin) * size_t((pp.maxlen + 1023) / 1024);
-        if (stages > 256) pipeParts.clear();
+        size_t stages = 0, keep = 0;   // the parts from the longest partition down while they stay below 256 stages
+        for (const PipePart& pp : pipeParts) {
+            stages += (pp.end - pp.begin) * size_t((pp.maxlen + 1023) / 1024);
+            if (stages > 256) break;
+            keep++;
+        }
+        pipeParts.resize(keep);
     }
     if (pipeParts.empty()) cut = lend;
     else cut = pipeParts.back().begin;

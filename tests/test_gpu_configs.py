@@ -263,6 +263,20 @@ def test_bench_sprot_like_workload_small():
     assert out["roofline"]["achieved"] > 0 and out["value"] > 0
 
 
+def test_bench_trembl_like_reduced_leg():
+    """BASELINE config 5's shape at a tenth of a tenth of TrEMBL (10^7 sequences, 3.8e9 residues generated on the device;
+    the full 2.5e8-sequence legs are in profiles/r05_scale/): the int32 configuration under a memory limit far below the DB
+    — hybrid residency, most of the chars streamed on every query — two queries, every sampled score equal to the CPU
+    oracle, top-10 equal to the top of all 10^7 scores, the H2D counter at the streamed part's size."""
+    out = run_bench(["--workload", "trembl-like", "--db-size", "10000000", "--kernel", "dpxs32", "--queries", "0,9", "--steps", "1",
+                     "--warmup", "0", "--max-gpu-mem", "2G", "--no-secondary", "--no-sweep", "--cpu-sample-subjects", "600"])
+    c = out["config"]
+    assert out["verified"] is True and c["db_subjects"] == 10_000_000 and c["residency"] == "hybrid"
+    assert 0 < c["cached_chars"] < c["shard_chars"]
+    assert abs(c["h2d_subject_bytes_per_step"] - 2 * (c["shard_chars"] - c["cached_chars"])) <= 0.03 * c["shard_chars"]   # (+ the next scan's first batch, staged ahead)
+    assert out["cpu_baseline"]["value"] > 0 and out["value"] > 1000
+
+
 def test_bench_real_db_switch(tmp_path):
     """`bench.py --db-prefix P` / $CUDASW4_SPROT_PREFIX (runsprotbenchmark.sh:18-51): the sprot-like leg runs on a real
     DB made by `makedb` — here a 50 000-sequence FASTA — instead of the synthetic stand-in, says so in `data`, and

@@ -201,17 +201,18 @@ def test_submit_collect_pipeline_equals_scan(devices, kw):
         assert piped[qi]["scores"].tolist() == es.tolist() and piped[qi]["ids"].tolist() == ei.tolist()
     with pytest.raises(driver.DriverError):
         d.collect()                       # nothing submitted
-    d.submit(letters[0])
-    d.submit(letters[1])
+    for qi in range(4):                   # SearchDriver::kMaxInFlight = 4 (round 5) may be pending
+        d.submit(letters[qi])
     with pytest.raises(driver.DriverError):
-        d.submit(letters[2])              # a third query in flight
+        d.submit(letters[4])              # a fifth query in flight
     with pytest.raises(driver.DriverError):
-        d.scan(letters[2])                # scan() while queries are pending
-    a, b = d.collect(), d.collect()
-    assert a["scores"].tolist() == one_by_one[0]["scores"].tolist() and b["scores"].tolist() == one_by_one[1]["scores"].tolist()
+        d.scan(letters[4])                # scan() while queries are pending
+    got = [d.collect() for _ in range(4)]
+    for qi in range(4):
+        assert got[qi]["scores"].tolist() == one_by_one[qi]["scores"].tolist() and got[qi]["ids"].tolist() == one_by_one[qi]["ids"].tolist()
     # the last scan's scores are those of the query collected last
     ids, sc = d.all_scores()
-    expect = O.scan(O.encode(letters[1]), chars, offsets, lengths, simd=True)
+    expect = O.scan(O.encode(letters[3]), chars, offsets, lengths, simd=True)
     assert (sc[np.argsort(ids)] == expect).all()
     d.close()
 
