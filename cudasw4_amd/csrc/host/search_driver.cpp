@@ -254,7 +254,7 @@ struct SearchDriver::Gpu {
     int rowsMode = 1;
     int64_t rowsLaunches = 0;          // side launches that ran row-parallel, since the driver was created
     double pipelineShare = kPipelineWalkShare;  // CUDASW4_AMD_PIPELINE_SHARE (A/B measurements)
-    double pipelineMinBulkSeconds = 0.002;
+    double pipelineMinBulkSeconds = 0.0;
     double pipelineRescoreShare = kPipelineRescoreShare;  // CUDASW4_AMD_PIPELINE_RESCORE_SHARE (A/B measurements; >= 100: never)
     int64_t pipelineRescores = 0;      // re-score launches whose long subjects went ahead pipelined
     int64_t pipelineLaunches = 0;      // ... of them as pipelines of one-wave stages (sw_scan_rows_pipelined)
@@ -1031,11 +1031,11 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         if (need == 0 || need > std::min(mem.maxTempBytes, g.tempCap) || pipeParts.size() >= size_t(GpuT::kAux)) { cut = e; break; }
         pipeParts.push_back(PipePart{b, e, p, maxlen, need});
     }
-    // ... but not hundreds of stages for a scan of a millisecond or two: each stage is a one-wave workgroup that wants a slot
-    // of its own, with two queries in flight they find slots only as the query before drains, and the bulk launch behind
-    // their handshake starts late — a stream of 48-residue queries on the whole Swiss-Prot-like DB (19 giants, 665 stages):
-    // 7 085 GCUPS against 7 759 with the windows of round 4, which cut the giants for exactly these queries; the 70 ... 190
-    // stages of a 1/8 shard are worth it at any length (9 571 against 9 070 GCUPS over the 20 queries)
+    // (CUDASW4_AMD_PIPELINE_MIN_BULK_MS, default 0 = off: scans estimated shorter than this keep at most 256 stages.  Built
+    // when a stream of 48-residue queries on the whole Swiss-Prot-like DB — 19 giants, 665 stages — ran 9 % slower with the
+    // pipelines than with the windows of round 4; the cause turned out to be four queries in flight instead of two, and
+    // with two the rule only costs: 1/8 shard 9 629 GCUPS without it, 9 449 / 9 299 / 9 359 at 0.6 / 1.2 / 2 ms, the 48-residue
+    // stream 8 161 against 8 153 ... 8 302, profiles/r05_short_queries.txt)
     if (g.rowsMode != 2 && bulkSeconds < g.pipelineMinBulkSeconds) {
         size_t stages = 0, keep = 0;   // the parts from the longest partition down while they stay below 256 stages
         for (const PipePart& pp : pipeParts) {
