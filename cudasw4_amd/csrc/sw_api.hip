@@ -1261,6 +1261,7 @@ struct TopkState {
     unsigned long long remaining;   // how many elements are still to be taken from the current bucket
     unsigned int skip_rest;         // the whole current bucket is taken: no further passes needed
     unsigned int out_count;         // compaction cursor
+    unsigned int blocks_done;       // workgroups of the current histogram pass that have added their part (the last one picks)
     unsigned int hist[kSelBins];
 };
 
@@ -1272,33 +1273,14 @@ __device__ __forceinline__ unsigned long long topk_key(float score, unsigned int
 
 __global__ void topk_init_kernel(TopkState* st, int k) {
     for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) st->hist[i] = 0;
-    if (threadIdx.x == 0) { st->prefix = 0; st->decided = 0; st->remaining = (unsigned long long)k; st->skip_rest = 0; st->out_count = 0; }
+    if (threadIdx.x == 0) { st->prefix = 0; st->decided = 0; st->remaining = (unsigned long long)k; st->skip_rest = 0; st->out_count = 0; st->blocks_done = 0; }
 }
 
-__global__ void __launch_bounds__(256) topk_hist_kernel(const float* __restrict__ scores, int64_t n, TopkState* st, int pass) {
-    if (st->skip_rest) return;
-    __shared__ unsigned int h[kSelBins];
-    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) h[i] = 0;
-    __syncthreads();
-    const unsigned long long prefix = st->prefix, decided = st->decided;
-    const int shift = kSelShift[pass];
-    const unsigned int mask = (1u << kSelBits[pass]) - 1u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long key = topk_key(scores[i], (unsigned int)i);
-        if ((key & decided) == prefix) atomicAdd(&h[(unsigned int)(key >> shift) & mask], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x)
-        if (h[i]) atomicAdd(&st->hist[i], h[i]);
-}
-
-// one workgroup: walk the histogram from the top bin down to the bin that holds the `remaining`-th element
-__global__ void __launch_bounds__(256) topk_pick_kernel(TopkState* st, int pass) {
-    if (st->skip_rest) return;
-    __shared__ unsigned int h[kSelBins];
-    __shared__ unsigned long long part[256];
+// walk the histogram from the top bin down to the bin that holds the `remaining`-th element (one workgroup of 256 threads;
+// h: kSelBins words, part: 256 double words of LDS)
+__device__ void topk_pick(TopkState* st, int pass, unsigned int* h, unsigned long long* part) {
     const int nb = 1 << kSelBits[pass];
-    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) { h[i] = i < nb ? st->hist[i] : 0u; }
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) { h[i] = i < nb ? __hip_atomic_load(&st->hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; }
     __syncthreads();
     // thread t owns bins [nb - 8(t+1), nb - 8t) (descending): sum, then a serial scan over 256 partial sums by thread 0
     constexpr int per = kSelBins / 256;
@@ -1323,6 +1305,35 @@ __global__ void __launch_bounds__(256) topk_pick_kernel(TopkState* st, int pass)
     for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) st->hist[i] = 0;
 }
 
+__global__ void __launch_bounds__(256) topk_hist_kernel(const float* __restrict__ scores, int64_t n, TopkState* st, int pass) {
+    if (st->skip_rest) return;
+    __shared__ unsigned int h[kSelBins];
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const unsigned long long prefix = st->prefix, decided = st->decided;
+    const int shift = kSelShift[pass];
+    const unsigned int mask = (1u << kSelBits[pass]) - 1u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = topk_key(scores[i], (unsigned int)i);
+        if ((key & decided) == prefix) atomicAdd(&h[(unsigned int)(key >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x)
+        if (h[i]) atomicAdd(&st->hist[i], h[i]);
+    // the workgroup that adds its part last picks the bin (round 5: was a launch of its own after every pass — twelve small
+    // launches per top-K instead of six weigh on a query that is scanned in a millisecond)
+    __shared__ unsigned long long part[256];
+    __shared__ bool last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&st->blocks_done, 1u) + 1u == gridDim.x;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    topk_pick(st, pass, h, part);
+    if (threadIdx.x == 0) st->blocks_done = 0;
+}
+
 // winners: keys above the decided prefix, or inside it (all of them when skip_rest, else the prefix is a full key)
 __global__ void __launch_bounds__(256) topk_compact_kernel(const float* __restrict__ scores, const int32_t* __restrict__ ids, int64_t n,
                                                            TopkState* st, int k, unsigned long long* out_keys, int32_t* out_ids) {
@@ -1343,6 +1354,23 @@ __global__ void topk_emit_kernel(const unsigned long long* keys, const int32_t* 
         u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
         out_s[i] = __uint_as_float(u);
         out_i[i] = vals[i];
+    }
+}
+
+// the k winners in descending key order (keys are unique): every element's rank is the number of larger keys — one
+// workgroup, k <= 1024 (hipCUB's radix sort of ten 64-bit keys took 15 ... 90 us)
+__global__ void __launch_bounds__(256) topk_rank_emit_kernel(const unsigned long long* keys, const int32_t* vals, int k, float* out_s, int32_t* out_i) {
+    __shared__ unsigned long long sk[1024];
+    for (int i = threadIdx.x; i < k; i += blockDim.x) sk[i] = keys[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const unsigned long long mine = sk[i];
+        int rank = 0;
+        for (int j = 0; j < k; j++) rank += sk[j] > mine ? 1 : 0;
+        unsigned int u = (unsigned int)(mine >> 32);
+        u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+        out_s[rank] = __uint_as_float(u);
+        out_i[rank] = vals[i];
     }
 }
 
@@ -1404,13 +1432,16 @@ int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int
         hipLaunchKernelGGL(topk_init_kernel, dim3(1), dim3(256), 0, s, st, k);
         for (int pass = 0; pass < kSelPasses; pass++) {
             hipLaunchKernelGGL(topk_hist_kernel, dim3(grid), dim3(256), 0, s, scores, n, st, pass);
-            hipLaunchKernelGGL(topk_pick_kernel, dim3(1), dim3(256), 0, s, st, pass);
         }
         hipLaunchKernelGGL(topk_compact_kernel, dim3(grid), dim3(256), 0, s, scores, ids, n, st, k, keys_a, vals_a);
         SW_HIP(hipGetLastError());
-        size_t cub = L.cub_bytes;
-        SW_HIP(hipcub::DeviceRadixSort::SortPairsDescending(base + L.cub_off, cub, keys_a, keys_b, vals_a, vals_b, k, 0, 64, s));
-        hipLaunchKernelGGL(topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, s, keys_b, vals_b, k, out_scores, out_ids);
+        if (k <= 1024) {
+            hipLaunchKernelGGL(topk_rank_emit_kernel, dim3(1), dim3(256), 0, s, keys_a, vals_a, k, out_scores, out_ids);
+        } else {
+            size_t cub = L.cub_bytes;
+            SW_HIP(hipcub::DeviceRadixSort::SortPairsDescending(base + L.cub_off, cub, keys_a, keys_b, vals_a, vals_b, k, 0, 64, s));
+            hipLaunchKernelGGL(topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, s, keys_b, vals_b, k, out_scores, out_ids);
+        }
         SW_HIP(hipGetLastError());
         return SW_OK;
     }
