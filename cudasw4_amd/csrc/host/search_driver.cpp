@@ -246,7 +246,12 @@ struct SearchDriver::Gpu {
     static constexpr int kWindowBufs = 4;  // per auxiliary stream: two queries in flight, two side launches each at most
     WindowBuf winBuf[kAux][kWindowBufs];
     int winNext[kAux] = {0, 0};
-    int latencyMode = 1;               // CUDASW4_AMD_LATENCY_MODE=never|always (0 / 2): partition 34 on wave-wide groups beside the bulk launch never / always
+    // CUDASW4_AMD_LATENCY_MODE=never|auto|always (0 / 1 / 2): partition 34 on wave-wide groups beside the bulk launch never / by
+    // the estimate of round 4 / always.  Round 5: never by default — the walk-time cut (kPipelineWalkShare) takes the subjects
+    // whose walk matters out of the scan launches, and what is left of partition 34 runs 40 % faster inside the bulk grid's
+    // 16-lane groups than on wave-wide ones (share 0.3: 1/4 shard 10 933 -> 10 959, 1/8 shard 9 168 -> 9 698 GCUPS,
+    // profiles/r05_shard_proxy.txt)
+    int latencyMode = 0;
     int64_t latencyScans = 0;          // scans (batches) planned in latency mode, since the driver was created
     // CUDASW4_AMD_ROWS=never|always|single (0 / 2 / 3): the row-parallel kernels for partition 35 never / whatever the time
     // estimate says / only the one-workgroup form of round 4 (sw_scan_rows), by its time estimate.  Default (1): the
@@ -541,7 +546,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
             if (const char* e = std::getenv("CUDASW4_AMD_TAIL_GATE")) g->laneGate = !(e[0] == '0');
             if (const char* e = std::getenv("CUDASW4_AMD_RESCORE_SERVICE")) g->svcForce = e[0] == '1' ? 1 : 0;
         }
-        if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : 1;
+        if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "auto" ? 1 : 0;
         if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "single" ? 3 : 1;
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE")) g->pipelineShare = std::max(0.01, std::atof(e));
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_MIN_BULK_MS")) g->pipelineMinBulkSeconds = std::max(0.0, std::atof(e)) * 1e-3;

@@ -75,7 +75,7 @@ constexpr size_t kLongPartitionMergeMin = 512;
 // would take more than kPipelineWalkShare of the bulk launch's estimated time — but at most this many (a handful of long
 // subjects is a latency problem, thousands of them are throughput: the scan kernels)
 constexpr int32_t kPipelineMaxSubjects = 256;
-constexpr double kPipelineWalkShare = 0.5;
+constexpr double kPipelineWalkShare = 0.3;
 // ... and the flagged subjects of an overflow list whose 32-bit re-score walk would take more than this share of it
 constexpr double kPipelineRescoreShare = 0.1;
 

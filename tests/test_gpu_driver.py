@@ -350,7 +350,7 @@ def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
     # (this DB's scans take well under 2 ms: without this switch the driver would not start hundreds of stages for them)
     monkeypatch.setenv("CUDASW4_AMD_PIPELINE_MIN_BULK_MS", "0")
     for rows in ("never", "always", "single", None):
-        for lat in ("never", "always", None):
+        for lat in ("never", "always", "auto", None):
             if rows == "single" and lat is not None:
                 continue
             for name, val in (("CUDASW4_AMD_ROWS", rows), ("CUDASW4_AMD_LATENCY_MODE", lat)):
