@@ -436,7 +436,13 @@ def roofline_objects(args, workload, kernel_name, events, info, cal=None, sclk=N
     valu.update({"cus": cus, "lanes_per_clk_per_cu": round(lanes_per_clk, 2), "nominal_clock_ghz": 2.4,
                  "peak_measured": round(peak_measured / 1e12, 3) if peak_measured else None,
                  "peak_at_observed_clock": round(peak_at_clock / 1e12, 3) if peak_at_clock else None,
-                 "observed_sclk": sclk, "calibration": cal})
+                 "observed_sclk": sclk, "calibration": cal,
+                 "peak_measured_note": "lane-instructions per second of a 50 ms in-process micro-run of the kind's bounding mix on THIS "
+                                       "device (packed kinds: a pure v_pk_maximum3_f16 stream, 57.9 lanes/clk/CU at 2.4 GHz on this chip at the "
+                                       "2.33-2.38 GHz that load lets it hold).  It is a floor of the ceiling, not the ceiling: the kernels' own "
+                                       "mix holds ~10 % VOP1/VOP2/DPP instructions, which issue at up to 100 lanes/clk/CU, so "
+                                       "frac_of_measured_peak can exceed 1; `frac` prices the same achieved rate against 64 lanes/clk/CU "
+                                       "x CUs x the nominal 2.4 GHz, frac_at_observed_clock against the clock sampled during the timed region"})
     if ipu:
         ach = kern_gcups * 1e9 / (2 if packed else 1) * ipu["value"]
         valu.update({"frac_of_measured_peak": round(ach / peak_measured, 4) if peak_measured else None,
