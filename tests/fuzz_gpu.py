@@ -92,13 +92,68 @@ def main(argv=None):
         expect = O.scan(q, chars, offsets, lens, m21=mo, gop=gop, gex=gex)
         kinds = kind_cfgs[int(r.integers(0, len(kind_cfgs)))]
         host = "capi" if (full25 or which != 62 or (gop, gex) != (-11, -1) or r.integers(0, 2)) else "driver"
+        # round 5: the pipelined entry points straight through the C ABI — every subject of the case as a pipeline of one-wave
+        # stages (any length: short ones are one stage), and a re-score list split between the pipelined and the claim launch
+        if host == "capi" and gop <= gex and r.integers(0, 4) == 0:
+            host = "pipe"
         desc = "case %d seed %d host %s n %d lens %d..%d qlen %d kinds %s mat %d%s gap %d/%d" % (
             case, seed, host, n, int(lengths[0]), int(lengths[-1]), qlen, kinds, which, "_25" if full25 else "", gop, gex)
-        if host == "capi":
+        if host == "pipe":
+            import torch
+            cpl = int(r.choice([0, 4, 8, 16]))
+            os.environ.pop("CUDASW4_AMD_PIPE_CPL", None)
+            if cpl:
+                os.environ["CUDASW4_AMD_PIPE_CPL"] = str(cpl)
+            ctx = capi.Context(0)
+            ctx.set_matrix(m)
+            ctx.set_query(q)
+            ddb = search.DeviceDB.from_arrays(chars, offsets, lens, device=0)
+            maxlen = int(lens.max())
+            tb = ctx.scan_rows_pipelined_temp_bytes(n, maxlen)
+            if tb > (3 << 30):
+                print("skip " + desc + " (pipelined: hand-off array of %d MB)" % (tb >> 20), flush=True)
+                continue
+            slot = int(r.choice([0, 128, 168, 256]))
+            ctx.set_rows_pipeline_slot(slot)
+            dsc = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+            did = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+            fails = torch.zeros(1, dtype=torch.int32, device="cuda")
+            over = torch.zeros(2, dtype=torch.int32, device="cuda")
+            limit = int(r.choice([60, 2048]))
+            mode = int(r.integers(0, 2))
+            if mode == 0:   # the whole range pipelined
+                temp = torch.empty(max(tb, 256), dtype=torch.uint8, device="cuda")
+                ctx.scan_rows_pipelined(ddb.chars.data_ptr(), ddb.offsets.data_ptr(), ddb.lengths.data_ptr(), 0, n, maxlen, gop, gex,
+                                        dsc.data_ptr(), did.data_ptr(), 0, fails.data_ptr(), temp.data_ptr(), tb, 0,
+                                        over.data_ptr(), over.data_ptr() + 4, limit)
+            else:           # a re-score list of every subject: the long entries pipelined, the rest by the claim launch
+                lst = torch.from_numpy(r.permutation(n).astype(np.int32)).cuda()
+                cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+                minlen = int(r.choice([1, 64, 300, 1500]))
+                tb1 = ctx.rescore_overflow_pipelined_temp_bytes(maxlen)
+                kk = capi.KIND_F32 if r.integers(0, 2) else capi.KIND_I32
+                tb2 = ctx.scan_temp_bytes(kk, -1, n, maxlen)
+                temp = torch.empty(max(tb1, tb2, 256), dtype=torch.uint8, device="cuda")
+                ctx.rescore_overflow_pipelined(lst.data_ptr(), cnt.data_ptr(), n, ddb.chars.data_ptr(), ddb.offsets.data_ptr(), ddb.lengths.data_ptr(),
+                                               maxlen, minlen, gop, gex, dsc.data_ptr(), did.data_ptr(), 0, fails.data_ptr(), limit,
+                                               over.data_ptr(), temp.data_ptr(), temp.numel())
+                ctx.rescore_overflow_claim(kk, lst.data_ptr(), cnt.data_ptr(), n, ddb.chars.data_ptr(), ddb.offsets.data_ptr(), ddb.lengths.data_ptr(),
+                                           maxlen, gop, gex, dsc.data_ptr(), did.data_ptr(), 0, temp.data_ptr(), temp.numel(), limit, over.data_ptr())
+            torch.cuda.synchronize()
+            got = dsc.cpu().numpy().astype(np.int64)
+            desc += " cpl %d slot %d %s" % (cpl, slot, "range" if mode == 0 else "list")
+            want_over = int((expect >= limit).sum())
+            if int(fails.item()) != 0 or int(over[0].item()) != want_over or (did.cpu().numpy() != np.arange(n)).any():
+                print("FAIL pipelined bookkeeping", int(fails.item()), over.cpu().numpy(), want_over, desc)
+                sys.exit(1)
+            top = tuple(x.tolist() for x in O.topk(expect, min(10, n)))   # (no top-K in this case: the scores are what is checked)
+            ctx.close()
+        elif host == "capi":
             kt = K(*kinds)
             os.environ["CUDASW4_AMD_I32_NATIVE"] = str(int(r.integers(0, 2)))
             os.environ["CUDASW4_AMD_LANES8_MAX_Q"] = str(int(r.choice([-1, -1, 0, 100000])))
             os.environ["CUDASW4_AMD_LANES8_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 0, 100000])))
+            os.environ["CUDASW4_AMD_STREAM"] = str(int(r.choice([0, 0, 2, 4])))
             s = search.Searcher(device=0, num_top=min(10, n), matrix=m, kernel_types=kt, gop=gop, gex=gex,
                                 merge_partitions=bool(r.integers(0, 2)))
             s.set_database(search.DeviceDB.from_arrays(chars, offsets, lens, device=0))
@@ -138,6 +193,17 @@ def main(argv=None):
             os.environ.pop("CUDASW4_AMD_TAIL_OVERLAP", None)
             if r.integers(0, 4) == 0:
                 os.environ["CUDASW4_AMD_TAIL_OVERLAP"] = "0"
+            # round 5: which subjects run pipelined (never / every long one / by the estimate with an extreme share), the span
+            # width, the pipelined re-score, round 4's latency mode, the streamed-subjects kernel
+            r5 = {"CUDASW4_AMD_ROWS": r.choice(["", "never", "always", "single"]), "CUDASW4_AMD_PIPELINE_SHARE": r.choice(["", "0.02", "5"]),
+                  "CUDASW4_AMD_PIPELINE_RESCORE_SHARE": r.choice(["", "0.001", "1000"]), "CUDASW4_AMD_PIPE_CPL": r.choice(["", "4", "8", "16"]),
+                  "CUDASW4_AMD_LATENCY_MODE": r.choice(["", "auto", "always"]), "CUDASW4_AMD_STREAM": r.choice(["", "2", "4"]),
+                  "CUDASW4_AMD_SIDE_RESERVE": r.choice(["", "0", "64"])}
+            for k5, v5 in r5.items():
+                os.environ.pop(k5, None)
+                if v5:
+                    os.environ[k5] = str(v5)
+            mode += " r5=" + ",".join("%s=%s" % (k5.replace("CUDASW4_AMD_", ""), v5) for k5, v5 in r5.items() if v5)
             d = driver.Driver(devices=devs, num_top=min(10, n), kinds=kinds, **kw)
             d.db_from_arrays(chars, offsets, lens)
             if r.integers(0, 3) == 0:
