@@ -687,12 +687,16 @@ int rows_common_checks(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets
 
 // Columns per lane of a pipeline stage.  Narrow spans finish a row sooner, wide ones keep the number of stages — and of
 // hand-offs the first row passes through before the last stage starts — down.  Measured on MI355X (tools/giants_bench.py,
-// profiles/r05_giants_bench.txt): a row takes 0.26 / 0.33 / 0.50 us at 4 / 8 / 16 columns per lane, a hand-off 3.6 / 5.0 / 8 us
+// profiles/r05_giants_bench.txt): a row takes 0.27 / 0.38 / 0.57 us at 4 / 8 / 16 columns per lane, a hand-off 3.6 / 5.0 / 8 us
 // (the consumer starts a batch of rows when the producer has finished it), so the launch takes about
 // qlen * row + stages * hand-off: the width that minimises that for the current query and the longest subject.
 int pipeline_cpl(const sw_ctx* ctx, int32_t n, int32_t max_subject_len) {
     if (ctx->pipe_cpl == 4 || ctx->pipe_cpl == 8 || ctx->pipe_cpl == 16) return ctx->pipe_cpl;
-    static const double kRowUs[3] = {0.26, 0.33, 0.50}, kHopUs[3] = {3.6, 5.0, 8.0};
+    // (sw_rows_pipeline.hpp: batches of 8 rows for queries up to kPipeShortBatchMaxQuery, of 16 above)
+    static const double kRowUs16[3] = {0.27, 0.38, 0.57}, kHopUs16[3] = {3.6, 5.0, 8.0}, kRowUs8[3] = {0.32, 0.42, 0.61}, kHopUs8[3] = {2.4, 3.4, 5.3};
+    const bool shortBatch = ctx->qlen <= swk::kPipeShortBatchMaxQuery;
+    const double* kRowUs = shortBatch ? kRowUs8 : kRowUs16;
+    const double* kHopUs = shortBatch ? kHopUs8 : kHopUs16;
     int best = 16;
     double bestT = 1e300;
     for (int k = 0; k < 3; k++) {
@@ -767,16 +771,22 @@ int launch_pipeline(sw_ctx* ctx, swk::PipelineParams& p, int cpl, int64_t stages
     SW_HIP(hipMemsetAsync(xfer, 0xFF, need, stream));   // "not written yet"
     const dim3 grid((unsigned)tickets), block(64);
     const int slot = ctx->pipe_slot;
+#define SW_PIPE_LAUNCH_B(CPL, B)                                                                                            \
+    do {                                                                                                                    \
+        if (slot == 128) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 128, B>), grid, block, 0, stream, p);        \
+        else if (slot == 168) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 168, B>), grid, block, 0, stream, p);   \
+        else if (slot == 256) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 256, B>), grid, block, 0, stream, p);   \
+        else hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 0, B>), grid, block, 0, stream, p);                      \
+    } while (0)
 #define SW_PIPE_LAUNCH(CPL)                                                                                              \
     do {                                                                                                                 \
-        if (slot == 128) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 128>), grid, block, 0, stream, p);        \
-        else if (slot == 168) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 168>), grid, block, 0, stream, p);   \
-        else if (slot == 256) hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 256>), grid, block, 0, stream, p);   \
-        else hipLaunchKernelGGL((swk::sw_rows_pipeline_kernel<CPL, 0>), grid, block, 0, stream, p);                      \
+        if (ctx->qlen <= swk::kPipeShortBatchMaxQuery) SW_PIPE_LAUNCH_B(CPL, 8);                                         \
+        else SW_PIPE_LAUNCH_B(CPL, 16);                                                                                  \
     } while (0)
     if (cpl == 4) SW_PIPE_LAUNCH(4);
     else if (cpl == 8) SW_PIPE_LAUNCH(8);
     else SW_PIPE_LAUNCH(16);
+#undef SW_PIPE_LAUNCH_B
 #undef SW_PIPE_LAUNCH
     SW_HIP(hipGetLastError());
     return SW_OK;

@@ -76,7 +76,12 @@ struct PipelineParams {
     int32_t test_drop_stage;   // >= 0 (tests of the failure path): this stage of every subject leaves without producing
 };
 
-constexpr int kPipeBatch = 16;                       // rows whose hand-off words a stage fetches at once
+// Rows whose hand-off words a stage fetches at once (BATCH) and how many batches ahead it requests them.  A stage starts a
+// batch when its neighbour has finished it, so the first row reaches the last stage after stages x (BATCH rows + latency):
+// 8 rows two batches ahead make a hand-off 2.4 / 3.4 / 5.3 us at 4 / 8 / 16 columns per lane instead of 3.6 / 5.0 / 8 us with
+// 16 rows one batch ahead, for 10-15 % more time per row (0.32 / 0.42 / 0.61 against 0.27 / 0.38 / 0.57 us): short batches for
+// queries up to kPipeShortBatchMaxQuery rows (35 213 x 567: 0.60 -> 0.46 ms, x 144: 0.39 -> 0.26 ms, x 5 478: 1.98 -> 2.10).
+constexpr int kPipeShortBatchMaxQuery = 2048;
 constexpr unsigned long long kPipeEmpty = ~0ull;
 constexpr float kPipeFailedScore = -2.0f;
 
@@ -92,8 +97,9 @@ __device__ __forceinline__ unsigned long long pipe_pack(int lo, int hi) {
 
 constexpr int kPipeTableRows = 26;   // query letters (<= 25) + the padding row
 
-template <int CPL, int SLOT>
+template <int CPL, int SLOT, int BATCH>
 __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelineParams p) {
+    constexpr int kPipeBatch = BATCH, kPipeDepth = BATCH <= 8 ? 2 : 1;
     // the wave's register allocation is what the highest register it names says: claim the whole slot
     if constexpr (SLOT == 128) asm volatile("v_mov_b32 v127, 0" ::: "v127");
     if constexpr (SLOT == 168) asm volatile("v_mov_b32 v167, 0" ::: "v167");
@@ -177,15 +183,18 @@ __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelinePara
 
     // the first stage has nothing to its left: "no prefix yet" and H(., -1) = 0 in every row
     const unsigned long long kNoLeft = pipe_pack(kRowsNeg, 0);
-    unsigned long long nxt = kNoLeft;
-    if (stage > 0) nxt = pipe_load(xin + min(sl, p.qlen));
+    unsigned long long pend[kPipeDepth];
+#pragma unroll
+    for (int d = 0; d < kPipeDepth; d++) pend[d] = stage > 0 ? pipe_load(xin + min(d * kPipeBatch + sl, p.qlen)) : kNoLeft;
     for (int i0 = 0; i0 < p.qlen; i0 += kPipeBatch) {
         const int nrows = __builtin_amdgcn_readfirstlane(min(kPipeBatch, p.qlen - i0));
-        unsigned long long cur = nxt;
+        unsigned long long cur = pend[0];
         if (stage > 0) {
             cur = await(cur, (size_t)min(i0 + sl, p.qlen), sl < nrows);
             if (failed) break;
-            nxt = pipe_load(xin + min(i0 + kPipeBatch + sl, p.qlen));   // the batch after this one, a batch ahead
+#pragma unroll
+            for (int d = 0; d + 1 < kPipeDepth; d++) pend[d] = pend[d + 1];
+            pend[kPipeDepth - 1] = pipe_load(xin + min(i0 + kPipeDepth * kPipeBatch + sl, p.qlen));   // kPipeDepth batches ahead
         }
         const int curLo = (int)(uint32_t)cur, curHi = (int)(uint32_t)(cur >> 32);
         // lane r holds query letter i0 + r (letters behind the query's end are never used)
