@@ -53,6 +53,7 @@ def main(argv=None):
     ap.add_argument("--driver-bias", type=float, default=0.0, help="fraction of cases forced to the default scoring so that they can go through the C++ driver")
     args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
+    env_before = {k: v for k, v in os.environ.items() if k.startswith("CUDASW4_AMD_")}
     t_end = time.time() + args.seconds
     case = 0
     K = search.KernelTypeConfig
@@ -236,6 +237,12 @@ def main(argv=None):
             print("mismatches at", bad[:10], "got", got[bad[:10]], "expect", expect[bad[:10]], "lengths", lens[bad[:10]])
             print("top got", top, "expect", es, ei)
             sys.exit(1)
+    # (tests/test_gpu_fuzz.py runs this in the pytest process: leave no switch behind for the tests after it)
+    for k in list(os.environ):
+        if k.startswith("CUDASW4_AMD_") and k not in env_before:
+            os.environ.pop(k)
+    for k, v in env_before.items():
+        os.environ[k] = v
     print("fuzz: %d cases, no mismatch" % case)
     return case
 
