@@ -259,6 +259,7 @@ struct SearchDriver::Gpu {
     int rowsMode = 1;
     int64_t rowsLaunches = 0;          // side launches that ran row-parallel, since the driver was created
     double pipelineShare = kPipelineWalkShare;  // CUDASW4_AMD_PIPELINE_SHARE (A/B measurements)
+    double pipelineShareFinal = kPipelineWalkShareFinal;  // CUDASW4_AMD_PIPELINE_SHARE_FINAL
     double pipelineMinBulkSeconds = 0.0;
     double pipelineRescoreShare = kPipelineRescoreShare;  // CUDASW4_AMD_PIPELINE_RESCORE_SHARE (A/B measurements; >= 100: never)
     int64_t pipelineRescores = 0;      // re-score launches whose long subjects went ahead pipelined
@@ -549,6 +550,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "auto" ? 1 : 0;
         if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "single" ? 3 : 1;
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE")) g->pipelineShare = std::max(0.01, std::atof(e));
+        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE_FINAL")) g->pipelineShareFinal = std::max(0.01, std::atof(e));
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_MIN_BULK_MS")) g->pipelineMinBulkSeconds = std::max(0.0, std::atof(e)) * 1e-3;
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_RESCORE_SHARE")) g->pipelineRescoreShare = std::max(0.001, std::atof(e));
         if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
@@ -1001,9 +1003,8 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // while an 8 000-residue subject of partition 34 walks for 14 ms on a wave-wide group and a 5 500-residue relative of the
     // query is re-scored for 16 ms behind it.  So the LONGEST subjects of the range — every subject whose lone walk would
     // take more than kPipelineWalkShare of the bulk launch's estimated time, at most kPipelineMaxSubjects — leave the scan
-    // launches: [cut, lend) runs as pipelines of one-wave stages over many SIMDs (~0.3 us per query row whatever the
+    // launches: they run as pipelines of one-wave stages over many SIMDs (~0.3 us per query row whatever the
     // subject's length, exact 32-bit scores, nothing to re-score), partition by partition (each part on an auxiliary stream).
-    size_t cut = lend;
     // (CUDASW4_AMD_WINDOWS=always: the giants are wanted as windows — tests of that path)
     const bool pipelineWanted = (g.rowsMode == 1 || g.rowsMode == 2) && gop <= gex && lend > lbegin && !g.windowsAlways;
     // a wave-wide group's step of R rows per lane: ~(6.5 R + 19) instructions at ~6 cycles each beside a busy grid
@@ -1011,30 +1012,45 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     const double colSeconds = std::ceil(qrows64 / 8.0) * (6.5 * std::min(qrows64, 8.0) + 19.0) * 6.0 / 2.4e9;
     const double bulkSeconds = double(g.localOffsets[lend] - g.localOffsets[lbegin]) * double(g.qlen) / 10e12;
     const bool pipelineOk = pipelineWanted;
+    // Each of the two partitions keeps its shorter subjects [b, cut) in the scan launches and hands [cut, e) to the pipeline.
+    // A subject of partition 34 scored in a packed kind may have to be walked twice (the re-score follows the bulk launch),
+    // hence the smaller share; a walk of partition 35 in a 32-bit kind is final, and up to kPipelineWalkShareFinal of the
+    // bulk's time it hides beside the bulk launch it starts with (two queries in flight / the default stream, shares 0.3 / 0.55 /
+    // 0.8 for partition 35: whole Swiss-Prot-like DB 11 160 / 11 200 / 11 244 and 11 254 / 11 294 / 11 360 GCUPS, 1/2 shard
+    // 11 109 / 11 040 / 11 049, 1/4 10 870 / 10 901 / 10 911, 1/8 9 694 / 9 681 / 9 724 — profiles/r05_shard_proxy.txt).
+    constexpr int kSmallLong = kNumLengthPartitions - 2, kLargeLong = kNumLengthPartitions - 1;
+    const size_t b34 = std::max(lbegin, std::min(lend, g.localBegin[kSmallLong]));
+    const size_t b35 = std::max(lbegin, std::min(lend, g.localBegin[kLargeLong]));
+    size_t cut34 = b35, cut35 = lend;
     if (pipelineOk) {
-        constexpr int kSmallLong = kNumLengthPartitions - 2;
-        double maxWalk = g.pipelineShare * bulkSeconds / colSeconds;
-        if (g.rowsMode == 2) maxWalk = 8000.0;   // "always": every subject of partition 35, whatever the estimate says
-        const size_t lo = std::max(lbegin, std::min(lend, g.localBegin[kSmallLong]));   // partitions 34 and 35 only
-        size_t a = lo, b = lend;   // first position whose subject is longer than maxWalk (ascending lengths)
-        while (a < b) {
-            const size_t mid = a + (b - a) / 2;
-            if (double(db.length(size_t(g.toGlobal(int64_t(mid))))) > maxWalk) b = mid; else a = mid + 1;
-        }
-        cut = std::max(a, lend - std::min<size_t>(lend - lo, size_t(kPipelineMaxSubjects)));
-        if (int64_t(db.length(size_t(g.toGlobal(int64_t(lend - 1))))) * int64_t(-gex) >= (int64_t(1) << 28)) cut = lend;
+        auto first_longer = [&](size_t a, size_t b, double maxWalk) {   // ascending lengths within a partition
+            while (a < b) {
+                const size_t mid = a + (b - a) / 2;
+                if (double(db.length(size_t(g.toGlobal(int64_t(mid))))) > maxWalk) b = mid; else a = mid + 1;
+            }
+            return a;
+        };
+        const double share35 = is_packed(kt.for_partition(kLargeLong)) ? g.pipelineShare : std::max(g.pipelineShare, g.pipelineShareFinal);
+        const double walks = bulkSeconds / colSeconds;
+        const bool always = g.rowsMode == 2;   // "always": every subject of partition 35, whatever the estimate says
+        cut34 = std::max(first_longer(b34, b35, always ? 8000.0 : g.pipelineShare * walks), b35 - std::min<size_t>(b35 - b34, size_t(kPipelineMaxSubjects)));
+        cut35 = std::max(first_longer(b35, lend, always ? 8000.0 : share35 * walks), lend - std::min<size_t>(lend - b35, size_t(kPipelineMaxSubjects)));
+        if (int64_t(db.length(size_t(g.toGlobal(int64_t(lend - 1))))) * int64_t(-gex) >= (int64_t(1) << 28)) { cut34 = b35; cut35 = lend; }
     }
-    // the parts of [cut, lend), longest partition first; a part whose hand-off array does not fit the scratch budget stays
-    // with the scan launches (and so does everything below it)
+    // the parts, longest partition first; a part whose hand-off array does not fit the scratch budget stays with the scan
+    // launches
     struct PipePart { size_t begin, end; int part_id; int32_t maxlen; size_t need; };
     std::vector<PipePart> pipeParts;
-    for (int p = kNumLengthPartitions - 1; p >= kNumLengthPartitions - 2 && cut < lend; p--) {
-        const size_t b = std::max(cut, g.localBegin[p]), e = std::min(lend, g.localBegin[p + 1]);
-        if (e <= b) continue;
-        const int32_t maxlen = int32_t(db.length(size_t(g.toGlobal(int64_t(e - 1)))));
-        const size_t need = sw_scan_rows_pipelined_temp_bytes(g.ctx, int32_t(e - b), maxlen);
-        if (need == 0 || need > std::min(mem.maxTempBytes, g.tempCap) || pipeParts.size() >= size_t(GpuT::kAux)) { cut = e; break; }
-        pipeParts.push_back(PipePart{b, e, p, maxlen, need});
+    {
+        const size_t pb[2] = {cut35, cut34}, pe[2] = {lend, b35};
+        for (int k = 0; k < 2; k++) {
+            const size_t b = pb[k], e = pe[k];
+            if (e <= b) continue;
+            const int32_t maxlen = int32_t(db.length(size_t(g.toGlobal(int64_t(e - 1)))));
+            const size_t need = sw_scan_rows_pipelined_temp_bytes(g.ctx, int32_t(e - b), maxlen);
+            if (need == 0 || need > std::min(mem.maxTempBytes, g.tempCap) || pipeParts.size() >= size_t(GpuT::kAux)) continue;
+            pipeParts.push_back(PipePart{b, e, kLargeLong - k, maxlen, need});
+        }
     }
     // (CUDASW4_AMD_PIPELINE_MIN_BULK_MS, default 0 = off: scans estimated shorter than this keep at most 256 stages.  Built
     // when a stream of 48-residue queries on the whole Swiss-Prot-like DB — 19 giants, 665 stages — ran 9 % slower with the
@@ -1050,27 +1066,34 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         }
         pipeParts.resize(keep);
     }
-    if (pipeParts.empty()) cut = lend;
-    else cut = pipeParts.back().begin;
-    lend = cut;   // what the scan launches below cover
+    cut34 = b35; cut35 = lend;   // what the scan launches below cover: [lbegin, cut34) and [b35, cut35)
+    for (const PipePart& pp : pipeParts) (pp.part_id == kLargeLong ? cut35 : cut34) = pp.begin;
+    const size_t scanEnd = cut35 > b35 ? cut35 : cut34;   // (contiguous unless part of partition 34 is pipelined and part of 35 is not)
     bool latencyMode = g.latencyMode == 2;
-    if (g.latencyMode == 1 && slot < 0 && lend > lbegin) {
-        constexpr int kSmallLong = kNumLengthPartitions - 2;
-        const size_t b34 = std::max(lbegin, g.localBegin[kSmallLong]), e34 = std::min(lend, g.localBegin[kSmallLong + 1]);
+    if (g.latencyMode == 1 && slot < 0 && cut34 > lbegin) {
+        const size_t e34 = cut34;
         if (e34 > b34 && e34 - b34 >= kLongPartitionMergeMin) {
             const double longest = double(db.length(size_t(g.toGlobal(int64_t(e34 - 1)))));
             // a step of a 16-lane group with R rows per lane: ~(6.5 R + 19) instructions at three waves per SIMD
             const double rows16 = std::min(32.0, std::ceil(double(g.qlen) / 16.0));
             const double tLong16 = longest * std::ceil(double(g.qlen) / 512.0) * (6.5 * rows16 + 19.0) * 3.1 / 2.4e9;
-            const double tAll = double(g.localOffsets[lend] - g.localOffsets[lbegin]) * double(g.qlen) / 1e13;
+            const double tAll = double(g.localOffsets[scanEnd] - g.localOffsets[lbegin]) * double(g.qlen) / 1e13;
             // (queries below 256 residues leave a wave-wide group fewer than four rows per lane: not for them)
             latencyMode = g.qlen >= 256 && tLong16 >= 0.5 * tAll;
         }
     }
     SWCHECK(sw_set_long16_min(g.ctx, latencyMode ? INT32_MAX : -1));
-    const auto runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, lend,
-                                       [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); },
-                                       latencyMode ? SIZE_MAX : kLongPartitionMergeMin);
+    auto length_at = [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); };
+    const size_t mergeMin = latencyMode ? SIZE_MAX : kLongPartitionMergeMin;
+    std::vector<LaunchRun> runs;
+    if (cut34 == b35) runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, cut35, length_at, mergeMin);
+    else {   // the longest of partition 34 are pipelined, the shortest of partition 35 are not: two ranges
+        runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, cut34, length_at, mergeMin);
+        if (cut35 > b35) {
+            const auto tail = plan_launch_runs(kt, g.localBegin.data(), b35, cut35, length_at, mergeMin);
+            runs.insert(runs.end(), tail.begin(), tail.end());
+        }
+    }
     if (latencyMode) g.latencyScans++;
     const uint64_t* offsets = g.d_offsets + lbegin;
     const int32_t* lengths = g.d_lengths + lbegin;
@@ -1157,7 +1180,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     // short queries.  Returns false when the run is to be launched as it is.
     auto launch_rows = [&](size_t ri, hipStream_t stream) -> bool {
         const LaunchRun& r = runs[ri];
-        // (round 5: the subjects whose walk would matter have left the scan launches as pipelines — `cut` above; what is left
+        // (round 5: the subjects whose walk would matter have left the scan launches as pipelines — cut34 / cut35 above; what is left
         // here is CUDASW4_AMD_ROWS=single, the one-workgroup form of round 4 by its time estimate, kept for A/B measurements)
         if (g.rowsMode != 3 || is_packed(r.kind) || r.part_id != kNumLengthPartitions - 1) return false;
         if (gop > gex || r.maxlen > sw_scan_rows_max_subject() || r.end - r.begin > 64) return false;

@@ -76,6 +76,8 @@ constexpr size_t kLongPartitionMergeMin = 512;
 // subjects is a latency problem, thousands of them are throughput: the scan kernels)
 constexpr int32_t kPipelineMaxSubjects = 256;
 constexpr double kPipelineWalkShare = 0.3;
+// ... and of a subject of partition 35 scored in a 32-bit kind (its walk is final: no re-score can follow it)
+constexpr double kPipelineWalkShareFinal = 0.8;
 // ... and the flagged subjects of an overflow list whose 32-bit re-score walk would take more than this share of it
 constexpr double kPipelineRescoreShare = 0.1;
 
