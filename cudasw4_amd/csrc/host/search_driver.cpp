@@ -260,6 +260,8 @@ struct SearchDriver::Gpu {
     int64_t rowsLaunches = 0;          // side launches that ran row-parallel, since the driver was created
     double pipelineShare = kPipelineWalkShare;  // CUDASW4_AMD_PIPELINE_SHARE (A/B measurements)
     double pipelineShareFinal = kPipelineWalkShareFinal;  // CUDASW4_AMD_PIPELINE_SHARE_FINAL
+    int32_t pipelineMaxSubjects = kPipelineMaxSubjects;   // CUDASW4_AMD_PIPELINE_MAX_SUBJECTS
+    int32_t split34MaxLanes = 4;   // CUDASW4_AMD_SPLIT34_MAX_LANES: partition 34 keeps its own launch below a bulk launch on groups of at most this many lanes
     double pipelineMinBulkSeconds = 0.0;
     double pipelineRescoreShare = kPipelineRescoreShare;  // CUDASW4_AMD_PIPELINE_RESCORE_SHARE (A/B measurements; >= 100: never)
     int64_t pipelineRescores = 0;      // re-score launches whose long subjects went ahead pipelined
@@ -550,6 +552,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "auto" ? 1 : 0;
         if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "single" ? 3 : 1;
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE")) g->pipelineShare = std::max(0.01, std::atof(e));
+        if (const char* e = std::getenv("CUDASW4_AMD_SPLIT34_MAX_LANES")) g->split34MaxLanes = std::atoi(e);
+        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_MAX_SUBJECTS")) g->pipelineMaxSubjects = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE_FINAL")) g->pipelineShareFinal = std::max(0.01, std::atof(e));
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_MIN_BULK_MS")) g->pipelineMinBulkSeconds = std::max(0.0, std::atof(e)) * 1e-3;
         if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_RESCORE_SHARE")) g->pipelineRescoreShare = std::max(0.001, std::atof(e));
@@ -1022,6 +1026,19 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     const size_t b34 = std::max(lbegin, std::min(lend, g.localBegin[kSmallLong]));
     const size_t b35 = std::max(lbegin, std::min(lend, g.localBegin[kLargeLong]));
     size_t cut34 = b35, cut35 = lend;
+    // Below a bulk launch on 4-lane groups (very short queries, sw_api.hip: lanes_for_partition) partition 34 keeps a launch
+    // of its own on 16-lane groups: a quad's column costs ~(6.5 R + 19) instructions with R a quarter of the query, and the
+    // longest subject's walk bounds a launch — a 4 700-residue subject merged into a 96-residue query's launch on quads
+    // walks for 3.6 ms, the launch's instructions take 1.8 ms (SQ_BUSY_CYCLES 53 %, profiles/r05_short_queries.txt).
+    // (Handing more of partition 34 to the pipeline instead — a walk estimate of the short groups' own, ~11 cycles per
+    // instruction as measured — costs more than the tail it removes: 144 residues 9 440 -> 8 621 GCUPS, 192: 10 104 -> 9 379.)
+    bool split34 = false;
+    if (b35 > b34 && b34 > lbegin && kt.for_partition(kSmallLong - 1) == kt.for_partition(kSmallLong)) {
+        int32_t ek = 0, r33 = 0, ns33 = 0, l33 = 16;
+        SWCHECK(sw_plan_launch(g.ctx, int(kt.for_partition(kSmallLong)), kSmallLong - 1, int32_t(b34 - lbegin),
+                               int32_t(db.length(size_t(g.toGlobal(int64_t(b34 - 1))))), &ek, &r33, &ns33, &l33));
+        split34 = l33 <= g.split34MaxLanes;
+    }
     if (pipelineOk) {
         auto first_longer = [&](size_t a, size_t b, double maxWalk) {   // ascending lengths within a partition
             while (a < b) {
@@ -1033,8 +1050,8 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
         const double share35 = is_packed(kt.for_partition(kLargeLong)) ? g.pipelineShare : std::max(g.pipelineShare, g.pipelineShareFinal);
         const double walks = bulkSeconds / colSeconds;
         const bool always = g.rowsMode == 2;   // "always": every subject of partition 35, whatever the estimate says
-        cut34 = std::max(first_longer(b34, b35, always ? 8000.0 : g.pipelineShare * walks), b35 - std::min<size_t>(b35 - b34, size_t(kPipelineMaxSubjects)));
-        cut35 = std::max(first_longer(b35, lend, always ? 8000.0 : share35 * walks), lend - std::min<size_t>(lend - b35, size_t(kPipelineMaxSubjects)));
+        cut34 = std::max(first_longer(b34, b35, always ? 8000.0 : g.pipelineShare * walks), b35 - std::min<size_t>(b35 - b34, size_t(g.pipelineMaxSubjects)));
+        cut35 = std::max(first_longer(b35, lend, always ? 8000.0 : share35 * walks), lend - std::min<size_t>(lend - b35, size_t(g.pipelineMaxSubjects)));
         if (int64_t(db.length(size_t(g.toGlobal(int64_t(lend - 1))))) * int64_t(-gex) >= (int64_t(1) << 28)) { cut34 = b35; cut35 = lend; }
     }
     // the parts, longest partition first; a part whose hand-off array does not fit the scratch budget stays with the scan
@@ -1084,7 +1101,7 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     }
     SWCHECK(sw_set_long16_min(g.ctx, latencyMode ? INT32_MAX : -1));
     auto length_at = [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); };
-    const size_t mergeMin = latencyMode ? SIZE_MAX : kLongPartitionMergeMin;
+    const size_t mergeMin = (latencyMode || split34) ? SIZE_MAX : kLongPartitionMergeMin;
     std::vector<LaunchRun> runs;
     if (cut34 == b35) runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, cut35, length_at, mergeMin);
     else {   // the longest of partition 34 are pipelined, the shortest of partition 35 are not: two ranges

@@ -122,6 +122,18 @@ constexpr uint32_t kWorkSlots = 4096;
 #ifndef SW_LANES8_MAX_QUERY_PACKED
 #define SW_LANES8_MAX_QUERY_PACKED 256
 #endif
+#ifndef SW_LANES4_MAX_QUERY_PACKED
+#define SW_LANES4_MAX_QUERY_PACKED 96
+#endif
+#ifndef SW_LANES4_MAX_QUERY_SCALAR
+#define SW_LANES4_MAX_QUERY_SCALAR 128
+#endif
+#ifndef SW_LANES4_MAX_SUBJECT
+#define SW_LANES4_MAX_SUBJECT 1280
+#endif
+#ifndef SW_LANES4_MIN_BATCHES_PER_CU
+#define SW_LANES4_MIN_BATCHES_PER_CU 12
+#endif
 #ifndef SW_LANES8_MAX_SUBJECT
 #define SW_LANES8_MAX_SUBJECT 192
 #endif
@@ -155,13 +167,15 @@ struct sw_ctx {
     int query_next = 0;
     int32_t qlen = 0;
     bool have_query = false;
-    Profile profiles[4][3][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups, 2 = 8-lane groups][plain | column-offset recurrence]
+    Profile profiles[4][4][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups, 2 = 8-lane groups, 3 = 4-lane groups][plain | column-offset recurrence]
     bool use_offs = true;        // CUDASW4_AMD_NO_OFFS=1: always the plain recurrence (A/B measurements)
     int64_t long16_min = -1;     // CUDASW4_AMD_LONG16_MIN / sw_set_long16_min: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
     int64_t long16_min_default = -1;  // what the environment said at creation (sw_set_long16_min(ctx, -1) returns to it)
     int matrix_max = 1;          // largest substitution score of the installed matrix
     bool i32_native = false;     // CUDASW4_AMD_I32_NATIVE=1: never compute the int32 kind in fp32 lanes (tests of the int32 kernels)
     int32_t lanes8_max_subject = -1;  // CUDASW4_AMD_LANES8_MAX_SUBJECT: multi-stripe queries use 8-lane groups when no subject of the launch is longer (-1: built-in)
+    int32_t lanes4_max_subject = -1;  // CUDASW4_AMD_LANES4_MAX_SUBJECT: ... when no subject of the launch is longer (-1: 1280)
+    int32_t lanes4_max_q = -1;   // CUDASW4_AMD_LANES4_MAX_Q: queries up to this length use 4-lane groups (0: never; -1: the built-in limits)
     int32_t lanes8_max_q = -1;   // CUDASW4_AMD_LANES8_MAX_Q: queries up to this length use 8-lane groups (0: never; -1: the built-in limits)
     bool check_bounds = false;   // CUDASW4_AMD_CHECK_BOUNDS=1 (debug): every scan first verifies the max_subject_len contract on the device (synchronises)
     // sw_scan_rows_pipelined: control words of the launches in flight (tickets, counted-in workgroups, abort, spare), rotating
@@ -190,7 +204,7 @@ int max_grid(const sw_ctx* ctx) { return std::max(1, ctx->num_cus) * ctx->grid_m
 // overflowed subjects can have any length: long ones would dominate a 16-lane launch
 int rescore_lanes(int32_t max_subject_len) { return max_subject_len > 1280 ? 64 : 16; }
 
-int shape_index(int lanes) { return lanes == 64 ? 1 : lanes == 8 ? 2 : 0; }
+int shape_index(int lanes) { return lanes == 64 ? 1 : lanes == 8 ? 2 : lanes == 4 ? 3 : 0; }
 
 // The int32 kind in fp32 lanes.  On gfx950 the fp32 form of the recurrence runs 30 % faster than the int32 form (8.35
 // against 6.44 TCUPS on the peak DB): v_add_f32 co-issues with v_max3_f32, v_add_u32 does not.  fp32
@@ -210,6 +224,16 @@ int effective_kind_of(const sw_ctx* ctx, int kind, int32_t max_subject_len) {
 int lanes_for_partition(const sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
     if (part_id < SW_NUM_LENGTH_PARTITIONS - 2) {
         if (!ctx->have_query) return 16;
+        // very short queries: 4-lane groups (a DPP quad; single-stripe kernels only).  A batch is 128 (packed kinds) or 64
+        // subjects then: only where the launch still hands every workgroup slot several batches
+        const int32_t limit4 = ctx->lanes4_max_q >= 0 ? ctx->lanes4_max_q : kind_packed(kind) ? SW_LANES4_MAX_QUERY_PACKED : SW_LANES4_MAX_QUERY_SCALAR;
+        const int64_t batches4 = (int64_t)n / (64 * (kind_packed(kind) ? 2 : 1));
+        const bool enough4 = ctx->lanes4_max_q >= 0 || batches4 >= (int64_t)SW_LANES4_MIN_BATCHES_PER_CU * std::max(1, ctx->num_cus);   // (an explicit limit: tests reach the shape with a handful of subjects)
+        // ... and holds no long subject: a column costs a quad ~(6.5 R + 19) instructions with R = a quarter of the query, and
+        // the longest subject's walk bounds the launch (partition 34 merged into a 96-residue query's launch: 3.6 ms
+        // against 1.8 ms of instructions); the host driver keeps partition 34 out of such a launch
+        const int32_t lmax4 = ctx->lanes4_max_subject >= 0 ? ctx->lanes4_max_subject : SW_LANES4_MAX_SUBJECT;
+        if (ctx->qlen <= 4 * swk::max_rows(kind, 4) && ctx->qlen <= limit4 && enough4 && max_subject_len <= lmax4) return 4;
         const bool fits8 = ctx->qlen <= 8 * swk::max_rows(kind, 8);  // one stripe of 8-lane groups
         const int32_t limit = ctx->lanes8_max_q >= 0 ? ctx->lanes8_max_q : kind_packed(kind) ? SW_LANES8_MAX_QUERY_PACKED : SW_LANES8_MAX_QUERY_SCALAR;
         if (fits8 && ctx->qlen <= limit) return 8;
@@ -263,6 +287,7 @@ int32_t border_capacity(int32_t max_len, int lanes) {
     return (int32_t)((steps + 15) / 16 * 16 + 16);  // + one prefetched quad past the end, rounded to 64 bytes
 }
 size_t border_bytes_per_wg(int32_t lcap, int lanes) {
+    if (lanes == 4) return 0;   // single-stripe kernels only: no border
     const size_t region = lanes == 16 ? swk::border_region_words<16>(lcap) : lanes == 8 ? swk::border_region_words<8>(lcap) : swk::border_region_words<64>(lcap);
     return (size_t)(swk::kThreads / lanes) * region * sizeof(uint32_t);
 }
@@ -491,6 +516,8 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = ctx->long16_min_default = atoll(e);
     if (const char* e = getenv("CUDASW4_AMD_I32_NATIVE")) ctx->i32_native = e[0] == '1';
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_Q")) ctx->lanes8_max_q = atoi(e);
+    if (const char* e = getenv("CUDASW4_AMD_LANES4_MAX_Q")) ctx->lanes4_max_q = atoi(e);
+    if (const char* e = getenv("CUDASW4_AMD_LANES4_MAX_SUBJECT")) ctx->lanes4_max_subject = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_SUBJECT")) ctx->lanes8_max_subject = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_CHECK_BOUNDS")) ctx->check_bounds = e[0] == '1';
     if (const char* e = getenv("CUDASW4_AMD_PIPE_SPIN_LIMIT")) ctx->pipe_spin_limit = (uint32_t)std::max(1ll, atoll(e));

@@ -57,6 +57,7 @@ enum { F16X2 = 0, I16X2 = 1, I32 = 2, F32 = 3 };
 constexpr int DPP_ROW_SHL1 = 0x101;   // lane i <- lane i+1 (within a row of 16)
 constexpr int DPP_ROW_SHR1 = 0x111;   // lane i <- lane i-1
 constexpr int DPP_ROW_ROR1 = 0x121;
+constexpr int DPP_QUAD_SHR1 = 0x90;   // quad_perm [0,0,1,2]: lane i <- lane i-1 within its quad (lane 0 of a quad: itself)
 constexpr int DPP_WAVE_SHL1 = 0x130;  // the same across all 64 lanes of the wave
 constexpr int DPP_WAVE_SHR1 = 0x138;
 
@@ -68,10 +69,13 @@ constexpr int DPP_WAVE_SHR1 = 0x138;
 // instructions) is spread over twice the cells, and the pipeline fill per subject is 7 instead of 15 steps.  The
 // row_shr:1 exchange crosses from lane 7 into lane 8, the head of the second group of the row, which costs one select
 // per exchanged value (prev_lane).  With several stripes the shape pays off for short subjects only: half the fill per
-// stripe, but twice the stripes.)
+// stripe, but twice the stripes.), or
+// LANES = 4 (a DPP quad, 16 groups per wave: VERY SHORT QUERIES, single-stripe only.  A 48-residue query gives an 8-lane
+// group 6 rows per lane — (6.5 * 6 + 19) / 6 = 9.67 instructions per cell pair, SQ_INSTS_VALU says the same — and a quad 12:
+// 8.08.  The exchange is a quad_perm, every group's head selects its boundary value like lane 8 above.)
 template <int LANES>
 struct Shift {
-    static_assert(LANES == 8 || LANES == 16 || LANES == 64, "group = half a DPP row, a DPP row or the whole wave");
+    static_assert(LANES == 4 || LANES == 8 || LANES == 16 || LANES == 64, "group = a DPP quad, half a DPP row, a DPP row or the whole wave");
     static constexpr int kShr1 = LANES <= 16 ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
     static constexpr int kShl1 = LANES <= 16 ? DPP_ROW_SHL1 : DPP_WAVE_SHL1;
 };
@@ -88,6 +92,9 @@ template <int LANES, bool ZERO_FILL>
 __device__ __forceinline__ u32 prev_lane(u32 headval, u32 src, bool head) {
     if constexpr (LANES == 8) {
         const u32 v = dpp<DPP_ROW_SHR1, false>(headval, src);
+        return head ? headval : v;
+    } else if constexpr (LANES == 4) {
+        const u32 v = dpp<DPP_QUAD_SHR1, false>(headval, src);
         return head ? headval : v;
     } else {
         (void)head;
@@ -564,8 +571,8 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
     // more — a per-lane constant (laneStep) in place of the literal, no instruction more.  With both groups in slots
     // 0..7 they met in the same banks with different letter rows: every second LDS cycle of the 8-lane kernels was a
     // conflict on ragged subjects.
-    const u32 step2 = LANES == 8 ? laneStep : 0x00100010u;
-    const u32 step1 = LANES == 8 ? laneStep : 16u;
+    const u32 step2 = LANES < 16 ? laneStep : 0x00100010u;
+    const u32 step1 = LANES < 16 ? laneStep : 16u;
     constexpr u32 kSel = 0x0c0c000cu | ((u32)BYTE << 8);  // letter byte BYTE -> bits 15:8
     constexpr int kPostShift = G::kLetterShift - 8;        // row offset = byte << kLetterShift
 
@@ -778,10 +785,19 @@ __device__ __forceinline__ u32 half_row_max(u32 v, MAX&& mx) {
     return v;
 }
 
+// ... and over the 4 lanes of a quad, left in all of them
+template <class MAX>
+__device__ __forceinline__ u32 quad_max(u32 v, MAX&& mx) {
+    v = mx(v, dpp<0xB1, false>(v, v));   // quad_perm [1,0,3,2]
+    v = mx(v, dpp<0x4E, false>(v, v));   // quad_perm [2,3,0,1]
+    return v;
+}
+
 template <int KIND, int LANES>
 __device__ __forceinline__ u32 group_max(u32 v) {
     using A = Arith<KIND>;
     if constexpr (LANES == 8) return half_row_max(v, [](u32 a, u32 b) { return A::max2(a, b); });
+    if constexpr (LANES == 4) return quad_max(v, [](u32 a, u32 b) { return A::max2(a, b); });
     v = A::max2(v, dpp<0x128, false>(v, v));  // row_ror:8
     v = A::max2(v, dpp<0x124, false>(v, v));  // row_ror:4
     v = A::max2(v, dpp<0x122, false>(v, v));  // row_ror:2
@@ -889,8 +905,9 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
     const int group = tid / LANES;
     const bool head = lane == 0;
     // 8-lane groups: the two groups of a DPP row use the two halves of the row's 16 profile slots (dp_step: laneStep)
-    const int slot = LANES == 8 ? (tid & 15) : lane;
-    const u32 laneStep = (A::kPacked ? 0x00100010u : 16u) * ((LANES == 8 && (tid & 15) == 8) ? 9u : 1u);
+    // (4-lane groups likewise: the four groups of a row in slots 0..3, 4..7, 8..11, 12..15)
+    const int slot = LANES < 16 ? (tid & 15) : lane;
+    const u32 laneStep = (A::kPacked ? 0x00100010u : 16u) * ((LANES < 16 && head) ? u32(slot + 1) : 1u);
     if (p.start_signal && tid == 0) {
         // this workgroup holds its registers and LDS now: whoever the caller ordered behind the signal cannot take them
         if (atomicAdd(p.work_counter + 1, 1u) + 1u == p.start_quorum)
@@ -998,7 +1015,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
         }
         int lmax = len0 > len1 ? len0 : len1;
         if constexpr (LANES <= 16) {  // the 4 (8) groups of a wave run in lock-step
-            if constexpr (LANES == 8) lmax = max(lmax, __shfl_xor(lmax, 8));
+            if constexpr (LANES <= 4) lmax = max(lmax, __shfl_xor(lmax, 4));
+            if constexpr (LANES <= 8) lmax = max(lmax, __shfl_xor(lmax, 8));
             lmax = max(lmax, __shfl_xor(lmax, 16));
             lmax = max(lmax, __shfl_xor(lmax, 32));
         }
@@ -1253,6 +1271,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             // group maximum of true scores
             if constexpr (LANES == 8) {
                 maxv = half_row_max(maxv, [](u32 a, u32 b) { return A::true_max(a, b); });
+            } else if constexpr (LANES == 4) {
+                maxv = quad_max(maxv, [](u32 a, u32 b) { return A::true_max(a, b); });
             } else {
                 maxv = A::true_max(maxv, dpp<0x128, false>(maxv, maxv));
                 maxv = A::true_max(maxv, dpp<0x124, false>(maxv, maxv));

@@ -12,5 +12,8 @@ namespace swk {
 #define SWK_CASE_SCAN8_I32(R) case R: return launch_scan_r<I32, R, 8>(multi, offs, grid, reserve, stream, p);
 #define SWK_CASE_PROF8_I32(R) case R: return launch_profile_r<I32, R, 8>(q, qlen, m, pr, ns, out, shift, s);
 #define SWK_CASE_TILE8_I32(R) case R: return tile_bytes_r<I32, R, 8>();
+#define SWK_CASE_SCAN4_I32(R) case R: return launch_scan_r<I32, R, 4>(multi, offs, grid, reserve, stream, p);
+#define SWK_CASE_PROF4_I32(R) case R: return launch_profile_r<I32, R, 4>(q, qlen, m, pr, ns, out, shift, s);
+#define SWK_CASE_TILE4_I32(R) case R: return tile_bytes_r<I32, R, 4>();
 SWK_DEFINE_KIND(launch_i32, I32, SWK_FOR_EACH_R_I32)
 }  // namespace swk

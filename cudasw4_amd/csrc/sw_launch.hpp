@@ -106,7 +106,7 @@ hipError_t launch_scan_ro(bool multi, int grid, int reserve, hipStream_t stream,
         return hipErrorInvalidValue;
     } else {
         if (multi) {
-            if constexpr (2 * R > kMaxR) {
+            if constexpr (2 * R > kMaxR && LANES != 4) {   // (4-lane groups: single-stripe queries only)
                 return launch_scan_k(sw_scan_kernel<KIND, R, LANES, true, OFFS>, grid, reserve, stream, p);
             } else {
                 return hipErrorInvalidValue;
@@ -161,6 +161,7 @@ constexpr size_t tile_bytes_r() {
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN64_##KIND) } }                                 \
         else if (lanes == 8) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN8_##KIND) } }                                   \
+        else if (lanes == 4) { switch (R) { FOR_EACH_R(SWK_CASE_SCAN4_##KIND) } }                                   \
         return hipErrorInvalidValue;                                                                                \
     }                                                                                                               \
     static hipError_t FN##_profile(int R, int lanes, const int8_t* q, int32_t qlen, const int8_t* m, int32_t pr,    \
@@ -168,12 +169,14 @@ constexpr size_t tile_bytes_r() {
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_PROF16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_PROF64_##KIND) } }                                 \
         else if (lanes == 8) { switch (R) { FOR_EACH_R(SWK_CASE_PROF8_##KIND) } }                                   \
+        else if (lanes == 4) { switch (R) { FOR_EACH_R(SWK_CASE_PROF4_##KIND) } }                                   \
         return hipErrorInvalidValue;                                                                                \
     }                                                                                                               \
     static size_t FN##_tile_bytes(int R, int lanes) {                                                               \
         if (lanes == 16) { switch (R) { FOR_EACH_R(SWK_CASE_TILE16_##KIND) } }                                      \
         else if (lanes == 64) { switch (R) { FOR_EACH_R(SWK_CASE_TILE64_##KIND) } }                                 \
         else if (lanes == 8) { switch (R) { FOR_EACH_R(SWK_CASE_TILE8_##KIND) } }                                   \
+        else if (lanes == 4) { switch (R) { FOR_EACH_R(SWK_CASE_TILE4_##KIND) } }                                   \
         return 0;                                                                                                   \
     }                                                                                                               \
     static __global__ void FN##_warm_kernel() {}                                                                    \

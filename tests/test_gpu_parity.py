@@ -391,8 +391,9 @@ def test_every_compiled_tile_shape(monkeypatch):
     short = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1, 260, 37))]
     long_ = [rng.integers(0, 21, int(l)).astype(np.int8) for l in np.sort(rng.integers(1281, 1700, 9))]
     seen = set()
-    for seqs, part_id, lanes in ((short, 33, 16), (long_, 34, 64), (short, 33, 8)):
+    for seqs, part_id, lanes in ((short, 33, 16), (long_, 34, 64), (short, 33, 8), (short, 33, 4)):
         monkeypatch.setenv("CUDASW4_AMD_I32_NATIVE", "1")  # the int32 kernels themselves, not their fp32 stand-ins
+        monkeypatch.setenv("CUDASW4_AMD_LANES4_MAX_Q", "1000000" if lanes == 4 else "0")
         monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_Q", "1000000" if lanes == 8 else "0")
         monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_SUBJECT", "1000000" if lanes == 8 else "0")
         ctx = capi.Context(0)  # reads the environment
@@ -406,23 +407,26 @@ def test_every_compiled_tile_shape(monkeypatch):
         ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
         ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
-            rmax = {8: 48 if kind < 3 else 36, 16: 48 if kind < 3 else 36, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
+            rmax = {4: 48 if kind < 3 else 36, 8: 48 if kind < 3 else 36, 16: 48 if kind < 3 else 36, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
             rmax_multi = 32 if (kind == 3 and lanes <= 16) else rmax  # fp32: several stripes only up to 32 rows per lane
             qlens = set()
             for r in range(1, rmax + 1):
                 qlens.add(lanes * r - 1)                       # one stripe of R rows
                 if lanes == 16:
                     assert capi.plan_query(kind, lanes * r - 1) == (r, 1)
-                if 2 * r > rmax and r <= rmax_multi:
+                if 2 * r > rmax and r <= rmax_multi and lanes != 4:
                     qlens.add(2 * lanes * r - lanes - 3)       # two stripes of R rows
                     if lanes == 16:
                         assert capi.plan_query(kind, 2 * lanes * r - lanes - 3) == (r, 2)
             qlens.add(lanes * rmax)                            # the longest single-stripe query of the shape
-            qlens.add(3 * lanes * rmax_multi - 5)              # three full stripes
+            if lanes != 4:
+                qlens.add(3 * lanes * rmax_multi - 5)          # three full stripes
             for qlen in sorted(qlens):
                 q = rng.integers(0, 20, qlen).astype(np.int8)
                 expect = O.scan(q, chars, offsets, lengths, simd=True)
                 ctx.set_query(q)
+                if lanes != 64:
+                    assert ctx.plan_launch(kind, part_id, n, maxlen)[3] == lanes, (kind, lanes, qlen)
                 need = ctx.scan_temp_bytes(kind, part_id, n, maxlen)
                 temp = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
                 scores.fill_(-1.0)
@@ -435,7 +439,7 @@ def test_every_compiled_tile_shape(monkeypatch):
                 np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect,
                                               err_msg="kind %d lanes %d qlen %d" % (kind, lanes, qlen))
                 seen.add((kind, lanes, qlen))
-    assert len(seen) > 480
+    assert len(seen) > 650
 
 
 @pytest.mark.parametrize("gop,gex", [(-12, -5), (-1000, -1000), (-3, -12)])

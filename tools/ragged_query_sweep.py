@@ -18,6 +18,7 @@ ap.add_argument("--db-size", type=int, default=synthdb.SPROT_SEQUENCES)
 ap.add_argument("--configs", default="dpx,half2,float")
 ap.add_argument("--lengths", default="48,96,144,189,222,256,272,288,304,320,352,384")
 ap.add_argument("--modes", default="0,1000000")
+ap.add_argument("--var", default="CUDASW4_AMD_LANES8_MAX_Q", help="the switch the modes are values of (CUDASW4_AMD_LANES4_MAX_Q: 4-lane groups)")
 args = ap.parse_args()
 chars, offsets, lengths = synthdb.sprot_like(args.db_size)
 residues = float(lengths.astype(np.int64).sum())
@@ -28,7 +29,7 @@ CONFIGS = {"dpx": (1, 1, 2, 2), "half2": (0, 0, 3, 3), "float": (3, 0, 3, 3), "d
 for cname in args.configs.split(","):
     res = {}
     for mode in args.modes.split(","):
-        os.environ["CUDASW4_AMD_LANES8_MAX_Q"] = mode
+        os.environ[args.var] = mode
         d = driver.Driver(devices=[0], num_top=10, kinds=CONFIGS[cname])
         d.db_from_arrays(chars, offsets, lengths)
         d.upload()
@@ -51,8 +52,8 @@ for cname in args.configs.split(","):
     modes = args.modes.split(",")
     print(cname, "query lengths:", [len(q) for q in queries])
     for m in modes:
-        print(cname, "LANES8_MAX_Q=%-8s scan GCUPS:" % m, res[m][0])
-        print(cname, "LANES8_MAX_Q=%-8s bulk launch ms:" % m, res[m][1], res[m][2])
+        print(cname, "%s=%-8s scan GCUPS:" % (args.var[12:], m), res[m][0])
+        print(cname, "%s=%-8s bulk launch ms:" % (args.var[12:], m), res[m][1], res[m][2])
     if len(modes) == 2:
         a, b = res[modes[0]], res[modes[1]]
         print(cname, "same scores:", all((x == y).all() for x, y in zip(a[3], b[3])),
