@@ -1402,15 +1402,29 @@ static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t le
     bool auxBusy[GpuT::kAux] = {};
     std::vector<int> streamOf(runs.size(), -1);  // auxiliary stream of a run, -1: work stream
     bool anySide = false;
+    // The bulk launch waits until every side launch holds its slots, and a stream runs its launches in order: with two
+    // pipeline parts and two side runs on two auxiliary streams the last side launch starts behind a pipeline part (the
+    // giants' 0.2 ms beside a 48-residue query, whose whole scan takes 1.5 ms).  When the re-score service is not in play
+    // (short queries, streamed batches excluded) its stream takes the first pipeline part.
+    const bool svcFree = g.svcStream && g.svcConcurrent && g.handshake && !useService && slot < 0 && !second && !g.laneActive &&
+                         pipeParts.size() + (runs.empty() ? 0 : runs.size() - 1) > size_t(GpuT::kAux);
+    bool svcTaken = false;
     for (const PipePart& pp : pipeParts) {
-        const int a = auxNext++ % GpuT::kAux;
-        if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], fork, 0));
-        auxBusy[a] = true;
         if (g.handshake && !runs.empty()) {
             SWCHECK(sw_set_start_signal(g.ctx, g.startSignal));
             g.sideLaunches++;
             anySide = true;
         }
+        if (svcFree && !svcTaken) {
+            svcTaken = true;
+            HIPCHECK(hipStreamWaitEvent(g.svcStream, fork, 0));
+            launch_pipeline(pp, g.svcStream, GpuT::kAux + 2);
+            g.svcUsed = true;
+            continue;
+        }
+        const int a = auxNext++ % GpuT::kAux;
+        if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], fork, 0));
+        auxBusy[a] = true;
         launch_pipeline(pp, g.aux[a], a + 1);
     }
     for (size_t i = 0; i < runs.size(); i++) {
