@@ -332,7 +332,7 @@ int sw_check_letter_codes(sw_ctx* ctx, const int8_t* chars, size_t n, int32_t* b
 
 /* Introspection for measurement: which kernel instantiation sw_scan_partition (part_id >= 0) or sw_rescore_overflow
  * (part_id = -1) would launch for the CURRENT query: the arithmetic kind actually computed in (SW_KIND_I32 may be served
- * in fp32 lanes, see SW_KIND_I32), rows per lane, query stripes and lanes per alignment group (8 | 16 | 64) — the
+ * in fp32 lanes, see SW_KIND_I32), rows per lane, query stripes and lanes per alignment group (4 | 8 | 16 | 64) — the
  * template arguments of swk::sw_scan_kernel as rocprofv3 prints them.  Any output pointer may be NULL. */
 int sw_plan_launch(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len,
                    int32_t* effective_kind, int32_t* rows_per_lane, int32_t* nstripes, int32_t* lanes);

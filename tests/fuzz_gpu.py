@@ -154,6 +154,8 @@ def main(argv=None):
             os.environ["CUDASW4_AMD_I32_NATIVE"] = str(int(r.integers(0, 2)))
             os.environ["CUDASW4_AMD_LANES8_MAX_Q"] = str(int(r.choice([-1, -1, 0, 100000])))
             os.environ["CUDASW4_AMD_LANES8_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 0, 100000])))
+            os.environ["CUDASW4_AMD_LANES4_MAX_Q"] = str(int(r.choice([-1, 0, 100000, 100000])))   # (explicit: quads whatever the batch count)
+            os.environ["CUDASW4_AMD_LANES4_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 100000])))
             os.environ["CUDASW4_AMD_STREAM"] = str(int(r.choice([0, 0, 2, 4])))
             s = search.Searcher(device=0, num_top=min(10, n), matrix=m, kernel_types=kt, gop=gop, gex=gex,
                                 merge_partitions=bool(r.integers(0, 2)))
@@ -199,7 +201,8 @@ def main(argv=None):
             r5 = {"CUDASW4_AMD_ROWS": r.choice(["", "never", "always", "single"]), "CUDASW4_AMD_PIPELINE_SHARE": r.choice(["", "0.02", "5"]),
                   "CUDASW4_AMD_PIPELINE_RESCORE_SHARE": r.choice(["", "0.001", "1000"]), "CUDASW4_AMD_PIPE_CPL": r.choice(["", "4", "8", "16"]),
                   "CUDASW4_AMD_LATENCY_MODE": r.choice(["", "auto", "always"]), "CUDASW4_AMD_STREAM": r.choice(["", "2", "4"]),
-                  "CUDASW4_AMD_SIDE_RESERVE": r.choice(["", "0", "64"])}
+                  "CUDASW4_AMD_SIDE_RESERVE": r.choice(["", "0", "64"]), "CUDASW4_AMD_LANES4_MAX_Q": r.choice(["", "0", "100000"]),
+                  "CUDASW4_AMD_SPLIT34_MAX_LANES": r.choice(["", "0", "8"])}
             for k5, v5 in r5.items():
                 os.environ.pop(k5, None)
                 if v5:
