@@ -466,6 +466,10 @@ namespace {
 #define SW_OP_MAX3_F32(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
 #define SW_OP_ADD_U32(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
 #define SW_OP_MAX3_I32(i) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define SW_OP_PK_FMA(i) asm volatile("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(b), "v"(c));
+#define SW_OP_PK_ADD(i) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define SW_OP_DPP(i) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+#define SW_OP_PERM(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
 template <int MIX>
 __global__ void __launch_bounds__(256) valu_rate_kernel(unsigned* out, unsigned long long* clocks, unsigned seed, int iters) {
     unsigned a[8];
@@ -477,6 +481,17 @@ __global__ void __launch_bounds__(256) valu_rate_kernel(unsigned* out, unsigned 
         // fp32 kind: 4 v_add_f32 : 3.5 v_max3_f32 per cell = 16 : 14 + 2 to fill the 32
         if constexpr (MIX == 1) { SW_REP8(SW_OP_ADD_F32) SW_REP8(SW_OP_MAX3_F32) SW_REP8(SW_OP_ADD_F32) SW_OP_MAX3_F32(0) SW_OP_MAX3_F32(1) SW_OP_MAX3_F32(2) SW_OP_MAX3_F32(3) SW_OP_MAX3_F32(4) SW_OP_MAX3_F32(5) SW_OP_ADD_F32(6) SW_OP_ADD_F32(7) }
         // int32 kind: 2.25 v_add_u32 : 3.5 v_max3_i32 per cell ~ 12 : 20
+        // the packed kernels' OWN mix (static histogram of the dominant loop body, sw_scan_kernel<f16x2, R = 32, 16 lanes, multi-stripe>,
+        // per four steps: 128 v_pk_fma_f16, 454 v_pk_maximum3_f16, 164 v_pk_add_f16 and ~76 others — DPP moves, v_perm_b32, address
+        // adds — of 822): in 64 slots 10 fma, 35 max3, 13 add, 3 DPP, 2 v_add_u32, 1 v_perm.  A pure v_pk_maximum3_f16 stream issues
+        // FEWER lane-instructions per second than the kernel does (round 5: frac_of_measured_peak 1.06), this one cannot be beaten
+        // by a loop of the same composition that also waits for LDS and neighbours
+        if constexpr (MIX == 3) {
+            SW_REP8(SW_OP_PK_MAX3) SW_OP_PK_FMA(0) SW_OP_PK_FMA(1) SW_OP_PK_ADD(2) SW_OP_PK_ADD(3) SW_OP_DPP(4) SW_OP_PK_FMA(5) SW_OP_PK_ADD(6) SW_OP_ADD_U32(7)
+            SW_REP8(SW_OP_PK_MAX3) SW_OP_PK_FMA(0) SW_OP_PK_FMA(1) SW_OP_PK_ADD(2) SW_OP_PK_ADD(3) SW_OP_DPP(4) SW_OP_PK_FMA(5) SW_OP_PK_ADD(6) SW_OP_PERM(7)
+            SW_REP8(SW_OP_PK_MAX3) SW_OP_PK_FMA(0) SW_OP_PK_FMA(1) SW_OP_PK_ADD(2) SW_OP_PK_ADD(3) SW_OP_DPP(4) SW_OP_PK_ADD(5) SW_OP_PK_ADD(6) SW_OP_ADD_U32(7)
+            SW_REP8(SW_OP_PK_MAX3) SW_OP_PK_FMA(0) SW_OP_PK_FMA(1) SW_OP_PK_ADD(2) SW_OP_PK_ADD(3) SW_OP_PK_MAX3(4) SW_OP_PK_MAX3(5) SW_OP_PK_MAX3(6) SW_OP_PK_ADD(7)
+        }
         if constexpr (MIX == 2) { SW_REP8(SW_OP_MAX3_I32) SW_REP8(SW_OP_ADD_U32) SW_REP8(SW_OP_MAX3_I32) SW_OP_ADD_U32(0) SW_OP_ADD_U32(1) SW_OP_ADD_U32(2) SW_OP_ADD_U32(3) SW_OP_MAX3_I32(4) SW_OP_MAX3_I32(5) SW_OP_MAX3_I32(6) SW_OP_MAX3_I32(7) }
     }
     const unsigned long long t1 = clock64(), w1 = wall_clock64();
@@ -1022,7 +1037,7 @@ int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b) {
 }
 
 int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_per_s, double* shader_hz) {
-    if (!ctx || mix < 0 || mix > 2) return fail(SW_ERR_INVALID, "null context or unknown instruction mix");
+    if (!ctx || mix < 0 || mix > 3) return fail(SW_ERR_INVALID, "null context or unknown instruction mix");
     SW_HIP(hipSetDevice(ctx->device));
     const int grid = std::max(1, ctx->num_cus) * 4;   // 16 waves per CU: four per SIMD
     unsigned* out = nullptr;
@@ -1037,7 +1052,8 @@ int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_pe
         if (e != hipSuccess) return e;
         if (mix == 0) hipLaunchKernelGGL(valu_rate_kernel<0>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
         else if (mix == 1) hipLaunchKernelGGL(valu_rate_kernel<1>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
-        else hipLaunchKernelGGL(valu_rate_kernel<2>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
+        else if (mix == 2) hipLaunchKernelGGL(valu_rate_kernel<2>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
+        else hipLaunchKernelGGL(valu_rate_kernel<3>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
@@ -1064,7 +1080,7 @@ int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_pe
     (void)hipFree(out);
     (void)hipFree(clocks);
     if (err != hipSuccess) return fail(SW_ERR_HIP, std::string("sw_measure_valu_rate: ") + hipGetErrorString(err));
-    if (lane_instr_per_s) *lane_instr_per_s = ms > 0.0f ? (double)grid * 256.0 * 32.0 * (double)iters / (ms * 1e-3) : 0.0;
+    if (lane_instr_per_s) *lane_instr_per_s = ms > 0.0f ? (double)grid * 256.0 * (mix == 3 ? 64.0 : 32.0) * (double)iters / (ms * 1e-3) : 0.0;
     if (shader_hz) *shader_hz = hz;
     return SW_OK;
 }

@@ -37,14 +37,16 @@ def test_roofline_arithmetic_uses_the_device_and_the_measured_peaks():
     """VERDICT r4 item 5: the VALU peak comes from the device's own CU count, the in-process micro-run and the sampled clock;
     nothing is hard-coded but the nominal clock, which is named."""
     b = load_bench()
-    cal = {"cus": 304, "mix": {"0": {"lane_instr_per_s": 4.0e13}, "1": {"lane_instr_per_s": 6.0e13}, "2": {"lane_instr_per_s": 4.4e13}}}
+    cal = {"cus": 304, "mix": {"0": {"lane_instr_per_s": 3.6e13}, "1": {"lane_instr_per_s": 6.0e13}, "2": {"lane_instr_per_s": 4.4e13},
+                               "3": {"lane_instr_per_s": 4.0e13}}}
     sclk = {"avg_mhz": 2100.0}
     nominal, measured, at_clock, lanes, cus = b.valu_peaks(0, cal, sclk)
+    # packed kinds are priced against the micro-run of the kernels' OWN mix (3), not the pure VOP3P stream (0): VERDICT r5 item 5
     assert cus == 304 and lanes == 64.0 and nominal == 304 * 64.0 * 2.4e9 and measured == 4.0e13 and at_clock == 304 * 64.0 * 2.1e9
     assert b.valu_peaks(3, cal, None)[1:3] == (6.0e13, None) and b.valu_peaks(2, cal, sclk)[1] == 4.4e13
     assert b.valu_peaks(1, None, None)[:2] == (256 * 64.0 * 2.4e9, None)       # no calibration: the planning figures, and no measured peak
-    # the CPU team rule: the largest team within 10 % of the best rate
-    assert b.pick_team({128: 9.1, 64: 10.0, 32: 9.9, 16: 8.0}) == 128
+    # the CPU team rule: the best sustained rate (ties within 2 %: the smaller team)
+    assert b.pick_team({128: 9.1, 64: 10.0, 32: 9.9, 16: 8.0}) == 32
     assert b.pick_team({128: 5.0, 64: 10.0, 32: 9.5, 16: 8.0}) == 64
     events = [{"eff_kind": 0, "rows": 32, "lanes": 16, "nstripes": 2, "ms": 100.0, "chars": 5.12e8, "cells": 5.12e11, "subjects": 10 ** 6,
                "qlen": 1000, "t0_ms": 0.0, "t1_ms": 100.0}]
@@ -56,6 +58,47 @@ def test_roofline_arithmetic_uses_the_device_and_the_measured_peaks():
     assert valu["kernel_gcups"] == 5120.0 and valu["observed_sclk"] == sclk and valu["peak_at_observed_clock"] == round(304 * 64 * 2.1e9 / 1e12, 3)
     if valu["frac"] is not None:
         assert abs(valu["frac_of_measured_peak"] * 4.0e13 - valu["frac"] * 304 * 64.0 * 2.4e9) < 1e9
+        assert abs(valu["frac_of_128"] * 2 - valu["frac"]) < 2e-4      # the same achieved rate against 128 lanes/clk/CU
+
+
+def test_cpu_baseline_calibration_and_sampling_arithmetic():
+    """the team sweep measures what the legs measure — the whole query set, sustained — and the ragged
+    leg's timed sample is a uniform draw without the giants (checked apart)."""
+    b = load_bench()
+    queries = [np.zeros(n, np.int8) for n in (100, 300, 600)]
+    lengths = np.full(40000, 64, np.int32)
+    offsets = np.arange(40001, dtype=np.uint64) * 64
+    chars = np.zeros(40000 * 64, np.int8)
+    calls = []
+    clock = [0.0]
+    rate_of = {8: 8e9, 4: 4e9, 2: 2e9, 1: 0.5e9}   # cells per second a team sustains
+
+    def fake_scan(q, c, o, l, nt):
+        calls.append((len(q), len(l), nt))
+        clock[0] += len(q) * float(l.sum()) / rate_of[nt]
+    real = b.time.perf_counter
+    b.time.perf_counter = lambda: clock[0]
+    try:
+        sweep = b.calibrate_team(queries, chars, offsets, lengths, fake_scan, 8, min_seconds=0.5)
+    finally:
+        b.time.perf_counter = real
+    assert sorted(sweep) == [1, 2, 4, 8]
+    for nt, r in sweep.items():   # the rate of the whole set, warm-up call excluded ... close to what the fake sustains
+        assert abs(r - rate_of[nt] / 1e9) / (rate_of[nt] / 1e9) < 0.35, (nt, r)
+    # every team ran ALL queries, on a slice in proportion to the team (3 blocks of 32 subjects per thread)
+    for nt in (1, 2, 4, 8):
+        mine = [c for c in calls if c[2] == nt]
+        assert {c[0] for c in mine[1:]} == {100, 300, 600} and {c[1] for c in mine} == {nt * 3 * 32}
+    assert b.pick_team(sweep) == 8
+    c, o, l = b.calibration_sample(chars, offsets, lengths, 128)
+    assert len(l) == 128 * 3 * 32 and len(o) == len(l) + 1 and len(c) == len(l) * 64
+    assert len(b.calibration_sample(chars, offsets, lengths[:100], 128)[2]) == 100     # never more than the sample holds
+    pick, giants = b.cpu_sample_of(570000, 20000)
+    assert giants.tolist() == [569996, 569997, 569998, 569999] and len(np.intersect1d(pick, giants)) == 0
+    assert 19990 <= len(pick) <= 20000 and (np.diff(pick) > 0).all()
+    assert abs(pick.mean() / 570000 - 0.5) < 0.01     # uniform over the length-sorted DB
+    ncpu, quota = b.cpu_quota()
+    assert ncpu >= 1 and (quota is None or quota > 0)
 
 
 def test_bench_refuses_mismatched_world_size():
