@@ -264,7 +264,7 @@ def cpu_baseline(queries, chars, offsets, lengths, what, extra=None):
             raise SystemExit("bench.py: the two CPU ports disagree")
         scores = out
     if extra is not None and len(extra[2]):
-        more = [O.scan(q, *extra, m21=m, nthreads=best_nt, simd=True) for q in queries]
+        more = [O.scan(q, *extra[:3], m21=m, nthreads=best_nt, simd=True) for q in queries]
         scores = [np.concatenate([a, b]) for a, b in zip(scores, more)]
     # the reference's own scalar int32 DP (cudasw4.cuh:2331-2392 restated), one core, a few hundred subjects
     ns = min(300, len(lengths))
@@ -682,7 +682,7 @@ def shard_proxy(env, args, full_peak_gcups):
             if workload == "peak":
                 ok = ok and len(sc) == num and int(sc.min()) == int(sc.max()) == int(golden[qi])
             else:
-                want = O.scan(queries[qi], *sub, m21=m62, simd=True, nthreads=nt)
+                want = O.scan(queries[qi], *sub[:3], m21=m62, simd=True, nthreads=nt)
                 by_id = np.empty(num, dtype=np.int32)
                 by_id[ids] = sc
                 ok = ok and len(sc) == num and (by_id[pick[::-1]] == want).all()
@@ -719,7 +719,7 @@ def shard_proxy(env, args, full_peak_gcups):
                 ids, sc = drv.all_scores()
                 by_id = np.empty(num, dtype=np.int32)
                 by_id[ids] = sc
-                sok = bool((by_id[pick[::-1]] == O.scan(enc0, *sub, m21=m62, simd=True, nthreads=nt)).all())
+                sok = bool((by_id[pick[::-1]] == O.scan(enc0, *sub[:3], m21=m62, simd=True, nthreads=nt)).all())
                 one_at_a_time = lambda L: [drv.scan(q) for q in L]
                 drv.scan_stream(qs)
                 t_alone, t_stream, lists = 1e30, 1e30, []
