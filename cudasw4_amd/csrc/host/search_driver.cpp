@@ -1,9 +1,11 @@
 #include "search_driver.hpp"
 #include "parallel_blocks.hpp"
+#include "trace_ranges.hpp"
 
 #include <hip/hip_runtime_api.h>
 
 #include <sched.h>
+#include <time.h>
 
 #include <cctype>
 #include <cmath>
@@ -214,89 +216,33 @@ struct SearchDriver::Gpu {
     float* d_scores = nullptr;
     int32_t* d_ids = nullptr;
     int32_t* d_ovfPos = nullptr;
-    // [0]: subjects whose exact score reached the packed limit (the reference's statistic); [1 + k * kOvfLists + i]:
-    // length of overflow list i of batch k — every packed run of a batch has its own list, and the lists of one scan
-    // never share a counter, because the long-subject runs of a batch keep running next to the following batches
+    // one block of SW_BATCH_COUNTERS words per batch of a scan (block 0: the resident part; SW_BATCH_CNT_*: the reference's
+    // overflow statistic, the lengths of the batch's overflow lists — every packed launch has its own —, pipeline stages
+    // that gave up), and behind the blocks the bad-letter flag of streamed batches that are checked on the device
     int32_t* d_ovfCount = nullptr;
     size_t ovfCountCap = 0;
-    static constexpr int kOvfLists = 4;
-    // Launches that run concurrently need their own stripe-border scratch: slot 0 = work stream,
-    // slots 1.. = auxiliary streams (the reference round-robins 10 work streams, cudasw4.cuh:293,1745-1748)
-    static constexpr int kAux = 2;
-    hipStream_t aux[kAux] = {nullptr, nullptr};
-    hipEvent_t forkEvent[2] = {nullptr, nullptr}, joinEvent[kAux] = {nullptr, nullptr}, join2Event = nullptr;
-    // the auxiliary launches of a streamed batch read the batch's staging buffer: recorded after the last of them on each
-    // auxiliary stream, waited for before the buffer is overwritten
-    hipEvent_t auxDone[kSlots][kAux] = {};
-    bool auxPending[kSlots][kAux] = {};
-    bool auxUsed[kAux] = {false, false};  // this scan put work on the stream: joined before the top-K
-    // Start handshake (include/cudasw4_amd.h: sw_set_start_signal): every side launch adds 1 to *startSignal when its
-    // workgroups are resident; the bulk launch of the batch waits on the work stream for the count of side launches
-    // enqueued so far.  Without it the persistent bulk grid, once dispatched, holds every workgroup slot to its end and a
-    // side launch that loses the race for the first slots runs BEHIND it (tools/ubench/side_launch_probe.hip: 8 of 8).
-    // Windows of long subjects for short queries (include/cudasw4_amd.h: sw_window_overlap): per auxiliary stream one
-    // pinned host block (window offsets / lengths, first window and position of every subject) and its device copy with the
-    // windows' scores and ids behind it; the host block is rewritten by a later scan only after its copy has completed
-    struct WindowBuf {
-        char* h = nullptr; size_t hcap = 0;
-        char* d = nullptr; size_t dcap = 0;
-        hipEvent_t copied = nullptr;
-        bool used = false;
-    };
-    static constexpr int kWindowBufs = 4;  // per auxiliary stream: two queries in flight, two side launches each at most
-    WindowBuf winBuf[kAux][kWindowBufs];
-    int winNext[kAux] = {0, 0};
-    // CUDASW4_AMD_LATENCY_MODE=never|auto|always (0 / 1 / 2): partition 34 on wave-wide groups beside the bulk launch never / by
-    // the estimate of round 4 / always.  Round 5: never by default — the walk-time cut (kPipelineWalkShare) takes the subjects
-    // whose walk matters out of the scan launches, and what is left of partition 34 runs 40 % faster inside the bulk grid's
-    // 16-lane groups than on wave-wide ones (share 0.3: 1/4 shard 10 933 -> 10 959, 1/8 shard 9 168 -> 9 698 GCUPS,
-    // profiles/r05_shard_proxy.txt)
-    int latencyMode = 0;
-    int64_t latencyScans = 0;          // scans (batches) planned in latency mode, since the driver was created
-    // CUDASW4_AMD_ROWS=never|always|single (0 / 2 / 3): the row-parallel kernels for partition 35 never / whatever the time
-    // estimate says / only the one-workgroup form of round 4 (sw_scan_rows), by its time estimate.  Default (1): the
-    // pipelined form (sw_scan_rows_pipelined) whenever it applies, else the one-workgroup form by its time estimate.
-    int rowsMode = 1;
-    int64_t rowsLaunches = 0;          // side launches that ran row-parallel, since the driver was created
-    double pipelineShare = kPipelineWalkShare;  // CUDASW4_AMD_PIPELINE_SHARE (A/B measurements)
-    double pipelineShareFinal = kPipelineWalkShareFinal;  // CUDASW4_AMD_PIPELINE_SHARE_FINAL
-    int32_t pipelineMaxSubjects = kPipelineMaxSubjects;   // CUDASW4_AMD_PIPELINE_MAX_SUBJECTS
-    int32_t split34MaxLanes = 4;   // CUDASW4_AMD_SPLIT34_MAX_LANES: partition 34 keeps its own launch below a bulk launch on groups of at most this many lanes
-    double pipelineMinBulkSeconds = 0.0;
-    double pipelineRescoreShare = kPipelineRescoreShare;  // CUDASW4_AMD_PIPELINE_RESCORE_SHARE (A/B measurements; >= 100: never)
-    int64_t pipelineRescores = 0;      // re-score launches whose long subjects went ahead pipelined
-    int64_t pipelineLaunches = 0;      // ... of them as pipelines of one-wave stages (sw_scan_rows_pipelined)
-    int32_t* failSlot = nullptr;       // device word of the current scan that counts pipeline stages that gave up (d_ovfCount's last but one)
-    int32_t* pipeOverSlot = nullptr;   // ... and the one that counts pipelined subjects of packed partitions at or above the packed limit
-    bool windows = true;               // CUDASW4_AMD_NO_WINDOWS=1 turns them off (A/B measurements, tests)
-    bool windowsAlways = false;        // CUDASW4_AMD_WINDOWS=always: whenever the bound cuts a subject, whatever the time estimate says
-    int64_t windowLaunches = 0, windowCount = 0;  // side launches that ran on windows / windows scanned, since the driver was created
-    uint32_t* startSignal = nullptr;   // signal memory (hipMallocSignalMemory)
-    uint32_t sideLaunches = 0;         // enqueued since the signal was last zeroed
-    bool handshake = true;             // CUDASW4_AMD_NO_HANDSHAKE=1 turns it off (A/B measurements)
+    // The launches of a batch — bulk grid, side launches of the long subjects beside it, pipelines, windows, overflow
+    // re-score, re-score service — are the kernel library's business since round 6: one sw_scan_batch call per batch on
+    // the engine below (include/cudasw4_amd.h; side streams, signal memory and scratch buffers live there).
+    sw_batch* eng = nullptr;
+    static constexpr int kSide = 3;                       // side streams of an engine: two auxiliary, the service's
+    // the side launches of a streamed batch read the batch's staging buffer: recorded behind the last of them on each side
+    // stream (sw_batch_side_events), waited for before the buffer is overwritten
+    hipEvent_t auxDone[kSlots][kSide] = {};
+    bool auxPending[kSlots][kSide] = {};
+    hipEvent_t join2Event = nullptr;
+    bool handshake = false;            // the engine's start handshake passed its probe (sw_batch_handshake_active)
+    int sideReserve = 32;              // CUDASW4_AMD_SIDE_RESERVE: slots the bulk grid leaves free when two queries are in flight and the batch has side work
+    int testLoseSideLaunch = 0;        // CUDASW4_AMD_TEST_LOSE_SIDE_LAUNCH=n (tests of the watchdog)
     bool stream2Used = false;
     bool firstBatchStaged = false;  // staging buffer slotBase already holds the first batch of the next streamed scan
     size_t slotBase = 0;            // staging buffer of the first batch of the next streamed scan
     bool slotUsed[kSlots] = {};     // the buffer has been scanned from since the DB was set: scanned[] is valid
     bool prefetchNext = true;       // CUDASW4_AMD_NO_NEXT_PREFETCH=1 turns that off (A/B measurements)
     bool twoWorkStreams = true;   // CUDASW4_AMD_ONE_WORK_STREAM=1: every batch of a streamed scan on the work stream (A/B measurements)
-    void* d_temp[kAux + 3] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // work stream, auxiliary streams, stream2, re-score service
-    size_t tempBytes[kAux + 3] = {0, 0, 0, 0, 0};
-    // Re-score service (include/cudasw4_amd.h: sw_rescore_service): a few workgroups on a stream of their own re-score
-    // the bulk launch's overflow list while the bulk launch fills it; the work stream raises *doneSignal to doneSeq behind
-    // the bulk launch.  On while recent scans re-scored anything (a DB without relatives of its queries never pays the
-    // service's workgroup slots); CUDASW4_AMD_RESCORE_SERVICE=0|1 forces it off / on.
-    hipStream_t svcStream = nullptr;
-    hipEvent_t svcJoin = nullptr;
-    uint32_t* doneSignal = nullptr;
-    uint32_t doneSeq = 0;
-    bool svcUsed = false;
-    bool svcConcurrent = false;        // probed at construction: the service stream runs beside the auxiliary and work streams
-    int svcForce = -1;
-    int quietScans = 0;                // consecutive scans without a re-scored subject
-    int64_t serviceLaunches = 0;
-    double rescoredEma = 8.0;          // recent re-scored subjects per scan: sizes the service (2, 4 or 8 workgroups)
-    int serviceWorkgroups() const { return rescoredEma < 8.0 ? 2 : rescoredEma < 64.0 ? 4 : 8; }
+    // host copies of what the engine plans with: lengths and byte offsets of the shard's subjects of partitions 34 / 35
+    std::vector<int32_t> longLengths;
+    std::vector<uint64_t> longOffsets;
     // Tail hand-over between two queries in flight (include/cudasw4_amd.h: sw_set_dry_signal).  A query that is submitted
     // while the one before is still running goes to the OTHER lane: a second context (its own profile and work counters),
     // the second work stream with its scratch, and second score / id / overflow / top-K arrays (Lane below; the first set is
@@ -313,6 +259,7 @@ struct SearchDriver::Gpu {
     // 1000-residue queries: -5 %): the reserve stays 0.
     struct Lane {
         sw_ctx* ctx = nullptr;
+        sw_batch* eng = nullptr;
         float* d_scores = nullptr;
         int32_t* d_ids = nullptr;
         int32_t* d_ovfPos = nullptr;
@@ -325,14 +272,11 @@ struct SearchDriver::Gpu {
         int32_t* d_topI = nullptr;
         int topCapacity = 0;
     } lane1;
-    static constexpr int kLaneReserve = 0;
-    int laneReserve = kLaneReserve;    // CUDASW4_AMD_LANE_RESERVE (A/B measurements)
-    // ... but with two queries in flight AND side work (pipelined subjects, side launches, their re-scores) a few slots are
-    // worth keeping: whatever is enqueued while the other lane's persistent grid holds every register of every SIMD — a
-    // re-score launch, the stages of the next query's long subjects, even a one-workgroup helper kernel — is dispatched
-    // only as that grid drains, and the query it belongs to completes that much later (1/4 and 1/8 Swiss-Prot-like shards:
-    // +3 ... +4 % with 32 of ~768 slots, profiles/r05_shard_proxy.txt).  CUDASW4_AMD_SIDE_RESERVE.
-    int sideReserve = 32;
+    // With two queries in flight AND side work (pipelined subjects, side launches, their re-scores) a few workgroup slots
+    // are worth keeping free beside the bulk grids (sideReserve above): whatever is enqueued while the other lane's
+    // persistent grid holds every register of every SIMD — a re-score launch, the stages of the next query's long subjects,
+    // even a one-workgroup helper kernel — is dispatched only as that grid drains, and the query it belongs to completes
+    // that much later (1/4 and 1/8 Swiss-Prot-like shards: +3 ... +4 % with 32 of ~768 slots, profiles/r05_shard_proxy.txt).
     bool laneGate = true;              // CUDASW4_AMD_TAIL_GATE=0: second lane without the dry-signal gate (A/B measurements)
     static constexpr size_t kLaneMaxRounds = 20;
     static constexpr double kLaneMaxSeconds = 0.008;   // ... or scans of at most this long, at 10 TCUPS
@@ -352,10 +296,8 @@ struct SearchDriver::Gpu {
     int64_t laneOverlaps = 0;          // queries whose bulk launch was gated on the one before
     void swapLane() {
         std::swap(ctx, lane1.ctx);
+        std::swap(eng, lane1.eng);
         std::swap(stream, stream2);
-        std::swap(d_temp[0], d_temp[kAux + 1]);
-        std::swap(tempBytes[0], tempBytes[kAux + 1]);
-        std::swap(forkEvent[0], forkEvent[1]);
         std::swap(d_scores, lane1.d_scores);
         std::swap(d_ids, lane1.d_ids);
         std::swap(d_ovfPos, lane1.d_ovfPos);
@@ -375,8 +317,7 @@ struct SearchDriver::Gpu {
         LaneGuard(Gpu& gpu, int lane) : g(gpu), swapped(lane == 1) { if (swapped) g.swapLane(); }
         ~LaneGuard() { if (swapped) g.swapLane(); }
     };
-    size_t tempCap = SIZE_MAX;  // plan_residency: what each of them may grow to inside the memory limit
-    static_assert(kAux + 3 == kTempStreams, "plan_residency budgets the scratch of this many streams");
+    size_t tempCap = SIZE_MAX;  // plan_residency: what each of the engine's scratch buffers may grow to inside the memory limit
     void* d_topkTemp = nullptr;
     size_t topkTempBytes = 0;
     float* d_topS = nullptr;
@@ -473,13 +414,7 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
     std::string why;
     if (!kernels_.valid(&why)) throw std::runtime_error("Invalid kernel type configuration: " + why);
     if (deviceIds.empty()) throw std::runtime_error("No GPU found");
-    std::string order = "WCAB";  // creation order of the streams of a GPU (below)
-    if (const char* e = std::getenv("CUDASW4_AMD_STREAM_ORDER")) {
-        std::string sorted = e;
-        std::sort(sorted.begin(), sorted.end());
-        if (sorted != "ABCW") throw std::runtime_error("CUDASW4_AMD_STREAM_ORDER must be a permutation of WCAB");
-        order = e;
-    }
+    if (const char* e = std::getenv("CUDASW4_AMD_WATCHDOG_SECONDS")) watchdogSeconds_ = std::max(0.0, std::atof(e));
     for (int dev : deviceIds) {
         auto g = std::make_unique<Gpu>();
         g->index = int(gpus_.size());
@@ -488,103 +423,40 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
         g->use();
         SWCHECK(sw_ctx_create(dev, &g->ctx));
         SWCHECK(sw_set_matrix(g->ctx, matrix_.m.data(), matrix_.dim));
-        // The auxiliary streams carry the few long subjects that must overlap the bulk launch.  The runtime multiplexes
-        // streams of one priority onto GPU_MAX_HW_QUEUES (4) hardware queues, and two streams that share a queue
-        // serialise (measured: the giant-subject launch in front of the bulk launch, 167 instead of 106 ms for a
-        // 5478-residue query on the Swiss-Prot-like DB).  High-priority streams come from a queue pool of their own, so
-        // they never share a hardware queue with the work stream — and the giants get their workgroups first.
-        // Since round 4 a resident scan needs ONE of them (the giants; partition 34 runs inside the bulk grid,
-        // plan_launch_runs), so the two auxiliary streams can no longer end up serialised behind each other either.
-        // CUDASW4_AMD_STREAM_ORDER permutes the creation order (letters W work, C copy, A / B auxiliary) for the test
-        // that shows the scan rate no longer depends on it.
-        int prioLow = 0, prioHigh = 0;
-        HIPCHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-        for (char c : order) {
-            if (c == 'W') HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-            else if (c == 'C') HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
-            else HIPCHECK(hipStreamCreateWithPriority(&g->aux[c - 'A'], hipStreamNonBlocking, prioHigh));
-        }
+        HIPCHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
         HIPCHECK(hipHostMalloc(&g->h_pad, 64));
         std::memset(g->h_pad, kOtherCode, 64);
-        for (auto& e : g->forkEvent) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&g->join2Event, hipEventDisableTiming));
         HIPCHECK(hipEventCreate(&g->scanStartEv));
         HIPCHECK(hipEventCreate(&g->recordRefEv));
         for (auto& r : g->res) HIPCHECK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
-        for (int i = 0; i < Gpu::kAux; i++) HIPCHECK(hipEventCreateWithFlags(&g->joinEvent[i], hipEventDisableTiming));
         for (int i = 0; i < Gpu::kSlots; i++) {
             HIPCHECK(hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&g->scanned[i], hipEventDisableTiming));
-            for (int a = 0; a < Gpu::kAux; a++) HIPCHECK(hipEventCreateWithFlags(&g->auxDone[i][a], hipEventDisableTiming));
+            for (int a = 0; a < Gpu::kSide; a++) HIPCHECK(hipEventCreateWithFlags(&g->auxDone[i][a], hipEventDisableTiming));
         }
-        {
-            int canWait = 0;
-            (void)hipDeviceGetAttribute(&canWait, hipDeviceAttributeCanUseStreamWaitValue, dev);
-            const char* no = std::getenv("CUDASW4_AMD_NO_HANDSHAKE");
-            g->handshake = canWait != 0 && !(no && no[0] == '1');
-            if (g->handshake) {
-                if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g->startSignal), 8, hipMallocSignalMemory) != hipSuccess ||
-                    hipExtMallocWithFlags(reinterpret_cast<void**>(&g->doneSignal), 8, hipMallocSignalMemory) != hipSuccess) {
-                    (void)hipGetLastError();
-                    (void)hipFree(g->startSignal);
-                    g->startSignal = nullptr;
-                    g->doneSignal = nullptr;
-                    g->handshake = false;
-                } else {
-                    *g->startSignal = 0;
-                    *g->doneSignal = 0;
-                    HIPCHECK(hipStreamCreateWithPriority(&g->svcStream, hipStreamNonBlocking, prioHigh));
-                    HIPCHECK(hipEventCreateWithFlags(&g->svcJoin, hipEventDisableTiming));
-                    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g->drySignal), 8, hipMallocSignalMemory) != hipSuccess) {
-                        (void)hipGetLastError();
-                        g->drySignal = nullptr;
-                    } else {
-                        *g->drySignal = 0;
-                    }
-                }
+        // the batch engine of this context: side streams (high priority: a pool of hardware queues of their own), start /
+        // done signals, the probes of what the runtime really does (include/cudasw4_amd.h: sw_batch_create)
+        SWCHECK(sw_batch_create(g->ctx, g->stream, &g->eng));
+        g->handshake = sw_batch_handshake_active(g->eng) == 1;
+        if (verbose_ && !g->handshake) std::cout << "GPU " << dev << ": start handshake, re-score service and tail hand-over off (plain stream order)\n";
+        if (g->handshake) {
+            // tail hand-over between two queries in flight: the dry signal of a bulk launch (Gpu::Lane)
+            if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g->drySignal), 8, hipMallocSignalMemory) != hipSuccess) {
+                (void)hipGetLastError();
+                g->drySignal = nullptr;
+            } else {
+                *g->drySignal = 0;
             }
             if (const char* e = std::getenv("CUDASW4_AMD_TAIL_OVERLAP")) g->laneForce = e[0] == '1' ? 1 : 0;
-            if (const char* e = std::getenv("CUDASW4_AMD_LANE_RESERVE")) g->laneReserve = std::max(0, std::atoi(e));
-            if (const char* e = std::getenv("CUDASW4_AMD_SIDE_RESERVE")) g->sideReserve = std::max(0, std::atoi(e));
             if (const char* e = std::getenv("CUDASW4_AMD_TAIL_GATE")) g->laneGate = !(e[0] == '0');
-            if (const char* e = std::getenv("CUDASW4_AMD_RESCORE_SERVICE")) g->svcForce = e[0] == '1' ? 1 : 0;
         }
-        if (const char* e = std::getenv("CUDASW4_AMD_LATENCY_MODE")) g->latencyMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "auto" ? 1 : 0;
-        if (const char* e = std::getenv("CUDASW4_AMD_ROWS")) g->rowsMode = std::string(e) == "never" ? 0 : std::string(e) == "always" ? 2 : std::string(e) == "single" ? 3 : 1;
-        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE")) g->pipelineShare = std::max(0.01, std::atof(e));
-        if (const char* e = std::getenv("CUDASW4_AMD_SPLIT34_MAX_LANES")) g->split34MaxLanes = std::atoi(e);
-        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_MAX_SUBJECTS")) g->pipelineMaxSubjects = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_SHARE_FINAL")) g->pipelineShareFinal = std::max(0.01, std::atof(e));
-        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_MIN_BULK_MS")) g->pipelineMinBulkSeconds = std::max(0.0, std::atof(e)) * 1e-3;
-        if (const char* e = std::getenv("CUDASW4_AMD_PIPELINE_RESCORE_SHARE")) g->pipelineRescoreShare = std::max(0.001, std::atof(e));
-        if (const char* e = std::getenv("CUDASW4_AMD_NO_WINDOWS")) g->windows = !(e[0] == '1');
-        if (const char* e = std::getenv("CUDASW4_AMD_WINDOWS")) g->windowsAlways = std::string(e) == "always";
+        if (const char* e = std::getenv("CUDASW4_AMD_SIDE_RESERVE")) g->sideReserve = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
         if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
-        g->ovfCountCap = 3 + Gpu::kOvfLists + 1;
+        g->ovfCountCap = 2 * SW_BATCH_COUNTERS + 1;
         HIPCHECK(hipMalloc(&g->d_ovfCount, g->ovfCountCap * sizeof(int32_t)));
-        // the service's polling kernel must not share a hardware queue with the side launches the bulk launch waits for
-        if (g->svcStream) {
-            g->svcConcurrent = sw_streams_run_concurrently(g->ctx, g->svcStream, g->aux[0]) == 1 &&
-                               sw_streams_run_concurrently(g->ctx, g->svcStream, g->aux[1]) == 1 &&
-                               sw_streams_run_concurrently(g->ctx, g->svcStream, g->stream) == 1;
-        }
-        // The handshake itself, once, bounded: the bulk launch waits in hipStreamWaitValue32 for a value only
-        // device code raises, the re-score service polls until the work stream writes behind the bulk launch.  Where
-        // kernels are serialised — rocprofv3 --pmc, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING — or wait-value packets are
-        // not released, that hangs the stream without a diagnostic: fall back to plain stream order (no service, one lane)
-        if (g->handshake) {
-            auto on = [](const char* name) { const char* e = std::getenv(name); return e && e[0] && e[0] != '0' && e[0] != 'f' && e[0] != 'F'; };
-            const char* why = nullptr;
-            if (on("ROCPROF_COUNTER_COLLECTION")) why = "rocprofv3 counter collection serialises kernels";
-            else if (on("AMD_SERIALIZE_KERNEL")) why = "AMD_SERIALIZE_KERNEL is set";
-            else if (on("HIP_LAUNCH_BLOCKING")) why = "HIP_LAUNCH_BLOCKING is set";
-            else if (sw_probe_handshake(g->ctx, g->aux[0], g->stream, g->startSignal) != 1) why = "the probe found that a gated launch does not start beside its side launch";
-            if (why) {
-                g->handshake = false;
-                if (verbose_) std::cout << "GPU " << dev << ": start handshake, re-score service and tail hand-over off (" << why << ")\n";
-            }
-        }
         g->live.hold(dev);
         gpus_.push_back(std::move(g));
     }
@@ -604,25 +476,18 @@ SearchDriver::~SearchDriver() {
             (void)hipHostFree(g.h_pinned[i]);
             if (g.copied[i]) (void)hipEventDestroy(g.copied[i]);
             if (g.scanned[i]) (void)hipEventDestroy(g.scanned[i]);
-            for (int a = 0; a < Gpu::kAux; a++)
+            for (int a = 0; a < Gpu::kSide; a++)
                 if (g.auxDone[i][a]) (void)hipEventDestroy(g.auxDone[i][a]);
         }
         (void)hipHostFree(g.h_pad);
-        if (g.startSignal) (void)hipFree(g.startSignal);
-        if (g.doneSignal) (void)hipFree(g.doneSignal);
-        if (g.drySignal) (void)hipFree(g.drySignal);
         if (g.laneSwapped) g.swapLane();
+        if (g.eng) sw_batch_destroy(g.eng);
+        if (g.lane1.eng) sw_batch_destroy(g.lane1.eng);
+        if (g.drySignal) (void)hipFree(g.drySignal);
         (void)hipFree(g.lane1.d_scores); (void)hipFree(g.lane1.d_ids); (void)hipFree(g.lane1.d_ovfPos); (void)hipFree(g.lane1.d_ovfCount);
         (void)hipFree(g.lane1.d_topkTemp); (void)hipFree(g.lane1.d_topS); (void)hipFree(g.lane1.d_topI);
         if (g.lane1.scanStartEv) (void)hipEventDestroy(g.lane1.scanStartEv);
         if (g.lane1.ctx) sw_ctx_destroy(g.lane1.ctx);
-        if (g.svcStream) (void)hipStreamDestroy(g.svcStream);
-        if (g.svcJoin) (void)hipEventDestroy(g.svcJoin);
-        for (auto& per : g.winBuf)
-            for (auto& wb : per) {
-                (void)hipHostFree(wb.h); (void)hipFree(wb.d);
-                if (wb.copied) (void)hipEventDestroy(wb.copied);
-            }
         for (hipEvent_t e : g.batchEv) (void)hipEventDestroy(e);
         if (g.scanStartEv) (void)hipEventDestroy(g.scanStartEv);
         if (g.recordRefEv) (void)hipEventDestroy(g.recordRefEv);
@@ -633,13 +498,6 @@ SearchDriver::~SearchDriver() {
         for (auto* v : {&g.timed, &g.freeTimed})
             for (TimedLaunch& t : *v) { (void)hipEventDestroy(t.ev0); (void)hipEventDestroy(t.ev1); }
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos); (void)hipFree(g.d_ovfCount);
-        for (void* t : g.d_temp) (void)hipFree(t);
-        for (int i = 0; i < Gpu::kAux; i++) {
-            if (g.aux[i]) (void)hipStreamDestroy(g.aux[i]);
-            if (g.joinEvent[i]) (void)hipEventDestroy(g.joinEvent[i]);
-        }
-        for (hipEvent_t e : g.forkEvent)
-            if (e) (void)hipEventDestroy(e);
         if (g.join2Event) (void)hipEventDestroy(g.join2Event);
         (void)hipFree(g.d_topkTemp); (void)hipFree(g.d_topS); (void)hipFree(g.d_topI);
         if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -745,6 +603,17 @@ void SearchDriver::setDatabase(std::shared_ptr<Database> db) {
         g.localOffsets[g.numLocal] = charPos;
         g.localChars = charPos;
         g.localResidues = residues;
+        // what the batch engine plans the long subjects with (pipelines, windows): lengths and byte offsets of the shard's
+        // subjects of partitions 34 / 35 — a few per cent of a real DB's subjects
+        {
+            const size_t from = g.localBegin[kNumLengthPartitions - 2];
+            g.longLengths.resize(g.numLocal - from);
+            g.longOffsets.resize(g.numLocal - from);
+            for (size_t i = from; i < g.numLocal; i++) {
+                g.longLengths[i - from] = db_->length(size_t(g.toGlobal(int64_t(i))));
+                g.longOffsets[i - from] = g.localOffsets[i];
+            }
+        }
 
         const size_t n = std::max<size_t>(g.numLocal, 1);
         (void)hipFree(g.d_scores); (void)hipFree(g.d_ids); (void)hipFree(g.d_ovfPos);
@@ -963,554 +832,120 @@ void SearchDriver::prefetchDBToGpus() {
     });
 }
 
-namespace {
-
-void* ensure_temp(void*& ptr, size_t& have, size_t need, size_t cap) {
-    need = std::min(need, cap);
-    if (need > have) {
-        (void)hipFree(ptr);
-        ptr = nullptr;
-        have = 0;
-        HIPCHECK(hipMalloc(&ptr, need));
-        have = need;
-    }
-    return ptr;
-}
-
-}  // namespace
-
-// Enqueue the scan of the shard-local subjects [lbegin, lend) whose chars start at `chars` (device) as batch `batch` of
-// the current query, staged in buffer `slot` (-1: resident chars).  The run with the most subjects goes to the work stream
-// together with its re-score; the others (few long subjects) are launched on the auxiliary streams, re-scored there, and
-// NOT joined at the end of the batch: a giant subject of a Swiss-Prot-like DB keeps one wave busy for as long as the whole
-// batch takes (61 ms for a 5478-residue query), and joining it per batch put that time in front of every following batch
-// (streamed Swiss-Prot-like DB: 133 instead of 107 ms for that query).  scanOnGpu joins the auxiliary streams before the
-// top-K; a staging buffer is overwritten only after the auxiliary launches that read it (auxDone).
+// Enqueue the scan of the shard-local subjects [lbegin, lend) whose chars start at `chars` (device) as batch `batch` of the
+// current query, staged in buffer `slot` (-1: resident chars): ONE call of the kernel library (sw_scan_batch: the body of
+// the reference's runAlignmentKernels and its overflow block, cudasw4.cuh:1742-2172).  What stays here is what only the
+// driver knows: where the batch's partitions begin, how long its long subjects are, which work stream and counter block
+// the batch gets, whether a second query is in flight (tail hand-over), and the bookkeeping of a staging buffer's readers.
+// The side launches of a batch are NOT joined at its end — a giant subject keeps one wave busy for as long as the whole
+// batch takes — but before the top-K (join_aux); a staging buffer is overwritten only after the side launches that read it.
 template <class GpuT>
 static void enqueue_batch(GpuT& g, const int8_t* chars, size_t lbegin, size_t lend, const Database& db,
                           const KernelTypeConfig& kt, const MemoryConfig& mem, int gop, int gex, int recordMode,
                           size_t batch, int slot, bool second) {
-    // every other batch of a streamed scan runs on stream2 with a scratch of its own (see Gpu::stream2)
-    const hipStream_t work = second ? g.stream2 : g.stream;
-    const int workTemp = second ? GpuT::kAux + 1 : 0;
-    const hipEvent_t fork = g.forkEvent[second ? 1 : 0];
-    // Latency mode.  Partition 34 (1281 ... 8000 residues) normally joins the bulk launch from 512 subjects up: one grid of
-    // 16-lane groups that takes the long subjects first.  A 16-lane group walks an 8000-residue subject for 8000 x
-    // (stripes of the query) steps of ~0.29 us — 26 ms for a 5 478-residue query — and on a SHARD of a real DB the whole bulk
-    // launch is shorter than that (71 000 Swiss-Prot-like subjects: 15 ms of work, measured 50 ms).  Then the partition
-    // keeps a launch of its own on wave-wide groups (a subject done 3 x sooner, sw_set_long16_min) beside the bulk launch:
-    // 71 250-subject shard, 20 queries, 224 -> 192 ms per pass (tools/shard_proxy.sh).  CUDASW4_AMD_LATENCY_MODE=never|always.
-    // Pipelined subjects (round 5; include/cudasw4_amd.h: sw_scan_rows_pipelined).  A subject is ONE alignment group's walk,
-    // stripe after stripe of the query, whatever the GPU's size — and possibly a second, slower walk when a packed launch
-    // flags it for the 32-bit re-score.  On a whole DB those walks hide beside the bulk launch; on a shard (what each of N
-    // GPUs gets) the bulk launch shrinks and they do not: a 1/8 Swiss-Prot-like shard scans a 5 478-residue query in 15 ms,
-    // while an 8 000-residue subject of partition 34 walks for 14 ms on a wave-wide group and a 5 500-residue relative of the
-    // query is re-scored for 16 ms behind it.  So the LONGEST subjects of the range — every subject whose lone walk would
-    // take more than kPipelineWalkShare of the bulk launch's estimated time, at most kPipelineMaxSubjects — leave the scan
-    // launches: they run as pipelines of one-wave stages over many SIMDs (~0.3 us per query row whatever the
-    // subject's length, exact 32-bit scores, nothing to re-score), partition by partition (each part on an auxiliary stream).
-    // (CUDASW4_AMD_WINDOWS=always: the giants are wanted as windows — tests of that path)
-    const bool pipelineWanted = (g.rowsMode == 1 || g.rowsMode == 2) && gop <= gex && lend > lbegin && !g.windowsAlways;
-    // a wave-wide group's step of R rows per lane: ~(6.5 R + 19) instructions at ~6 cycles each beside a busy grid
-    const double qrows64 = std::ceil(double(g.qlen) / 64.0);
-    const double colSeconds = std::ceil(qrows64 / 8.0) * (6.5 * std::min(qrows64, 8.0) + 19.0) * 6.0 / 2.4e9;
-    const double bulkSeconds = double(g.localOffsets[lend] - g.localOffsets[lbegin]) * double(g.qlen) / 10e12;
-    const bool pipelineOk = pipelineWanted;
-    // Each of the two partitions keeps its shorter subjects [b, cut) in the scan launches and hands [cut, e) to the pipeline.
-    // A subject of partition 34 scored in a packed kind may have to be walked twice (the re-score follows the bulk launch),
-    // hence the smaller share; a walk of partition 35 in a 32-bit kind is final, and up to kPipelineWalkShareFinal of the
-    // bulk's time it hides beside the bulk launch it starts with (two queries in flight / the default stream, shares 0.3 / 0.55 /
-    // 0.8 for partition 35: whole Swiss-Prot-like DB 11 160 / 11 200 / 11 244 and 11 254 / 11 294 / 11 360 GCUPS, 1/2 shard
-    // 11 109 / 11 040 / 11 049, 1/4 10 870 / 10 901 / 10 911, 1/8 9 694 / 9 681 / 9 724 — profiles/r05_shard_proxy.txt).
-    constexpr int kSmallLong = kNumLengthPartitions - 2, kLargeLong = kNumLengthPartitions - 1;
-    const size_t b34 = std::max(lbegin, std::min(lend, g.localBegin[kSmallLong]));
-    const size_t b35 = std::max(lbegin, std::min(lend, g.localBegin[kLargeLong]));
-    size_t cut34 = b35, cut35 = lend;
-    // Below a bulk launch on 4-lane groups (very short queries, sw_api.hip: lanes_for_partition) partition 34 keeps a launch
-    // of its own on 16-lane groups: a quad's column costs ~(6.5 R + 19) instructions with R a quarter of the query, and the
-    // longest subject's walk bounds a launch — a 4 700-residue subject merged into a 96-residue query's launch on quads
-    // walks for 3.6 ms, the launch's instructions take 1.8 ms (SQ_BUSY_CYCLES 53 %, profiles/r05_short_queries.txt).
-    // (Handing more of partition 34 to the pipeline instead — a walk estimate of the short groups' own, ~11 cycles per
-    // instruction as measured — costs more than the tail it removes: 144 residues 9 440 -> 8 621 GCUPS, 192: 10 104 -> 9 379.)
-    bool split34 = false;
-    if (b35 > b34 && b34 > lbegin && kt.for_partition(kSmallLong - 1) == kt.for_partition(kSmallLong)) {
-        int32_t ek = 0, r33 = 0, ns33 = 0, l33 = 16;
-        SWCHECK(sw_plan_launch(g.ctx, int(kt.for_partition(kSmallLong)), kSmallLong - 1, int32_t(b34 - lbegin),
-                               int32_t(db.length(size_t(g.toGlobal(int64_t(b34 - 1))))), &ek, &r33, &ns33, &l33));
-        split34 = l33 <= g.split34MaxLanes;
+    TraceRange traceBatch("batch %d: subjects [%ld, %ld) %s", int(batch), long(lbegin), long(lend), slot < 0 ? "resident" : "streamed");
+    if (lend <= lbegin) return;
+    if (lend - lbegin > size_t(INT32_MAX)) throw std::runtime_error("batch too large for 32-bit positions");
+    constexpr int kSmallLong = kNumLengthPartitions - 2;
+    int32_t partBegin[kNumLengthPartitions + 1], partMax[kNumLengthPartitions];
+    for (int p = 0; p <= kNumLengthPartitions; p++)
+        partBegin[p] = int32_t(std::min(std::max(g.localBegin[p], lbegin), lend) - lbegin);
+    for (int p = 0; p < kNumLengthPartitions; p++) {
+        const size_t e = std::min(g.localBegin[p + 1], lend), b = std::max(g.localBegin[p], lbegin);
+        partMax[p] = e > b ? int32_t(db.length(size_t(g.toGlobal(int64_t(e - 1))))) : 0;
     }
-    if (pipelineOk) {
-        auto first_longer = [&](size_t a, size_t b, double maxWalk) {   // ascending lengths within a partition
-            while (a < b) {
-                const size_t mid = a + (b - a) / 2;
-                if (double(db.length(size_t(g.toGlobal(int64_t(mid))))) > maxWalk) b = mid; else a = mid + 1;
-            }
-            return a;
-        };
-        const double share35 = is_packed(kt.for_partition(kLargeLong)) ? g.pipelineShare : std::max(g.pipelineShare, g.pipelineShareFinal);
-        const double walks = bulkSeconds / colSeconds;
-        const bool always = g.rowsMode == 2;   // "always": every subject of partition 35, whatever the estimate says
-        cut34 = std::max(first_longer(b34, b35, always ? 8000.0 : g.pipelineShare * walks), b35 - std::min<size_t>(b35 - b34, size_t(g.pipelineMaxSubjects)));
-        cut35 = std::max(first_longer(b35, lend, always ? 8000.0 : share35 * walks), lend - std::min<size_t>(lend - b35, size_t(g.pipelineMaxSubjects)));
-        if (int64_t(db.length(size_t(g.toGlobal(int64_t(lend - 1))))) * int64_t(-gex) >= (int64_t(1) << 28)) { cut34 = b35; cut35 = lend; }
+    sw_batch_args a{};
+    a.kinds[0] = int(kt.singlePassType); a.kinds[1] = int(kt.manyPassType_small);
+    a.kinds[2] = int(kt.manyPassType_large); a.kinds[3] = int(kt.overflowType);
+    a.chars = chars;
+    a.offsets = g.d_offsets + lbegin;
+    a.lengths = g.d_lengths + lbegin;
+    a.n = int32_t(lend - lbegin);
+    a.part_begin = partBegin;
+    a.part_maxlen = partMax;
+    const size_t longFrom = std::max(lbegin, g.localBegin[kSmallLong]);   // first subject of partitions 34 / 35 inside the batch
+    if (longFrom < lend && !g.longLengths.empty()) {
+        a.long_lengths = g.longLengths.data() + (longFrom - g.localBegin[kSmallLong]);
+        a.long_offsets = g.longOffsets.data() + (longFrom - g.localBegin[kSmallLong]);
+        a.long_offsets_bias = g.localOffsets[lbegin];
     }
-    // the parts, longest partition first; a part whose hand-off array does not fit the scratch budget stays with the scan
-    // launches
-    struct PipePart { size_t begin, end; int part_id; int32_t maxlen; size_t need; };
-    std::vector<PipePart> pipeParts;
-    {
-        const size_t pb[2] = {cut35, cut34}, pe[2] = {lend, b35};
-        for (int k = 0; k < 2; k++) {
-            const size_t b = pb[k], e = pe[k];
-            if (e <= b) continue;
-            const int32_t maxlen = int32_t(db.length(size_t(g.toGlobal(int64_t(e - 1)))));
-            const size_t need = sw_scan_rows_pipelined_temp_bytes(g.ctx, int32_t(e - b), maxlen);
-            if (need == 0 || need > std::min(mem.maxTempBytes, g.tempCap) || pipeParts.size() >= size_t(GpuT::kAux)) continue;
-            pipeParts.push_back(PipePart{b, e, kLargeLong - k, maxlen, need});
-        }
-    }
-    // (CUDASW4_AMD_PIPELINE_MIN_BULK_MS, default 0 = off: scans estimated shorter than this keep at most 256 stages.  Built
-    // when a stream of 48-residue queries on the whole Swiss-Prot-like DB — 19 giants, 665 stages — ran 9 % slower with the
-    // pipelines than with the windows of round 4; the cause turned out to be four queries in flight instead of two, and
-    // with two the rule only costs: 1/8 shard 9 629 GCUPS without it, 9 449 / 9 299 / 9 359 at 0.6 / 1.2 / 2 ms, the 48-residue
-    // stream 8 161 against 8 153 ... 8 302, profiles/r05_short_queries.txt)
-    if (g.rowsMode != 2 && bulkSeconds < g.pipelineMinBulkSeconds) {
-        size_t stages = 0, keep = 0;   // the parts from the longest partition down while they stay below 256 stages
-        for (const PipePart& pp : pipeParts) {
-            stages += (pp.end - pp.begin) * size_t((pp.maxlen + 1023) / 1024);
-            if (stages > 256) break;
-            keep++;
-        }
-        pipeParts.resize(keep);
-    }
-    cut34 = b35; cut35 = lend;   // what the scan launches below cover: [lbegin, cut34) and [b35, cut35)
-    for (const PipePart& pp : pipeParts) (pp.part_id == kLargeLong ? cut35 : cut34) = pp.begin;
-    const size_t scanEnd = cut35 > b35 ? cut35 : cut34;   // (contiguous unless part of partition 34 is pipelined and part of 35 is not)
-    bool latencyMode = g.latencyMode == 2;
-    if (g.latencyMode == 1 && slot < 0 && cut34 > lbegin) {
-        const size_t e34 = cut34;
-        if (e34 > b34 && e34 - b34 >= kLongPartitionMergeMin) {
-            const double longest = double(db.length(size_t(g.toGlobal(int64_t(e34 - 1)))));
-            // a step of a 16-lane group with R rows per lane: ~(6.5 R + 19) instructions at three waves per SIMD
-            const double rows16 = std::min(32.0, std::ceil(double(g.qlen) / 16.0));
-            const double tLong16 = longest * std::ceil(double(g.qlen) / 512.0) * (6.5 * rows16 + 19.0) * 3.1 / 2.4e9;
-            const double tAll = double(g.localOffsets[scanEnd] - g.localOffsets[lbegin]) * double(g.qlen) / 1e13;
-            // (queries below 256 residues leave a wave-wide group fewer than four rows per lane: not for them)
-            latencyMode = g.qlen >= 256 && tLong16 >= 0.5 * tAll;
-        }
-    }
-    SWCHECK(sw_set_long16_min(g.ctx, latencyMode ? INT32_MAX : -1));
-    auto length_at = [&](size_t pos) { return db.length(size_t(g.toGlobal(int64_t(pos)))); };
-    const size_t mergeMin = (latencyMode || split34) ? SIZE_MAX : kLongPartitionMergeMin;
-    std::vector<LaunchRun> runs;
-    if (cut34 == b35) runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, cut35, length_at, mergeMin);
-    else {   // the longest of partition 34 are pipelined, the shortest of partition 35 are not: two ranges
-        runs = plan_launch_runs(kt, g.localBegin.data(), lbegin, cut34, length_at, mergeMin);
-        if (cut35 > b35) {
-            const auto tail = plan_launch_runs(kt, g.localBegin.data(), b35, cut35, length_at, mergeMin);
-            runs.insert(runs.end(), tail.begin(), tail.end());
-        }
-    }
-    if (latencyMode) g.latencyScans++;
-    const uint64_t* offsets = g.d_offsets + lbegin;
-    const int32_t* lengths = g.d_lengths + lbegin;
-    // Every packed run keeps its own overflow list (the slice of d_ovfPos at its first subject) and counter, and is
-    // re-scored by a launch of its own: the group shape of a re-score follows the run's longest subject (16-lane groups for
-    // the bulk of the DB, the wave-wide shape only for the list of partition 34), not the longest subject of the batch.
-    int32_t* const counters = g.d_ovfCount + 1 + batch * GpuT::kOvfLists;  // zeroed at the start of the scan
-    size_t mainIdx = 0;
-    for (size_t i = 1; i < runs.size(); i++)
-        if (runs[i].end - runs[i].begin > runs[mainIdx].end - runs[mainIdx].begin) mainIdx = i;
-    // a pipeline stage (the long subjects above, the long entries of the re-score lists below) takes exactly the register-file
-    // slot of a wave of the bulk launch it runs beside, so that it leaves no hole behind in which no wave of that persistent
-    // grid fits (include/cudasw4_amd.h: sw_launch_vgpr_slot)
-    if (pipelineOk) {
-        int vslot = 0;
-        if (!runs.empty()) {
-            const LaunchRun& m = runs[mainIdx];
-            vslot = sw_launch_vgpr_slot(g.ctx, int(m.kind), m.part_id, int32_t(m.end - m.begin), m.maxlen);
-        }
-        SWCHECK(sw_set_rows_pipeline_slot(g.ctx, vslot));
-    }
-    // Re-score service for the bulk run's overflow list (Gpu::svcStream): resident chars only (a staging buffer would have
-    // to wait for it), a packed bulk run, and a query / subject size at which re-scoring one subject takes about as long as
-    // a launch does at all (5 * 10^5 cells)
-    const bool serviceWanted = g.svcForce >= 0 ? g.svcForce == 1 : g.quietScans < 3;
+    a.batch_bytes = g.localOffsets[lend] - g.localOffsets[lbegin];
+    a.gop = gop; a.gex = gex;
+    a.scores = g.d_scores + lbegin;
+    a.ids = g.d_ids + lbegin;
+    a.id_offset = int64_t(lbegin);
+    a.ovf_pos = g.d_ovfPos + lbegin;
+    a.counters = g.d_ovfCount + batch * size_t(SW_BATCH_COUNTERS);   // zeroed at the start of the scan
+    a.max_temp_bytes = std::min(mem.maxTempBytes, g.tempCap);
+    a.stream = second ? g.stream2 : g.stream;
+    a.work_slot = second ? 1 : 0;
+    // the re-score service polls on a stream of its own: resident chars only (a staging buffer would have to wait for it),
+    // and only while no other object's streams share this device's few hardware queues with it
     const bool aloneOnDevice = g.device < 0 || g.device >= 64 || g_liveOnDevice[g.device].load() == 1;
-    const bool useService = g.handshake && g.svcStream && g.svcConcurrent && aloneOnDevice && slot < 0 && !second && serviceWanted && !g.laneActive &&
-                            !runs.empty() && is_packed(runs[mainIdx].kind) && double(g.qlen) * double(runs[mainIdx].maxlen) >= 5e5;
-    if (useService) {
-        // the list starts empty (-1) for the compare-and-swap of its takers
-        const LaunchRun& r = runs[mainIdx];
-        HIPCHECK(hipMemsetAsync(g.d_ovfPos + r.begin, 0xFF, (r.end - r.begin) * sizeof(int32_t), work));
+    a.allow_service = slot < 0 && !second && !g.laneActive && aloneOnDevice;
+    // tail hand-over (Gpu::Lane): the bulk launch of a resident scan arms the dry signal for whoever is submitted while it
+    // runs, and waits for the dry signal of the query before it when that one still runs on the other lane
+    if (g.drySignal && g.handshake && slot < 0 && !second) {
+        a.arm_signal = g.drySignal;
+        a.arm_value = ++g.drySeq;
+        g.lastArmedSeq = g.drySeq;
+        if (g.waitDry) {
+            a.wait_signal = g.drySignal;
+            a.wait_value = g.waitDry;
+            g.waitDry = 0;
+            g.laneOverlaps++;
+        }
     }
-    if (runs.size() > 1 || useService || !pipeParts.empty()) HIPCHECK(hipEventRecord(fork, work));
-    std::vector<int> ovfList(runs.size(), -1);
-    int numLists = 0;
-    for (size_t i = 0; i < runs.size(); i++)
-        if (is_packed(runs[i].kind)) ovfList[i] = std::min(numLists++, GpuT::kOvfLists - 1);
-    // with more packed runs than lists (never with the reference's partitions: at most three runs per batch) the last
-    // list is shared, which is only safe on one stream
-    const bool shareLast = numLists > GpuT::kOvfLists;
-    auto launch = [&](size_t ri, hipStream_t stream, int tslot) {
-        const LaunchRun& r = runs[ri];
-        const int32_t n = int32_t(r.end - r.begin);
-        const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, r.maxlen);
-        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
-        TimedLaunch t;
-        const bool record = recordMode == 1 || (recordMode == 2 && tslot == workTemp);
-        if (record) {
+    a.grid_reserve_side = g.laneActive ? g.sideReserve : 0;
+    // two queries in flight: the side launches of consecutive queries start on different side streams of their engines
+    a.alt_side_stream = g.lastLane == 1 && slot < 0;
+    constexpr int kMaxRecords = 24;
+    sw_launch_record recs[kMaxRecords];
+    int32_t used = 0;
+    if (recordMode) {
+        for (auto& r : recs) {
+            TimedLaunch t;
             if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
             else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
-            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = false;
-            SWCHECK(sw_plan_launch(g.ctx, int(r.kind), r.part_id, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
-            HIPCHECK(hipEventRecord(t.ev0, stream));
+            r.ev0 = t.ev0; r.ev1 = t.ev1;
         }
-        const bool packed = ovfList[ri] >= 0;
-        SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, chars, offsets, lengths, int32_t(r.begin - lbegin), n,
-                                  r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin),
-                                  packed ? g.d_ovfPos + r.begin : nullptr, packed ? counters + ovfList[ri] : nullptr,
-                                  packed ? 1 : 0, temp, g.tempBytes[tslot], stream));
-        if (record) {
-            HIPCHECK(hipEventRecord(t.ev1, stream));
-            g.timed.push_back(t);
-        }
-    };
-    // A side launch of a 32-bit kind whose long subjects the current query allows to cut into windows (sw_window_overlap:
-    // exact).  The giants of a real DB are a handful of subjects of up to 35 000 residues, each one alignment group's
-    // 35 000 dependent steps: for a query of a few hundred residues that single group outlasted the scan of everything
-    // else.  Cut into windows of C = max(W, 2048) columns plus W columns of run-in, the same subjects are dozens of
-    // independent groups.  Returns false when the run is to be launched as it is.
-    // Rough clocks of a side launch of long subjects and of the bulk launch beside it: a wave-wide group alone on its SIMD
-    // issues a dependent step of R rows in ~(6.5 R + 19) * 8 cycles (measured: 60 ms for 35 000 columns x 11 stripes, this
-    // says 91); the bulk runs at ~10 TCUPS.
-    auto giant_seconds = [&](const LaunchRun& r) {
-        const double rows = std::ceil(double(g.qlen) / 64.0), stripes = std::ceil(rows / 8.0);
-        return double(r.maxlen) * stripes * (6.5 * std::min(rows, 8.0) + 19.0) * 8.0 / 2.4e9;
-    };
-    auto bulk_seconds = [&]() {
-        return double(g.localOffsets[runs[mainIdx].end] - g.localOffsets[runs[mainIdx].begin]) * double(g.qlen) / 10e12;
-    };
-    // The few subjects of partition 35, ROW-parallel (include/cudasw4_amd.h: sw_scan_rows): a whole workgroup of 1024
-    // threads per subject instead of one wave, 3 x faster for a long query and 20 x for a short one, for 2.3 x the
-    // instructions — so only where the one-wave launch would be (close to) what the scan waits for: shards of a real DB,
-    // short queries.  Returns false when the run is to be launched as it is.
-    auto launch_rows = [&](size_t ri, hipStream_t stream) -> bool {
-        const LaunchRun& r = runs[ri];
-        // (round 5: the subjects whose walk would matter have left the scan launches as pipelines — cut34 / cut35 above; what is left
-        // here is CUDASW4_AMD_ROWS=single, the one-workgroup form of round 4 by its time estimate, kept for A/B measurements)
-        if (g.rowsMode != 3 || is_packed(r.kind) || r.part_id != kNumLengthPartitions - 1) return false;
-        if (gop > gex || r.maxlen > sw_scan_rows_max_subject() || r.end - r.begin > 64) return false;
-        if (giant_seconds(r) < 0.8 * bulk_seconds()) return false;
-        const int32_t n = int32_t(r.end - r.begin);
-        TimedLaunch t;
-        const bool record = recordMode == 1;
-        if (record) {
-            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
-            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
-            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = false;
-            t.eff_kind = SW_KIND_I32; t.rows = (r.maxlen + 1023) / 1024; t.nstripes = 1; t.lanes = 1024;
-            HIPCHECK(hipEventRecord(t.ev0, stream));
-        }
-        SWCHECK(sw_scan_rows(g.ctx, chars, offsets, lengths, int32_t(r.begin - lbegin), n, r.maxlen, gop, gex, g.d_scores + lbegin,
-                             g.d_ids + lbegin, int64_t(lbegin), stream));
-        if (record) {
-            HIPCHECK(hipEventRecord(t.ev1, stream));
-            g.timed.push_back(t);
-        }
-        g.rowsLaunches++;
-        return true;
-    };
-    // one part of the pipelined subjects on an auxiliary stream
-    auto launch_pipeline = [&](const PipePart& pp, hipStream_t stream, int tslot) {
-        const int32_t n = int32_t(pp.end - pp.begin);
-        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], pp.need, std::min(mem.maxTempBytes, g.tempCap));
-        // the reference's statistic counts the subjects whose exact score reaches the packed kind's limit — also where no
-        // packed launch ever saw them
-        const KernelType pk = kt.for_partition(pp.part_id);
-        const int32_t limit = pk == KernelType::Half2 ? SW_MAX_ACC_F16 : pk == KernelType::DPXs16 ? SW_MAX_ACC_I16 : 0;
-        TimedLaunch t;
-        const bool record = recordMode == 1;
-        if (record) {
-            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
-            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
-            t.kind = int(pk); t.part_id = pp.part_id; t.qlen = g.qlen; t.lbegin = pp.begin; t.lend = pp.end; t.rescore = false;
-            t.eff_kind = SW_KIND_I32; t.rows = (pp.maxlen + 1023) / 1024; t.nstripes = 1; t.lanes = 64;
-            HIPCHECK(hipEventRecord(t.ev0, stream));
-        }
-        SWCHECK(sw_scan_rows_pipelined(g.ctx, chars, offsets, lengths, int32_t(pp.begin - lbegin), n, pp.maxlen, gop, gex,
-                                       g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), g.failSlot,
-                                       limit > 0 ? g.d_ovfCount : nullptr, limit > 0 ? g.pipeOverSlot : nullptr, limit, temp,
-                                       g.tempBytes[tslot], stream));
-        if (record) {
-            HIPCHECK(hipEventRecord(t.ev1, stream));
-            g.timed.push_back(t);
-        }
-        g.rowsLaunches++;
-        g.pipelineLaunches++;
-    };
-    auto launch_windows = [&](size_t ri, hipStream_t stream, int a) -> bool {
-        const LaunchRun& r = runs[ri];
-        if (!g.windows || is_packed(r.kind)) return false;
-        const int32_t W = sw_window_overlap(g.ctx, gop, gex);
-        if (W < 0) return false;
-        const int64_t W4 = (int64_t(W) + 3) / 4 * 4, C = std::max<int64_t>(W4, 2048);
-        if (int64_t(r.maxlen) <= C + W4) return false;  // nothing to cut
-        // Worth it only while the longest subject's lone group would outlast the bulk launch (windows double the side
-        // launch's work, which runs beside the bulk: measured -1 ... -1.7 % from 222 residues up on the Swiss-Prot-like DB,
-        // +47 % at 48, +23 % at 96, +4.5 % at 144, +3 % at 189).  Rough clocks: a wave-wide group alone on its SIMD issues a
-        // dependent step of R rows in ~(6.5 R + 19) * 8 cycles; the bulk runs at ~10 TCUPS.  CUDASW4_AMD_WINDOWS=always
-        // skips the estimate (tests).
-        if (!g.windowsAlways && giant_seconds(r) < 1.15 * bulk_seconds()) return false;
-        const size_t nreal = r.end - r.begin;
-        // host side: windows of every subject of the run
-        size_t nwin = 0;
-        for (size_t pos = r.begin; pos < r.end; pos++) {
-            const int64_t len = db.length(size_t(g.toGlobal(int64_t(pos))));
-            nwin += len <= C + W4 ? 1 : size_t((len + C - 1) / C);
-        }
-        if (nwin > size_t(INT32_MAX) / 2) return false;
-        auto al = [](size_t x) { return (x + 15) / 16 * 16; };
-        const size_t offOff = 0, lenOff = al(nwin * 8), firstOff = lenOff + al(nwin * 4), posOff = firstOff + al((nreal + 1) * 4);
-        const size_t hostBytes = posOff + al(nreal * 4);
-        const size_t scoreOff = hostBytes, idOff = scoreOff + al(nwin * 4), devBytes = idOff + al(nwin * 4);
-        auto& wb = g.winBuf[a][g.winNext[a]];
-        g.winNext[a] = (g.winNext[a] + 1) % GpuT::kWindowBufs;
-        if (!wb.copied) HIPCHECK(hipEventCreateWithFlags(&wb.copied, hipEventDisableTiming));
-        if (wb.used) HIPCHECK(hipEventSynchronize(wb.copied));
-        if (hostBytes > wb.hcap) {
-            (void)hipHostFree(wb.h); wb.h = nullptr; wb.hcap = 0;
-            HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&wb.h), hostBytes * 2));
-            wb.hcap = hostBytes * 2;
-        }
-        if (devBytes > wb.dcap) {
-            (void)hipFree(wb.d); wb.d = nullptr; wb.dcap = 0;
-            HIPCHECK(hipMalloc(reinterpret_cast<void**>(&wb.d), devBytes * 2));
-            wb.dcap = devBytes * 2;
-        }
-        uint64_t* hOff = reinterpret_cast<uint64_t*>(wb.h + offOff);
-        int32_t* hLen = reinterpret_cast<int32_t*>(wb.h + lenOff);
-        int32_t* hFirst = reinterpret_cast<int32_t*>(wb.h + firstOff);
-        int32_t* hPos = reinterpret_cast<int32_t*>(wb.h + posOff);
-        size_t w = 0;
-        int32_t maxWin = 0;
-        for (size_t pos = r.begin; pos < r.end; pos++) {
-            const int64_t len = db.length(size_t(g.toGlobal(int64_t(pos))));
-            const uint64_t base = g.localOffsets[pos] - g.localOffsets[lbegin];  // the subject's first byte, relative to `chars`
-            hFirst[pos - r.begin] = int32_t(w);
-            hPos[pos - r.begin] = int32_t(pos - lbegin);
-            const int64_t k = len <= C + W4 ? 1 : (len + C - 1) / C;
-            for (int64_t i = 0; i < k; i++) {
-                const int64_t b = k == 1 ? 0 : std::max<int64_t>(0, i * C - W4), e = k == 1 ? len : std::min(len, (i + 1) * C);
-                hOff[w] = base + uint64_t(b);
-                hLen[w] = int32_t(e - b);
-                maxWin = std::max(maxWin, hLen[w]);
-                w++;
+        a.records = recs; a.records_cap = kMaxRecords; a.records_used = &used; a.record_mode = recordMode;
+    }
+    if (g.testLoseSideLaunch > 0) { SWCHECK(sw_batch_test_lose_side_launch(g.eng, g.testLoseSideLaunch)); g.testLoseSideLaunch = 0; }
+    const int rc = sw_scan_batch(g.eng, &a);
+    if (recordMode) {
+        for (int i = 0; i < kMaxRecords; i++) {
+            TimedLaunch t;
+            t.ev0 = static_cast<hipEvent_t>(recs[i].ev0); t.ev1 = static_cast<hipEvent_t>(recs[i].ev1);
+            if (i < used && rc == SW_OK) {
+                t.kind = recs[i].kind; t.part_id = recs[i].part_id; t.qlen = g.qlen;
+                t.lbegin = lbegin + size_t(recs[i].begin); t.lend = lbegin + size_t(recs[i].end);
+                t.rescore = recs[i].rescore != 0;
+                t.eff_kind = recs[i].eff_kind; t.rows = recs[i].rows; t.nstripes = recs[i].nstripes; t.lanes = recs[i].lanes;
+                g.timed.push_back(t);
+            } else {
+                g.freeTimed.push_back(t);
             }
         }
-        hFirst[nreal] = int32_t(w);
-        HIPCHECK(hipMemcpyAsync(wb.d, wb.h, hostBytes, hipMemcpyHostToDevice, stream));
-        HIPCHECK(hipEventRecord(wb.copied, stream));
-        wb.used = true;
-        const int32_t n = int32_t(nwin);
-        const int tslot = a + 1;
-        const size_t need = sw_scan_temp_bytes(g.ctx, int(r.kind), r.part_id, n, maxWin);
-        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
-        TimedLaunch t;
-        const bool record = recordMode == 1;
-        if (record) {
-            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
-            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
-            t.kind = int(r.kind); t.part_id = r.part_id; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = false;
-            SWCHECK(sw_plan_launch(g.ctx, int(r.kind), r.part_id, n, maxWin, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
-            HIPCHECK(hipEventRecord(t.ev0, stream));
-        }
-        // the windows are subjects of their own: offsets relative to the first window's, whose first byte `chars + hOff[0]` is
-        SWCHECK(sw_scan_partition(g.ctx, int(r.kind), r.part_id, chars + hOff[0], reinterpret_cast<const uint64_t*>(wb.d + offOff),
-                                  reinterpret_cast<const int32_t*>(wb.d + lenOff), 0, n, maxWin, gop, gex,
-                                  reinterpret_cast<float*>(wb.d + scoreOff), reinterpret_cast<int32_t*>(wb.d + idOff), 0,
-                                  nullptr, nullptr, 0, temp, g.tempBytes[tslot], stream));
-        SWCHECK(sw_reduce_windows(g.ctx, reinterpret_cast<const float*>(wb.d + scoreOff), reinterpret_cast<const int32_t*>(wb.d + firstOff),
-                                  reinterpret_cast<const int32_t*>(wb.d + posOff), int32_t(nreal), g.d_scores + lbegin, g.d_ids + lbegin,
-                                  int64_t(lbegin), stream));
-        if (record) {
-            HIPCHECK(hipEventRecord(t.ev1, stream));
-            g.timed.push_back(t);
-        }
-        g.windowLaunches++;
-        g.windowCount += int64_t(nwin);
-        return true;
-    };
-    auto rescore = [&](size_t ri, hipStream_t stream, int tslot) {  // cudasw4.cuh:2134-2169
-        if (ovfList[ri] < 0) return;
-        const LaunchRun& r = runs[ri];
-        const int32_t n = int32_t(r.end - r.begin);
-        const size_t need = sw_scan_temp_bytes(g.ctx, int(kt.overflowType), -1, n, r.maxlen);
-        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
-        TimedLaunch t;
-        const bool record = recordMode == 1 || (recordMode == 2 && tslot == workTemp);
-        if (record) {
-            if (!g.freeTimed.empty()) { t = g.freeTimed.back(); g.freeTimed.pop_back(); }
-            else { HIPCHECK(hipEventCreate(&t.ev0)); HIPCHECK(hipEventCreate(&t.ev1)); }
-            t.kind = int(kt.overflowType); t.part_id = -1; t.qlen = g.qlen; t.lbegin = r.begin; t.lend = r.end; t.rescore = true;
-            SWCHECK(sw_plan_launch(g.ctx, int(kt.overflowType), -1, n, r.maxlen, &t.eff_kind, &t.rows, &t.nstripes, &t.lanes));
-            HIPCHECK(hipEventRecord(t.ev0, stream));
-        }
-        // The long subjects of the list first, pipelined (include/cudasw4_amd.h: sw_rescore_overflow_pipelined): a flagged
-        // subject is one group's walk — 16 ms for a 5 500-residue relative of a 5 478-residue query, behind the launch
-        // that flagged it — and on a shard that walk outlasts the bulk launch.  Entries whose walk would take more than
-        // kPipelineRescoreShare of the bulk launch's estimated time; the ordinary launch behind claims what is left.
-        bool picked = false;
-        if (pipelineOk && g.rowsMode != 3) {
-            const double minLen = std::max(256.0, g.pipelineRescoreShare * bulkSeconds / colSeconds);
-            const size_t need2 = double(r.maxlen) >= minLen && int64_t(r.maxlen) * int64_t(-gex) < (int64_t(1) << 28)
-                                     ? sw_rescore_overflow_pipelined_temp_bytes(g.ctx, r.maxlen) : 0;
-            if (need2 > 0 && need2 <= std::min(mem.maxTempBytes, g.tempCap)) {
-                temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], std::max(need, need2), std::min(mem.maxTempBytes, g.tempCap));
-                SWCHECK(sw_rescore_overflow_pipelined(g.ctx, g.d_ovfPos + r.begin, counters + ovfList[ri], n, chars, offsets, lengths,
-                                                      r.maxlen, int32_t(minLen), gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
-                                                      int64_t(lbegin), g.failSlot,
-                                                      r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16, g.d_ovfCount,
-                                                      temp, g.tempBytes[tslot], stream));
-                picked = true;
-                g.pipelineRescores++;
-            }
-        }
-        if ((useService && ri == mainIdx) || picked)   // what the service / the pipelined launch has not taken
-            SWCHECK(sw_rescore_overflow_claim(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[ri], n,
-                                              chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
-                                              int64_t(lbegin), temp, g.tempBytes[tslot],
-                                              r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16,
-                                              g.d_ovfCount, stream));
-        else
-        SWCHECK(sw_rescore_overflow_stat(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[ri], n,
-                                         chars, offsets, lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin,
-                                         int64_t(lbegin), temp, g.tempBytes[tslot],
-                                         r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16,
-                                         g.d_ovfCount, stream));
-        if (record) {
-            HIPCHECK(hipEventRecord(t.ev1, stream));
-            g.timed.push_back(t);
-        }
-    };
-    // Two queries in flight: the side launches of consecutive queries start on different auxiliary streams, so that the
-    // long-subject launch of query i + 1 runs beside the one of query i instead of behind it.  On a small shard of a real
-    // DB that launch outlasts everything else — one 35 000-residue subject is one wave's 35 000 dependent steps per
-    // stripe of the query, 60 ms for a 5 478-residue query whatever the shard's size — and the queries' long-subject
-    // launches back to back are the floor of the whole stream (tools/shard_proxy.sh).
-    int auxNext = g.lastLane == 1 && slot < 0 ? 1 : 0;
-    bool auxBusy[GpuT::kAux] = {};
-    std::vector<int> streamOf(runs.size(), -1);  // auxiliary stream of a run, -1: work stream
-    bool anySide = false;
-    // The bulk launch waits until every side launch holds its slots, and a stream runs its launches in order: with two
-    // pipeline parts and two side runs on two auxiliary streams the last side launch starts behind a pipeline part (the
-    // giants' 0.2 ms beside a 48-residue query, whose whole scan takes 1.5 ms).  When the re-score service is not in play
-    // (short queries, streamed batches excluded) its stream takes the first pipeline part.
-    const bool svcFree = g.svcStream && g.svcConcurrent && g.handshake && !useService && slot < 0 && !second && !g.laneActive &&
-                         pipeParts.size() + (runs.empty() ? 0 : runs.size() - 1) > size_t(GpuT::kAux);
-    bool svcTaken = false;
-    for (const PipePart& pp : pipeParts) {
-        if (g.handshake && !runs.empty()) {
-            SWCHECK(sw_set_start_signal(g.ctx, g.startSignal));
-            g.sideLaunches++;
-            anySide = true;
-        }
-        if (svcFree && !svcTaken) {
-            svcTaken = true;
-            HIPCHECK(hipStreamWaitEvent(g.svcStream, fork, 0));
-            launch_pipeline(pp, g.svcStream, GpuT::kAux + 2);
-            g.svcUsed = true;
-            continue;
-        }
-        const int a = auxNext++ % GpuT::kAux;
-        if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], fork, 0));
-        auxBusy[a] = true;
-        launch_pipeline(pp, g.aux[a], a + 1);
     }
-    for (size_t i = 0; i < runs.size(); i++) {
-        if (i == mainIdx || (shareLast && ovfList[i] == GpuT::kOvfLists - 1)) continue;
-        const int a = auxNext++ % GpuT::kAux;
-        if (!auxBusy[a]) HIPCHECK(hipStreamWaitEvent(g.aux[a], fork, 0));
-        auxBusy[a] = true;
-        streamOf[i] = a;
-        if (g.handshake) {
-            SWCHECK(sw_set_start_signal(g.ctx, g.startSignal));
-            g.sideLaunches++;
-            anySide = true;
-        }
-        // (windows first: where the span bound cuts the subjects — short queries — they are a little faster than the rows,
-        // 8 253 against 7 818 GCUPS for a stream of 48-residue queries; long queries have no windows)
-        if (!launch_windows(i, g.aux[a], a) && !launch_rows(i, g.aux[a])) launch(i, g.aux[a], a + 1);
-    }
-    if (useService) {
-        const LaunchRun& r = runs[mainIdx];
-        const int32_t n = int32_t(r.end - r.begin);
-        const int tslot = GpuT::kAux + 2;
-        const size_t need = sw_rescore_service_temp_bytes(g.ctx, int(kt.overflowType), r.maxlen, g.serviceWorkgroups());
-        void* temp = ensure_temp(g.d_temp[tslot], g.tempBytes[tslot], need, std::min(mem.maxTempBytes, g.tempCap));
-        HIPCHECK(hipStreamWaitEvent(g.svcStream, fork, 0));
-        SWCHECK(sw_set_start_signal(g.ctx, g.startSignal));
-        g.sideLaunches++;
-        anySide = true;
-        g.doneSeq++;
-        SWCHECK(sw_rescore_service(g.ctx, int(kt.overflowType), g.d_ovfPos + r.begin, counters + ovfList[mainIdx], n, chars, offsets,
-                                   lengths, r.maxlen, gop, gex, g.d_scores + lbegin, g.d_ids + lbegin, int64_t(lbegin), temp,
-                                   g.tempBytes[tslot], r.kind == KernelType::Half2 ? SW_MAX_ACC_F16 : SW_MAX_ACC_I16, g.d_ovfCount,
-                                   g.doneSignal, g.doneSeq, g.serviceWorkgroups(), g.svcStream));
-        g.svcUsed = true;
-        g.serviceLaunches++;
-    }
-    if (g.laneActive) SWCHECK(sw_set_grid_reserve(g.ctx, (!pipeParts.empty() || runs.size() > 1) ? std::max(g.laneReserve, g.sideReserve) : g.laneReserve));
-    // the bulk launch goes in only after the side launches hold their workgroup slots
-    if (anySide) HIPCHECK(hipStreamWaitValue32(work, g.startSignal, g.sideLaunches, hipStreamWaitValueGte, 0xffffffffu));
-    // ... and, when the query before is still running on the other lane, only when that one's work counter has run dry
-    if (g.waitDry && slot < 0 && !second) {
-        HIPCHECK(hipStreamWaitValue32(work, g.drySignal, g.waitDry, hipStreamWaitValueGte, 0xffffffffu));
-        g.waitDry = 0;
-        g.laneOverlaps++;
-    }
-    for (size_t i = 0; i < runs.size(); i++)
-        if (streamOf[i] < 0) {
-            if (i == mainIdx && g.drySignal && g.handshake && slot < 0 && !second) {
-                // whoever is submitted while this query runs is gated on this launch running dry (Gpu::Lane)
-                SWCHECK(sw_set_dry_signal(g.ctx, g.drySignal, ++g.drySeq));
-                g.lastArmedSeq = g.drySeq;
-            }
-            launch(i, work, workTemp);
-            // the service leaves once the list's producer has finished
-            if (useService && i == mainIdx) HIPCHECK(hipStreamWriteValue32(work, g.doneSignal, g.doneSeq, 0));
-        }
-    for (size_t i = 0; i < runs.size(); i++) {
-        if (streamOf[i] >= 0) rescore(i, g.aux[streamOf[i]], streamOf[i] + 1);
-        else rescore(i, work, workTemp);
-    }
-    for (int a = 0; a < GpuT::kAux; a++) {
-        if (!auxBusy[a]) continue;
-        g.auxUsed[a] = true;
-        if (slot >= 0) {
-            HIPCHECK(hipEventRecord(g.auxDone[slot][a], g.aux[a]));
-            g.auxPending[slot][a] = true;
-        }
+    SWCHECK(rc);
+    if (slot >= 0) {
+        void* evs[GpuT::kSide];
+        int usedSide[GpuT::kSide] = {};
+        for (int i = 0; i < GpuT::kSide; i++) evs[i] = g.auxDone[slot][i];
+        SWCHECK(sw_batch_side_events(g.eng, evs, usedSide));
+        for (int i = 0; i < GpuT::kSide; i++)
+            if (usedSide[i]) g.auxPending[slot][i] = true;
     }
 }
 
-// the work stream continues only after everything the auxiliary streams were given in this scan
+// the work stream continues only after everything the side streams were given in this scan
 template <class GpuT>
 static void join_aux(GpuT& g) {
-    for (int a = 0; a < GpuT::kAux; a++) {
-        if (!g.auxUsed[a]) continue;
-        HIPCHECK(hipEventRecord(g.joinEvent[a], g.aux[a]));
-        HIPCHECK(hipStreamWaitEvent(g.stream, g.joinEvent[a], 0));
-        g.auxUsed[a] = false;
-    }
+    SWCHECK(sw_batch_join(g.eng, g.stream));
     // auxPending stays set: the host no longer waits for the end of a scan before it enqueues the next one, so the copy
-    // that reuses a staging buffer must still wait for the auxiliary launches that read it (an event that has long
-    // completed costs nothing)
-    if (g.svcUsed) {
-        HIPCHECK(hipEventRecord(g.svcJoin, g.svcStream));
-        HIPCHECK(hipStreamWaitEvent(g.stream, g.svcJoin, 0));
-        g.svcUsed = false;
-    }
+    // that reuses a staging buffer must still wait for the side launches that read it (an event that has long completed
+    // costs nothing)
     if (g.stream2Used) {
         HIPCHECK(hipEventRecord(g.join2Event, g.stream2));
         HIPCHECK(hipStreamWaitEvent(g.stream, g.join2Event, 0));
@@ -1569,7 +1004,7 @@ void SearchDriver::scanStreamed(Gpu& g) {
         int8_t* dst = g.d_staging[slot];
         // the scan that last used this device buffer must have finished before the copy overwrites it
         if (slotUsed[slot]) HIPCHECK(hipStreamWaitEvent(g.copyStream, g.scanned[slot], 0));
-        for (int a = 0; a < Gpu::kAux; a++) {
+        for (int a = 0; a < Gpu::kSide; a++) {
             if (!g.auxPending[slot][a]) continue;
             HIPCHECK(hipStreamWaitEvent(g.copyStream, g.auxDone[slot][a], 0));
             g.auxPending[slot][a] = false;
@@ -1622,7 +1057,7 @@ void SearchDriver::scanStreamed(Gpu& g) {
         HIPCHECK(hipStreamWaitEvent(work, g.copied[slot], 0));
         if (!db_->codes_validated() && !g.batchChecked[nb - 1 - k]) {
             // the flag is the word behind this scan's overflow counters (enqueueOnGpu zeroes and copies it back)
-            SWCHECK(sw_check_letter_codes(g.ctx, dst, b.bytes, g.d_ovfCount + 1 + (1 + nb) * Gpu::kOvfLists, work));
+            SWCHECK(sw_check_letter_codes(g.ctx, dst, b.bytes, g.d_ovfCount + (1 + nb) * size_t(SW_BATCH_COUNTERS), work));
             g.batchChecked[nb - 1 - k] = true;
         }
         HIPCHECK(hipEventRecord(g.batchEv[2 * k], work));
@@ -1690,9 +1125,13 @@ bool SearchDriver::prepareLane(Gpu& g, int32_t queryLength) {
             SWCHECK(sw_ctx_create(g.device, &g.lane1.ctx));
             SWCHECK(sw_set_matrix(g.lane1.ctx, matrix_.m.data(), matrix_.dim));
         }
+        if (!g.lane1.eng) {
+            SWCHECK(sw_batch_create(g.lane1.ctx, g.stream2, &g.lane1.eng));
+            if (sw_batch_handshake_active(g.lane1.eng) != 1) { g.lanesFailed = true; return false; }
+        }
         if (!g.lane1.scanStartEv) HIPCHECK(hipEventCreate(&g.lane1.scanStartEv));
         if (!g.lane1.d_ovfCount) {
-            g.lane1.ovfCountCap = 3 + Gpu::kOvfLists + 1;
+            g.lane1.ovfCountCap = SW_BATCH_COUNTERS + 1;
             HIPCHECK(hipMalloc(&g.lane1.d_ovfCount, g.lane1.ovfCountCap * sizeof(int32_t)));
         }
         if (!g.lane1Ready) {
@@ -1726,6 +1165,7 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
     rs.lane = 0;
     g.spanBegin = g.spanEnd = now_seconds() - scanT0_;
     if (g.numLocal == 0) return;
+    TraceRange traceGpu("enqueue on GPU %d: query of %d residues, %ld subjects", g.device, int(queryLength), long(g.numLocal));
     g.use();
     // a query submitted while the one before is running takes the other lane and is gated on that one's dry signal
     const bool overlap = inFlight && prepareLane(g, std::min(g.qlen, queryLength));  // (g.qlen: the query before)
@@ -1740,23 +1180,22 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
         if (g.badCodes) throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
         g.qlen = queryLength;
         if (!g.cacheFilled) uploadShard(g);  // the first query pays the upload unless --uploadFull
-        SWCHECK(sw_set_grid_reserve(g.ctx, overlap ? g.laneReserve : 0));
         SWCHECK(sw_set_query(g.ctx, encodedQuery_.data(), queryLength, g.stream));
         // thrust::fill(scores, -1) (cudasw4.cuh:405-409) is not needed: every slot is written by a scan or a re-score
         // + 1: the bad-letter flag of streamed batches that are checked on the device (scanStreamed); + 1: pipeline stages
         // that gave up waiting (sw_scan_rows_pipelined: fail_count)
-        const size_t ncounters = 1 + (1 + g.batches.size()) * Gpu::kOvfLists;
-        if (ncounters + 3 > g.ovfCountCap) {
+        // one counter block per batch (the resident part is batch 0) and the bad-letter flag of streamed batches that are
+        // checked on the device (scanStreamed) behind them: zeroed by ONE memset, copied back by one copy
+        const size_t ncounters = (1 + g.batches.size()) * size_t(SW_BATCH_COUNTERS);
+        if (ncounters + 1 > g.ovfCountCap) {
             (void)hipFree(g.d_ovfCount);
             g.d_ovfCount = nullptr;
             g.ovfCountCap = 0;
-            HIPCHECK(hipMalloc(&g.d_ovfCount, (ncounters + 3) * sizeof(int32_t)));
-            g.ovfCountCap = ncounters + 3;
+            HIPCHECK(hipMalloc(&g.d_ovfCount, (ncounters + 1) * sizeof(int32_t)));
+            g.ovfCountCap = ncounters + 1;
         }
-        ensure_ovf_slots(rs.h_ovf, rs.ovfCap, ncounters + 3);
-        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, (ncounters + 3) * sizeof(int32_t), g.stream));
-        g.failSlot = g.d_ovfCount + ncounters + 1;
-        g.pipeOverSlot = g.d_ovfCount + ncounters + 2;   // (+ 1: pipelined subjects of packed partitions at or above the packed limit)
+        ensure_ovf_slots(rs.h_ovf, rs.ovfCap, ncounters + 1);
+        HIPCHECK(hipMemsetAsync(g.d_ovfCount, 0, (ncounters + 1) * sizeof(int32_t), g.stream));
         HIPCHECK(hipEventRecord(g.scanStartEv, g.stream));
         // the cached part first (the longest subjects: one set of launches over everything that is resident), then the
         // streamed batches — whose first copies run while the cached part computes
@@ -1792,27 +1231,32 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
                 HIPCHECK(hipMalloc(&g.d_topkTemp, tb));
                 g.topkTempBytes = tb;
             }
-            SWCHECK(sw_topk(g.ctx, g.d_scores, g.d_ids, int64_t(g.numLocal), kk, g.d_topS, g.d_topI, g.d_topkTemp,
-                            g.topkTempBytes, g.stream));
+            {
+                TraceRange traceTop("top-%d of %ld scores", kk, long(g.numLocal));
+                SWCHECK(sw_topk(g.ctx, g.d_scores, g.d_ids, int64_t(g.numLocal), kk, g.d_topS, g.d_topI, g.d_topkTemp,
+                                g.topkTempBytes, g.stream));
+            }
             HIPCHECK(hipMemcpyAsync(rs.h_topS, g.d_topS, kk * sizeof(float), hipMemcpyDeviceToHost, g.stream));
             HIPCHECK(hipMemcpyAsync(rs.h_topI, g.d_topI, kk * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
             rs.top = kk;
         }
         // per-query totals (addKernel, cudasw4.cuh:46-49,2175): summed on the host after the copy
-        HIPCHECK(hipMemcpyAsync(rs.h_ovf, g.d_ovfCount, (ncounters + 3) * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+        HIPCHECK(hipMemcpyAsync(rs.h_ovf, g.d_ovfCount, (ncounters + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
         HIPCHECK(hipEventRecord(rs.done, g.stream));
         rs.ncounters = ncounters;
         rs.used = true;
     } catch (...) {
         // Work may still be queued on the auxiliary, second and copy streams, and the bookkeeping of who waits for
         // whom is half-updated: drain the device and forget it, so that a later scan starts from a clean state
-        if (g.doneSignal) *g.doneSignal = g.doneSeq;   // a re-score service that is still polling leaves now
-        if (g.drySignal) *g.drySignal = g.drySeq;      // ... and so does a bulk launch that waits for a launch that never went in
+        for (sw_batch* e : {g.eng, g.lane1.eng})
+            if (e) (void)sw_batch_open_gates(e);       // a re-score service that is still polling, a bulk launch behind a side launch that never went in
+        if (g.drySignal) *g.drySignal = g.drySeq;      // ... and a bulk launch that waits for a launch that never went in
         g.waitDry = 0;
         g.lastArmedSeq = 0;
         (void)hipDeviceSynchronize();
         (void)hipGetLastError();
-        for (bool& u : g.auxUsed) u = false;
+        for (sw_batch* e : {g.eng, g.lane1.eng})
+            if (e) (void)sw_batch_reset(e);            // nothing is in flight now: the engines' counts start afresh
         g.stream2Used = false;
         for (auto& sl : g.auxPending)
             for (bool& pnd : sl) pnd = false;
@@ -1821,17 +1265,71 @@ void SearchDriver::enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bo
         g.slotBase = 0;
         // the letter-code checks this scan enqueued never reported back: check those batches again
         g.batchChecked.assign(g.batchChecked.size(), false);
-        // a side launch may have been counted but never enqueued: nothing is in flight now, start the count afresh
-        if (g.startSignal) *g.startSignal = 0;
-        g.sideLaunches = 0;
-        g.svcUsed = false;
         rs.used = false;
         throw;
     }
 }
 
+// The host-side watchdog.  A scan's work stream can wait in hipStreamWaitValue32 for values only
+// device code raises — the start signal of its side launches, the dry signal of the query before it — and a re-score service
+// polls until the work stream writes behind the bulk launch.  Device-side waits are bounded (spin limits); this bounds the
+// host side: the done event is polled with a deadline of watchdogSeconds_ (CUDASW4_AMD_WATCHDOG_SECONDS, default 60; 0:
+// wait without a limit) plus ten times what the scan should take at a tenth of the usual rate.  On expiry the gates are
+// opened by hand — signal memory is host-visible — so that the streams drain, the device is given a bounded time to do
+// so, and the scan FAILS with a message that names the signal that never arrived: the caller gets an exception, `align`
+// exits non-zero; nothing is re-executed.
+void SearchDriver::waitForScan(Gpu& g, void* doneEvent, int32_t qlen) {
+    const hipEvent_t done = static_cast<hipEvent_t>(doneEvent);
+    if (watchdogSeconds_ <= 0.0) { HIPCHECK(hipEventSynchronize(done)); return; }
+    const double estimate = double(std::max(qlen, 1)) * double(g.localResidues) / 1e12 + double(g.localChars - g.cacheBytes) / 2e9;
+    const double t0 = now_seconds(), deadline = watchdogSeconds_ + 10.0 * estimate;
+    auto poll = [&](double limit) -> bool {   // true: the event completed
+        for (uint64_t spins = 0;; spins++) {
+            const hipError_t q = hipEventQuery(done);
+            if (q == hipSuccess) return true;
+            if (q != hipErrorNotReady) hip_check(q, "hipEventQuery(scan done)");
+            const double waited = now_seconds() - t0;
+            if (waited > limit) return false;
+            // a scan of a millisecond is picked up by plain polling; a long one lets the core go
+            if (waited > 0.02) { struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr); }
+        }
+    };
+    if (poll(deadline)) return;
+    // which gate is closed?
+    std::string what = "scan timed out after " + std::to_string(int(now_seconds() - t0)) + " s (deadline " + std::to_string(int(deadline)) + " s)";
+    bool named = false;
+    for (sw_batch* e : {g.eng, g.lane1.eng}) {
+        if (!e || named) continue;
+        uint32_t startNow = 0, startTarget = 0, doneNow = 0, doneTarget = 0;
+        (void)sw_batch_signal_state(e, &startNow, &startTarget, &doneNow, &doneTarget);
+        if (int32_t(startTarget - startNow) > 0) {
+            what += ": " + std::to_string(startTarget - startNow) + " side launch(es) never reported their workgroups resident (start signal " +
+                    std::to_string(startNow) + " of " + std::to_string(startTarget) + "): the bulk launch behind it never started";
+            named = true;
+        } else if (int32_t(doneTarget - doneNow) > 0) {
+            what += ": the re-score service was never told that its producer had finished (done signal " + std::to_string(doneNow) + " of " +
+                    std::to_string(doneTarget) + ")";
+            named = true;
+        }
+    }
+    const uint32_t dryNow = g.drySignal ? *reinterpret_cast<volatile uint32_t*>(g.drySignal) : 0;
+    if (!named && g.drySignal && int32_t(g.drySeq - dryNow) > 0)
+        what += ": the dry signal stands at " + std::to_string(dryNow) + " of " + std::to_string(g.drySeq) + ": a bulk launch gated on the query before it never started";
+    else if (!named)
+        what += ": no gate of the driver is closed — a kernel does not finish";
+    for (sw_batch* e : {g.eng, g.lane1.eng})
+        if (e) (void)sw_batch_open_gates(e);
+    if (g.drySignal) *reinterpret_cast<volatile uint32_t*>(g.drySignal) = g.drySeq;
+    const bool drained = poll(deadline + 10.0);
+    what += drained ? "; the gates were opened by hand and the device drained, the scan's results are not valid" : "; the device did not drain within 10 s after the gates were opened";
+    // forget who waits for whom: a later scan on this driver starts clean (as after any failed enqueue)
+    g.waitDry = 0;
+    g.lastArmedSeq = 0;
+    throw std::runtime_error(what);
+}
+
 // wait for the results of the query that went into result slot `slot` and add up its counters
-void SearchDriver::finishOnGpu(Gpu& g, int slot) {
+void SearchDriver::finishOnGpu(Gpu& g, int slot, int32_t qlen) {
     Gpu::ResultSlot& rs = g.res[slot];
     g.lastTop = 0;
     g.lastOverflows = 0;
@@ -1841,7 +1339,7 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot) {
     g.resultLane = rs.lane;
     if (!rs.used) return;
     g.use();
-    HIPCHECK(hipEventSynchronize(rs.done));
+    waitForScan(g, rs.done, qlen);
     rs.used = false;
     // A streamed batch is checked by the FIRST scan that uses it; with two queries in flight the second one was enqueued
     // before the first one's flag came back and carries no check of its own: a flag raised by any earlier query
@@ -1850,15 +1348,20 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot) {
         g.badCodes = true;
         throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
     }
-    if (rs.h_ovf[rs.ncounters + 1])
-        throw std::runtime_error("scan failed: " + std::to_string(rs.h_ovf[rs.ncounters + 1]) +
+    int failed = 0;
+    for (size_t k = 0; k < rs.ncounters; k += size_t(SW_BATCH_COUNTERS)) {   // one block per batch of the scan
+        const int32_t* c = rs.h_ovf + k;
+        g.lastOverflows += c[SW_BATCH_CNT_OVERFLOWS];
+        for (int i = 0; i < 4; i++) g.lastRescored += c[SW_BATCH_CNT_LIST0 + i];
+        g.lastRescored += c[SW_BATCH_CNT_PIPE_OVER];   // pipelined subjects a packed launch would have flagged: scored in 32 bits as well
+        failed += c[SW_BATCH_CNT_FAILED];
+    }
+    if (failed)
+        throw std::runtime_error("scan failed: " + std::to_string(failed) +
                                  " pipeline stage(s) of a long subject gave up waiting for their neighbour (sw_scan_rows_pipelined)");
-    for (size_t i = 1; i < rs.ncounters; i++) g.lastRescored += rs.h_ovf[i];
-    g.lastRescored += rs.h_ovf[rs.ncounters + 2];   // pipelined subjects a packed launch would have flagged: scored in 32 bits as well
-    g.lastOverflows = rs.h_ovf[0];
     g.lastTop = rs.top;
-    g.quietScans = g.lastRescored > 0 ? 0 : std::min(g.quietScans + 1, 1000);
-    g.rescoredEma = 0.7 * g.rescoredEma + 0.3 * double(g.lastRescored);
+    // how much recent scans re-scored arms and sizes the re-score service of the lane's engine
+    if (sw_batch* e = rs.lane == 1 ? (g.laneSwapped ? g.eng : g.lane1.eng) : (g.laneSwapped ? g.lane1.eng : g.eng)) SWCHECK(sw_batch_feedback(e, g.lastRescored));
     rs.used = false;
     g.spanEnd = now_seconds() - scanT0_;
 }
@@ -1873,6 +1376,7 @@ void SearchDriver::submit(const char* query, int32_t queryLength) {
     if (matrix_.dim == 25) for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue25(query[i]);
     else for (int32_t i = 0; i < queryLength; i++) encodedQuery_[size_t(i)] = encode_residue(query[i]);
 
+    TraceRange traceQuery("submit query of %d residues (%d in flight)", int(queryLength), int(pendingCount_));
     PendingScan ps;
     ps.slot = nextSlot_;
     ps.qlen = queryLength;
@@ -1890,11 +1394,12 @@ void SearchDriver::submit(const char* query, int32_t queryLength) {
 ScanResult SearchDriver::collect() {
     if (!pendingCount_) throw std::runtime_error("collect() without a submitted query");
     const PendingScan ps = pending_[pendingHead_];
+    TraceRange traceCollect("collect query of %d residues", int(ps.qlen));
     pendingHead_ = (pendingHead_ + 1) % kMaxInFlight;
     pendingCount_--;
     std::exception_ptr first;
     for (auto& gp : gpus_) {  // plain waits: no need for the worker threads
-        try { finishOnGpu(*gp, ps.slot); } catch (...) { if (!first) first = std::current_exception(); }
+        try { finishOnGpu(*gp, ps.slot, ps.qlen); } catch (...) { if (!first) first = std::current_exception(); }
     }
     if (first) std::rethrow_exception(first);
 
@@ -2003,17 +1508,22 @@ bool SearchDriver::isResident(int gpu) const {
     return g.cacheBegin == 0 && g.cacheFilled;
 }
 uint64_t SearchDriver::cachedChars(int gpu) const { return gpus_.at(size_t(gpu))->cacheBytes; }
+namespace {
+int64_t engine_stat(const sw_batch* a, const sw_batch* b, int which) {
+    int64_t v[6] = {}, w[6] = {};
+    if (a) (void)sw_batch_stats(a, v, 6);
+    if (b) (void)sw_batch_stats(b, w, 6);
+    return v[which] + w[which];
+}
+}  // namespace
+
 void SearchDriver::windowStats(int64_t* launches, int64_t* windows) const {
     int64_t l = 0, w = 0;
-    for (auto& gp : gpus_) { l += gp->windowLaunches; w += gp->windowCount; }
+    for (auto& gp : gpus_) { l += engine_stat(gp->eng, gp->lane1.eng, 2); w += engine_stat(gp->eng, gp->lane1.eng, 3); }
     if (launches) *launches = l;
     if (windows) *windows = w;
 }
-int64_t SearchDriver::latencyScans() const {
-    int64_t n = 0;
-    for (auto& gp : gpus_) n += gp->latencyScans;
-    return n;
-}
+int64_t SearchDriver::latencyScans() const { return 0; }   // (latency mode: measured, superseded by the walk-time cut, removed in round 6)
 
 bool SearchDriver::handshakeActive() const {
     for (auto& gp : gpus_)
@@ -2023,15 +1533,11 @@ bool SearchDriver::handshakeActive() const {
 
 int64_t SearchDriver::pipelineLaunches() const {
     int64_t n = 0;
-    for (auto& gp : gpus_) n += gp->pipelineLaunches;
+    for (auto& gp : gpus_) n += engine_stat(gp->eng, gp->lane1.eng, 0);
     return n;
 }
 
-int64_t SearchDriver::rowsLaunches() const {
-    int64_t n = 0;
-    for (auto& gp : gpus_) n += gp->rowsLaunches;
-    return n;
-}
+int64_t SearchDriver::rowsLaunches() const { return pipelineLaunches(); }   // (row-parallel side launches are the pipelined ones)
 
 int64_t SearchDriver::tailOverlaps() const {
     int64_t n = 0;
@@ -2041,7 +1547,7 @@ int64_t SearchDriver::tailOverlaps() const {
 
 int64_t SearchDriver::serviceLaunches() const {
     int64_t n = 0;
-    for (auto& gp : gpus_) n += gp->serviceLaunches;
+    for (auto& gp : gpus_) n += engine_stat(gp->eng, gp->lane1.eng, 4);
     return n;
 }
 uint64_t SearchDriver::streamedBytesTotal() const {

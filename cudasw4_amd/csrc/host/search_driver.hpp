@@ -255,7 +255,8 @@ private:
     void enqueueOnGpu(Gpu& g, int32_t queryLength, int k, int slot, bool inFlight);
     bool prepareLane(Gpu& g, int32_t queryLength);
     bool laneEligible(const Gpu& g, int32_t queryLength) const;
-    void finishOnGpu(Gpu& g, int slot);
+    void finishOnGpu(Gpu& g, int slot, int32_t qlen);
+    void waitForScan(Gpu& g, void* doneEvent, int32_t qlen);
     void registerStreamedRanges();
     void unregisterRanges();
     template <class F> void forEachGpu(F&& fn);
@@ -275,6 +276,7 @@ private:
     std::vector<std::pair<const int8_t*, size_t>> registered_;  // what hipHostRegister was given
     std::vector<int8_t> encodedQuery_;
     double scanT0_ = 0;
+    double watchdogSeconds_ = 60.0;   // CUDASW4_AMD_WATCHDOG_SECONDS: base of collect()'s deadline (0: none)
     // queries submitted and not yet collected, oldest first (a ring of kMaxInFlight result slots per GPU)
     struct PendingScan { int slot = 0; int32_t qlen = 0; int k = 0; double t0 = 0; };
     PendingScan pending_[kMaxInFlight];

@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "../../include/cudasw4_amd.h"
+#include "../../include/cudasw4_amd_engine.h"
+#include "sw_internal.hpp"
 #include "sw_launch.hpp"
 #include "sw_rows_kernel.hpp"
 #include "sw_rows_pipeline.hpp"
@@ -154,6 +156,7 @@ struct sw_ctx {
     uint32_t dry_value = 0;
     int grid_reserve = 0;              // sw_set_grid_reserve: workgroup slots a scan launch leaves free (until changed)
     int grid_mult = 4;           // persistent workgroups per CU (CUDASW4_AMD_GRID_MULT overrides, for experiments)
+    int grid_cap = 0;            // CUDASW4_AMD_GRID_CAP (tests): most workgroups of a scan launch — small DBs then give long claims (sw_stream_kernel.hpp)
     bool have_matrix = false;
     int8_t* d_query = nullptr;
     size_t query_capacity = 0;
@@ -178,21 +181,22 @@ struct sw_ctx {
     int32_t lanes4_max_q = -1;   // CUDASW4_AMD_LANES4_MAX_Q: queries up to this length use 4-lane groups (0: never; -1: the built-in limits)
     int32_t lanes8_max_q = -1;   // CUDASW4_AMD_LANES8_MAX_Q: queries up to this length use 8-lane groups (0: never; -1: the built-in limits)
     bool check_bounds = false;   // CUDASW4_AMD_CHECK_BOUNDS=1 (debug): every scan first verifies the max_subject_len contract on the device (synchronises)
-    // sw_scan_rows_pipelined: control words of the launches in flight (tickets, counted-in workgroups, abort, spare), rotating
-    static constexpr uint32_t kPipeCtrlSlots = 64;
-    uint32_t* d_pipe_ctrl = nullptr;
-    uint32_t pipe_next = 0;
     uint32_t pipe_spin_limit = 1u << 20;  // CUDASW4_AMD_PIPE_SPIN_LIMIT: polls (~2 us each) before a pipeline stage gives up waiting
     int32_t pipe_drop_stage = -1;         // CUDASW4_AMD_PIPE_TEST_DROP_STAGE (tests): this stage of every subject is lost
     int32_t pipe_cpl = 0;                 // CUDASW4_AMD_PIPE_CPL=4|8|16: columns per lane of a stage (0: by the subjects' length)
-    int32_t stream_slots = 0;             // CUDASW4_AMD_STREAM=2..4: batches whose subjects stream through the lanes back to back (sw_stream_kernel.hpp; default off: measured +1 ... +3 % on uniform DBs for single-stripe queries, -0 ... -14 % on small ragged shards, profiles/r05_stream_kernel.txt)
+    int32_t stream_slots = swk::kStreamMaxSlots;   // CUDASW4_AMD_STREAM=0..16: most batches whose subjects stream through the lanes back to back (sw_stream_kernel.hpp; 0 / 1: sw_scan_kernel, one batch at a time)
+    int32_t stream_jump = 0;              // CUDASW4_AMD_STREAM_JUMP: what the zero levels rise by at a slot border (0: 128 for fp16, 512 for int16)
+    int32_t stream_cols_max = 4096;       // CUDASW4_AMD_STREAM_COLS: most columns of a round of several slots
     int32_t pipe_quorum = 0;              // CUDASW4_AMD_PIPE_QUORUM (0: all tickets)
     int32_t pipe_slot = 0;                // sw_set_rows_pipeline_slot: VGPRs a stage occupies (128 / 168 / 256; 0: what it needs)
 };
 
 namespace {
 
-int max_grid(const sw_ctx* ctx) { return std::max(1, ctx->num_cus) * ctx->grid_mult; }
+int max_grid(const sw_ctx* ctx) {
+    const int g = std::max(1, ctx->num_cus) * ctx->grid_mult;
+    return ctx->grid_cap > 0 ? std::min(g, ctx->grid_cap) : g;
+}
 
 // Reference partitions 34 (1281..8000) and 35 (> 8000) hold the long subjects.  When there are only a few
 // of them (the tail of a real DB) they get the wave-wide group shape: 4x the lanes per alignment, so the
@@ -300,6 +304,32 @@ __global__ void max_length_kernel(const int32_t* lengths, const int32_t* positio
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x)
         m = max(m, lengths[positions ? positions[i] : first_pos + i]);
     if (m > 0) atomicMax(out, m);
+}
+
+// Streamed subjects (sw_stream_kernel.hpp).  The levels of a round start at `base` and rise by a per column and by `jump` per
+// slot border; a subject is exact while level + score stays inside the kind's exact range, so the round's a * columns + jumps
+// may add up to `room`: what is left between the base and the highest level at which unrelated subjects (and moderate hits)
+// still pass unflagged.
+//   fp16: exact integers in [-2048, 2048]: base -2016, levels up to 1024 (a subject in the last columns of a round is flagged
+//         from 2048 - 1024 on — round 5's frame flagged from 988 on everywhere), jump 128;
+//   int16: biased patterns exact up to 31 743, limit 25 000: base 0, levels up to 12 400, jump 512.
+// A slot whose predecessor scored jump - 4 or more is re-scored (its lanes may have kept values above the raised levels):
+// the jump is what separates "unrelated" from "a hit" — 128 is far above the noise floor of a 35 000-residue subject (~90).
+struct StreamPlan { int slots = 0, cols = 0, room = 0, base = 0, jump = 0; };
+StreamPlan stream_plan(const sw_ctx* ctx, int kind, int lanes, int a, const QueryPlan& pl, int32_t max_subject_len, bool eligible) {
+    StreamPlan sp;
+    if (!eligible || !kind_packed(kind) || lanes != 16 || ctx->stream_slots <= 1 || a <= 0 || max_subject_len >= 0xffff) return sp;   // (the kernel keeps a slot's lengths in 16 bits)
+    const bool multi = pl.nstripes > 1;
+    if (!multi && pl.rows < swk::kStreamMinRowsSingle) return sp;
+    const int P = swk::frame_classes(true, pl.rows, lanes, multi);
+    sp.base = kind == SW_KIND_F16X2 ? -2016 : 0;
+    const int top = kind == SW_KIND_F16X2 ? 1024 : 12400;
+    sp.jump = ctx->stream_jump > 0 ? ctx->stream_jump : (kind == SW_KIND_F16X2 ? 128 : 512);
+    sp.room = top - sp.base - a * (2 * lanes + 4 + P);
+    sp.cols = std::min(sp.room / a, ctx->stream_cols_max);
+    if (sp.room < 4 * lanes * a || sp.cols < 4 * lanes) return StreamPlan();   // a gap-extension score too large for any round
+    sp.slots = std::min(ctx->stream_slots, swk::kStreamMaxSlots);
+    return sp;
 }
 
 // overflow lists that are re-scored while they are filled (sw_dp_kernel.hpp: ScanParams::claim / service)
@@ -415,17 +445,12 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
             default: p.renorm_word = swk::Arith<swk::F32>::encode_gap(lower); break;
         }
     }
-    if (offs && !multi && lanes == 16 && ctx->stream_slots > 1 && !positions && !list.claim && list.service_workgroups == 0) {
-        // streamed subjects (sw_stream_kernel.hpp): the zero levels a lane takes on at a slot border, a * (lanes - 4 + j)
-        p.stream_slots = ctx->stream_slots;
-        for (int j = 0; j < 16; j++) {
-            switch (kind) {
-                case SW_KIND_F16X2: p.sw_levels[j] = swk::Arith<swk::F16X2>::zero_at(a, lanes - 4 + j); break;
-                case SW_KIND_I16X2: p.sw_levels[j] = swk::Arith<swk::I16X2>::zero_at(a, lanes - 4 + j); break;
-                case SW_KIND_I32: p.sw_levels[j] = swk::Arith<swk::I32>::zero_at(a, lanes - 4 + j); break;
-                default: p.sw_levels[j] = swk::Arith<swk::F32>::zero_at(a, lanes - 4 + j); break;
-            }
-        }
+    // Streamed subjects (sw_stream_kernel.hpp): packed kinds on 16-lane groups, column-offset recurrence, plain ranges
+    const StreamPlan sp = stream_plan(ctx, kind, lanes, a, pl, max_subject_len, offs && !positions && !count_ptr && !list.claim && list.service_workgroups == 0);
+    if (sp.slots > 1) {
+        p.stream_slots = sp.slots; p.stream_cols = sp.cols; p.stream_room = sp.room; p.level_base = sp.base;
+        p.jump = sp.jump; p.jump_limit = sp.jump - 4;
+        p.jump_word = kind == SW_KIND_F16X2 ? swk::Arith<swk::F16X2>::pos_word(sp.jump) : swk::Arith<swk::I16X2>::pos_word(sp.jump);
     }
     p.scores = scores; p.ids = ids; p.id_offset = id_offset;
     p.ovf_pos = ovf_pos; p.ovf_count = ovf_count; p.ovf_check = (ovf_check && kind_packed(kind)) ? 1 : 0;
@@ -433,6 +458,13 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     p.stat_count = stat_count; p.stat_limit = stat_limit;
     if (multi) {
         p.lcap = border_capacity(max_subject_len, lanes);
+        if (p.stream_slots > 1) {
+            // the border arrays of a round hold all of its slots: as many columns as the caller's scratch gives the whole grid
+            int cols = p.stream_cols;
+            while (cols > max_subject_len && (size_t)grid * border_bytes_per_wg(border_capacity(cols, lanes), lanes) > temp_bytes) cols = cols * 3 / 4;
+            p.stream_cols = cols;
+            p.lcap = border_capacity(std::max(max_subject_len, cols), lanes);
+        }
         const size_t per_wg = border_bytes_per_wg(p.lcap, lanes);
         if (!temp || temp_bytes < per_wg) return fail(SW_ERR_TEMP, "temp buffer too small for a multi-stripe query");
         grid = (int)std::min<size_t>((size_t)grid, temp_bytes / per_wg);
@@ -502,6 +534,13 @@ __global__ void __launch_bounds__(256) valu_rate_kernel(unsigned* out, unsigned 
 }
 }  // namespace
 
+namespace swi {
+int fail(int code, const std::string& msg) { return ::fail(code, msg); }
+int32_t query_length(const sw_ctx* ctx) { return ctx && ctx->have_query ? ctx->qlen : 0; }
+int device_of(const sw_ctx* ctx) { return ctx ? ctx->device : -1; }
+int num_cus(const sw_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+}  // namespace swi
+
 extern "C" {
 
 const char* sw_version(void) { return "cudasw4_amd 0.2 (gfx950)"; }
@@ -527,6 +566,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
+    if (const char* e = getenv("CUDASW4_AMD_GRID_CAP")) ctx->grid_cap = std::max(0, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
     if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = ctx->long16_min_default = atoll(e);
     if (const char* e = getenv("CUDASW4_AMD_I32_NATIVE")) ctx->i32_native = e[0] == '1';
@@ -539,11 +579,12 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_PIPE_TEST_DROP_STAGE")) ctx->pipe_drop_stage = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_PIPE_CPL")) ctx->pipe_cpl = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_PIPE_QUORUM")) ctx->pipe_quorum = std::max(0, atoi(e));
-    if (const char* e = getenv("CUDASW4_AMD_STREAM")) ctx->stream_slots = std::max(0, std::min(4, atoi(e)));
+    if (const char* e = getenv("CUDASW4_AMD_STREAM")) ctx->stream_slots = std::max(0, std::min(swk::kStreamMaxSlots, atoi(e)));
+    if (const char* e = getenv("CUDASW4_AMD_STREAM_JUMP")) ctx->stream_jump = std::max(0, atoi(e));
+    if (const char* e = getenv("CUDASW4_AMD_STREAM_COLS")) ctx->stream_cols_max = std::max(64, atoi(e));
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check (word 64) and the two of sw_streams_run_concurrently (72, 73)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, 2 * kWorkSlots * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_pipe_ctrl, 4 * sw_ctx::kPipeCtrlSlots * sizeof(uint32_t));
     if (e == hipSuccess) {
         uint32_t z[64] = {};
         for (int i = 0; i < 16; i++) z[SW_KIND_I16X2 * 16 + i] = swk::Arith<swk::I16X2>::kZero;
@@ -563,7 +604,6 @@ int sw_ctx_destroy(sw_ctx* ctx) {
     if (ctx->d_matrix) (void)hipFree(ctx->d_matrix);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
-    if (ctx->d_pipe_ctrl) (void)hipFree(ctx->d_pipe_ctrl);
     if (ctx->d_query) (void)hipFree(ctx->d_query);
     for (int i = 0; i < sw_ctx::kQuerySlots; i++) {
         if (ctx->h_query[i]) (void)hipHostFree(ctx->h_query[i]);
@@ -752,6 +792,7 @@ int pipeline_cpl(const sw_ctx* ctx, int32_t n, int32_t max_subject_len) {
     }
     return best;
 }
+constexpr size_t kPipeCtrlBytes = 16;   // control words of a pipelined launch, in front of its hand-off words
 int64_t pipeline_stages(int cpl, int32_t max_subject_len) { return std::max<int64_t>(1, ((int64_t)max_subject_len + 64 * cpl - 1) / (64 * cpl)); }
 }  // namespace
 
@@ -791,26 +832,31 @@ int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, cons
 size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx* ctx, int32_t n, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || n <= 0 || max_subject_len < 0) return 0;
     const int64_t tickets = (int64_t)n * pipeline_stages(pipeline_cpl(ctx, n, max_subject_len), max_subject_len);
-    return (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
+    return kPipeCtrlBytes + (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
 }
 
 namespace {
 // the launch both pipelined entry points share: `tickets` workgroups of one wave, hand-off words at `xfer`
 int launch_pipeline(sw_ctx* ctx, swk::PipelineParams& p, int cpl, int64_t stages, int64_t tickets, uint32_t* start_signal, void* xfer,
                     hipStream_t stream) {
-    const size_t need = (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
+    const size_t need = kPipeCtrlBytes + (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
     p.query = ctx->d_query; p.qlen = ctx->qlen; p.matrix = ctx->d_matrix; p.dim = ctx->dim;
-    p.xfer = static_cast<unsigned long long*>(xfer);
-    p.ctrl = ctx->d_pipe_ctrl + 4 * (ctx->pipe_next++ % sw_ctx::kPipeCtrlSlots);
+    // the launch's control words sit in front of its hand-off words, in the caller's buffer: one memset for both, and no
+    // shared ring that a launch in flight on another stream could still be using
+    p.ctrl = static_cast<uint32_t*>(xfer);
+    p.xfer = reinterpret_cast<unsigned long long*>(static_cast<char*>(xfer) + kPipeCtrlBytes);
     p.start_signal = start_signal;
-    // every workgroup counts itself in, also those whose stage does not exist: all of them fit the GPU at once
-    // (CUDASW4_AMD_PIPE_QUORUM=n: the handshake fires after the first n, for measurements)
-    p.start_quorum = (uint32_t)(ctx->pipe_quorum > 0 ? std::min<int64_t>(tickets, ctx->pipe_quorum) : tickets);
+    // every workgroup counts itself in, also those whose stage does not exist; the handshake fires once as many are
+    // resident as the device holds of them beside a bulk grid that is about to take every other slot — one-wave workgroups
+    // at the slot's register size, up to 16 per CU — or all of them, whichever is less (with more tickets than
+    // resident slots the bulk launch was released only when almost the whole pipeline had run)
+    const int slot_regs = ctx->pipe_slot > 0 ? ctx->pipe_slot : 128;
+    const int64_t resident = (int64_t)std::max(1, ctx->num_cus) * 4 * std::max(1, std::min(8, 512 / slot_regs)) / 2;
+    p.start_quorum = (uint32_t)std::max<int64_t>(1, std::min(tickets, ctx->pipe_quorum > 0 ? (int64_t)ctx->pipe_quorum : resident));
     p.max_stages = (int32_t)stages;
     p.spin_limit = ctx->pipe_spin_limit;
     p.test_drop_stage = ctx->pipe_drop_stage;
-    SW_HIP(hipMemsetAsync(p.ctrl, 0, 4 * sizeof(uint32_t), stream));
-    SW_HIP(hipMemsetAsync(xfer, 0xFF, need, stream));   // "not written yet"
+    SW_HIP(hipMemsetAsync(xfer, 0xFF, need, stream));   // "not written yet" / "minus one"
     const dim3 grid((unsigned)tickets), block(64);
     const int slot = ctx->pipe_slot;
 #define SW_PIPE_LAUNCH_B(CPL, B)                                                                                            \
@@ -876,7 +922,7 @@ int sw_scan_rows_pipelined(sw_ctx* ctx, const int8_t* chars, const uint64_t* off
     const int64_t stages = pipeline_stages(cpl, max_subject_len);
     const int64_t tickets = (int64_t)n * stages;
     if (tickets > (int64_t)1 << 24) return fail(SW_ERR_INVALID, "too many pipeline stages for one sw_scan_rows_pipelined launch");
-    const size_t need = (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
+    const size_t need = kPipeCtrlBytes + (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
     if (!temp || temp_bytes < need) return fail(SW_ERR_TEMP, "temp buffer too small for sw_scan_rows_pipelined (sw_scan_rows_pipelined_temp_bytes)");
     swk::PipelineParams p{};
     p.chars = chars; p.offsets = offsets; p.lengths = lengths; p.first_pos = first_pos; p.n = n;
@@ -889,7 +935,7 @@ int sw_scan_rows_pipelined(sw_ctx* ctx, const int8_t* chars, const uint64_t* off
 size_t sw_rescore_overflow_pipelined_temp_bytes(sw_ctx* ctx, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || max_subject_len < 0) return 0;
     const int64_t tickets = (int64_t)kPipeRescoreCap * pipeline_stages(pipeline_cpl(ctx, kPipeRescoreCap, max_subject_len), max_subject_len);
-    return pipe_rescore_header_bytes() + (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
+    return pipe_rescore_header_bytes() + kPipeCtrlBytes + (size_t)tickets * ((size_t)ctx->qlen + 1) * sizeof(unsigned long long);
 }
 
 int sw_rescore_overflow_pipelined(sw_ctx* ctx, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count, const int8_t* chars,
@@ -1156,7 +1202,11 @@ size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t
     const int subj_per_batch = (swk::kThreads / lanes) * (kind_packed(kind) ? 2 : 1);
     const int64_t nbatches = ((int64_t)n + subj_per_batch - 1) / subj_per_batch;
     const int64_t grid = std::min<int64_t>(nbatches, max_grid(ctx));
-    return (size_t)grid * border_bytes_per_wg(border_capacity(max_subject_len, lanes), lanes);
+    // streamed subjects: the border arrays hold a round of several slots (gap scores are not known here: -1 is what the
+    // default and almost every caller use; a scratch sized for fewer columns only makes the rounds shorter)
+    const StreamPlan sp = stream_plan(ctx, kind, lanes, 1, pl, max_subject_len, true);
+    const int32_t cols = sp.slots > 1 ? std::max(max_subject_len, sp.cols) : max_subject_len;
+    return (size_t)grid * border_bytes_per_wg(border_capacity(cols, lanes), lanes);
 }
 
 int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, const uint64_t* offsets,

@@ -156,6 +156,8 @@ struct Arith<I16X2> {
     // column-offset recurrence (dp_step<OFFS>): the zero level of column offset k, +a, star -> true values
     static __host__ __device__ u32 zero_at(int a, int k) { u32 z = (u32)(kBias + a * k) & 0xffffu; return z | (z << 16); }
     static __host__ __device__ u32 pos_word(int a) { u32 m = (u32)a & 0xffffu; return m | (m << 16); }
+    // the zero level v (sw_stream_kernel.hpp: levels with a base and jumps) in both halves
+    static __device__ __forceinline__ u32 level_word(int v) { const u32 z = (u32)(kBias + v) & 0xffffu; return z | (z << 16); }
     static __device__ __forceinline__ u32 true_of(u32 m, u32 z) { return gap(m, z); }  // plain unsigned integers
     static __device__ __forceinline__ u32 true_max(u32 a, u32 b) {
         return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -210,6 +212,11 @@ struct Arith<F16X2> {
     static __device__ __forceinline__ int score_hi(u32 v) { return (int)(float)__builtin_bit_cast(f16x2, v).y; }
     static __host__ __device__ u32 zero_at(int a, int k) { u32 h = half_bits(a * k); return h | (h << 16); }
     static __host__ __device__ u32 pos_word(int a) { u32 h = half_bits(a); return h | (h << 16); }
+    // the zero level v (|v| <= 2048: exact) in both halves, by the hardware conversion
+    static __device__ __forceinline__ u32 level_word(int v) {
+        const u32 h = (u32)__builtin_bit_cast(unsigned short, (_Float16)(float)v);
+        return h | (h << 16);
+    }
     static __device__ __forceinline__ u32 true_of(u32 m, u32 z) {
         return __builtin_bit_cast(u32, (f16x2)(__builtin_bit_cast(f16x2, m) - __builtin_bit_cast(f16x2, z)));
     }
@@ -415,11 +422,18 @@ struct ScanParams {
     // from the start.  nullptr: none.
     u32* dry_signal;
     u32 dry_value;
-    // Streamed subjects (sw_stream_kernel.hpp): batches a workgroup may claim at once (<= 1: one batch at a time) and the
-    // zero levels a lane takes on when it switches to the next slot's subject: sw_levels[j] = the level a * (LANES - 4 + j)
-    // in the kind's encoding (Arith::zero_at)
+    // Streamed subjects (sw_stream_kernel.hpp): batches a workgroup may claim at once (<= 1: sw_scan_kernel), the most columns
+    // a round of several slots may have (the border scratch of multi-stripe queries is sized for it) and the most its
+    // a * columns + jumps may add up to (the frame is not lowered inside such a round); the level of column -LANES (fp16
+    // starts at the bottom of its exact range); what a lane's zero levels rise by at a slot border, and from which score of
+    // the slot before on a slot is flagged (its lanes may have kept values above the raised levels)
     int32_t stream_slots;
-    u32 sw_levels[16];
+    int32_t stream_cols;
+    int32_t stream_room;
+    int32_t level_base;
+    int32_t jump;
+    u32 jump_word;
+    int32_t jump_limit;
 };
 
 constexpr int32_t kListEmpty = -1, kListTaken = -2;
@@ -559,7 +573,9 @@ struct StripeState {
 // that grow with the column index: the launcher picks OFFS only while a * columns stays well inside the exact range
 // of the kind, and a subject whose bound maxscore + a * columns reaches the limit is flagged like an overflow.
 // `first` (MULTI): the stripe has no predecessor, lane 0's boundary is the zero level instead of the border row.
-template <int KIND, int R, int LANES, int BYTE, bool MULTI, bool OFFS = false, int P = 1>
+// ZFILL = false (sw_stream_kernel.hpp): the head lane's vertical gap state is the column's zero level (class 0) instead of the
+// bound_ctrl zero fill — levels that start below zero, and separator columns, which rebuild a lane's state from it.
+template <int KIND, int R, int LANES, int BYTE, bool MULTI, bool OFFS = false, int P = 1, bool ZFILL = true>
 __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsigned char* tile,
                                         u32 lettersA, u32 lettersB, u32 gop, u32 gex, u32 inH, u32 inF,
                                         u32 apos = 0, bool first = false, u32 wrapP = 0, u32 wrapLast = 0, bool head = false,
@@ -623,7 +639,8 @@ __device__ __forceinline__ void dp_step(StripeState<KIND, R, P>& st, const unsig
             upH = prev_lane<LANES, false>(bH, st.Hlast, head);
             // any F below the column's zero level is "no vertical gap": bound_ctrl zero fill (pattern 0 is below every
             // zero level of every kind, and the fp16 comparator of the int16 kind orders +0.0 below all its patterns)
-            F = prev_lane<LANES, true>(0u, st.Fout, head);
+            if constexpr (ZFILL) F = prev_lane<LANES, true>(0u, st.Fout, head);
+            else F = prev_lane<LANES, false>(st.Zc[Q], st.Fout, head);
         }
         u32 diag = st.upH_prev;
         st.upH_prev = upH;

@@ -34,6 +34,12 @@ constexpr int kWaves3MaxRowsPackedMulti = SWK_WAVES3_MAX_R_MULTI;  // int32 cann
 // long-subject shape (64-lane groups)
 constexpr int kMaxRowsPackedLong = 16;  // stripe = 1024 query rows, 43 KB tile
 constexpr int kMaxRowsScalarLong = 8;   // stripe = 512 query rows, 43 KB tile
+// single-stripe queries on 16-lane groups start above the 8-lane shape's 256 residues: the streamed kernel is compiled from
+// there up (shorter queries reach 16-lane groups only through explicit limits of tests and A/B runs: sw_scan_kernel)
+#ifndef SWK_STREAM_MIN_ROWS_SINGLE
+#define SWK_STREAM_MIN_ROWS_SINGLE 16
+#endif
+constexpr int kStreamMinRowsSingle = SWK_STREAM_MIN_ROWS_SINGLE;
 
 constexpr int max_rows(int kind, int lanes) {
     const bool packed = kind == F16X2 || kind == I16X2;
@@ -107,16 +113,20 @@ hipError_t launch_scan_ro(bool multi, int grid, int reserve, hipStream_t stream,
     } else {
         if (multi) {
             if constexpr (2 * R > kMaxR && LANES != 4) {   // (4-lane groups: single-stripe queries only)
+                // packed kinds, 16-lane groups, column-offset recurrence, a plain subject range: the subjects of up to
+                // p.stream_slots batches stream through the lanes back to back, stripe after stripe (sw_stream_kernel.hpp)
+                if constexpr (OFFS && Arith<KIND>::kPacked && LANES == 16) {
+                    if (p.stream_slots > 1 && !p.positions && !p.claim && !p.service && !p.count_ptr)
+                        return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, true>, grid, reserve, stream, p);
+                }
                 return launch_scan_k(sw_scan_kernel<KIND, R, LANES, true, OFFS>, grid, reserve, stream, p);
             } else {
                 return hipErrorInvalidValue;
             }
         } else {
-            // single-stripe queries, column-offset recurrence with windows, short groups, a plain subject range: the subjects
-            // of up to p.stream_slots batches stream through the lanes back to back (sw_stream_kernel.hpp)
-            if constexpr (OFFS && Arith<KIND>::kWindow && LANES == 16) {
+            if constexpr (OFFS && Arith<KIND>::kPacked && LANES == 16 && R >= kStreamMinRowsSingle) {
                 if (p.stream_slots > 1 && !p.positions && !p.claim && !p.service && !p.count_ptr)
-                    return launch_scan_k(sw_stream_kernel<KIND, R, LANES>, grid, reserve, stream, p);
+                    return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, false>, grid, reserve, stream, p);
             }
             return launch_scan_k(sw_scan_kernel<KIND, R, LANES, false, OFFS>, grid, reserve, stream, p);
         }

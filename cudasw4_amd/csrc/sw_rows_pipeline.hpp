@@ -64,7 +64,11 @@ struct PipelineParams {
     int32_t* ids;
     int64_t id_offset;
     unsigned long long* xfer;  // hand-off words: (qlen + 1) per ticket, all ones before the launch
-    uint32_t* ctrl;            // zeroed before the launch: [0] tickets handed out, [1] workgroups counted in (start handshake), [2] abort
+    // the 16 bytes in front of the hand-off words, filled with 0xFF together with them by ONE memset ("not written yet" and
+    // "minus one"): [0] tickets handed out, minus one; [1] workgroups counted in (start handshake), minus one; [2] abort (1:
+    // raised).  (Round 5 kept these words in a ring of 64 blocks of the context that nothing guarded against reuse by a
+    // launch still in flight on another stream: ADVICE r5.)
+    uint32_t* ctrl;
     uint32_t* start_signal;    // start handshake (sw_set_start_signal), or nullptr
     uint32_t start_quorum;
     int32_t* fail_count;       // += 1 per stage that gave up waiting (nullptr: not counted)
@@ -107,12 +111,12 @@ __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelinePara
     const int lane = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);   // a stage is a dependent chain that everybody to its right waits for
     if (p.start_signal && lane == 0) {
-        if (atomicAdd(p.ctrl + 1, 1u) + 1u == p.start_quorum)
+        if (atomicAdd(p.ctrl + 1, 1u) + 2u == p.start_quorum)
             __hip_atomic_fetch_add(p.start_signal, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // (subject, stage) from a ticket taken NOW: the stage this one waits for holds the ticket before, so it has started
     uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(p.ctrl, 1u);
+    if (lane == 0) t = atomicAdd(p.ctrl, 1u) + 1u;
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     const int stage = (int)(t % (uint32_t)p.max_stages);
     int pos;
@@ -167,15 +171,24 @@ __global__ void __launch_bounds__(64) sw_rows_pipeline_kernel(const PipelinePara
     const int sl = lane & (kPipeBatch - 1);
 
     // a wait for the stage before: poll until none of the wanted words is "not written yet"; bounded
+    // (bounded by the CLOCK, not by a number of polls: a poll takes 2 us on an idle chip and many times that for a wave that is
+    // descheduled or shares its SIMD with a busy grid — ADVICE r5.  spin_limit keeps its unit: polls of nominally 2 us = 200
+    // ticks of the 100 MHz clock; the default 2^20 is ~2 s.)
     auto await = [&](unsigned long long v, size_t idx, bool want) -> unsigned long long {
         uint32_t spins = 0;
+        unsigned long long t_first = 0;
         while (__builtin_amdgcn_ballot_w64(want && v == kPipeEmpty) != 0ull) {
             __builtin_amdgcn_s_sleep(2);
             v = pipe_load(xin + idx);
             spins++;
-            if (spins >= p.spin_limit || ((spins & 63u) == 0u && __hip_atomic_load(p.ctrl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                failed = true;
-                break;
+            if ((spins & 63u) == 0u) {
+                const unsigned long long now = wall_clock64();
+                if (t_first == 0) t_first = now;
+                if (now - t_first > 200ull * (unsigned long long)p.spin_limit ||
+                    __hip_atomic_load(p.ctrl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) {
+                    failed = true;
+                    break;
+                }
             }
         }
         return v;

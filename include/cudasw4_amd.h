@@ -155,42 +155,11 @@ int sw_rescore_overflow_stat(sw_ctx* ctx, int kind,
                              void* temp, size_t temp_bytes,
                              int32_t packed_limit, int32_t* true_overflow_count, void* stream);
 
-/* Re-scoring an overflow list WHILE it is filled.  The ordinary re-score launch runs behind the packed launch that fills
- * its list: on real data (the queries' own family in the DB) the few long subjects it then walks are pure tail — 9 ms for
- * one 5 500-residue subject against a 5 478-residue query, behind a 106 ms scan.  A SERVICE launch of a few workgroups,
- * started beside the packed launch (sw_set_start_signal), polls the list's length, takes entries as they appear and
- * leaves when *done_flag (a word the caller sets behind the packed launch, e.g. hipStreamWriteValue32) has reached
- * done_value; sw_rescore_overflow_claim then re-scores what the service has not taken.  Both take entries by
- * compare-and-swap, so the list must start as all -1 (hipMemsetAsync 0xFF over the packed launch's ovf_pos slice) and is
- * consumed (entries become -2).  `workgroups`: size of the service (each holds a workgroup slot for the packed launch's
- * whole duration); temp: sw_rescore_service_temp_bytes.  Otherwise as sw_rescore_overflow_stat. */
-size_t sw_rescore_service_temp_bytes(sw_ctx* ctx, int kind, int32_t max_subject_len, int workgroups);
-int sw_rescore_service(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
-                       const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
-                       int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
-                       int32_t packed_limit, int32_t* true_overflow_count, const uint32_t* done_flag, uint32_t done_value,
-                       int workgroups, void* stream);
-int sw_rescore_overflow_claim(sw_ctx* ctx, int kind, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count,
-                              const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
-                              int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* temp, size_t temp_bytes,
-                              int32_t packed_limit, int32_t* true_overflow_count, void* stream);
-
 /* 1 if a kernel on stream_b can start while a kernel on stream_a is still running, 0 if the runtime serialises the two
  * streams (it multiplexes streams onto a few hardware queues; two kernels of one queue never overlap), < 0 on error.  A
  * ~5 ms probe for callers that are about to keep a POLLING kernel on one of the streams (sw_rescore_service): behind a
  * polling kernel on the same queue, the launch it waits for would never start.  Synchronises both streams. */
 int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b);
-
-/* Start handshake for launches that must run BESIDE a launch that fills the GPU (the reference gets that overlap from
- * its ten work streams, cudasw4.cuh:293,1745-1748; on this runtime a persistent grid that is dispatched first keeps every
- * workgroup slot until its end, and a small launch on another stream — the few giant subjects of partition 35 — then
- * runs BEHIND it instead of beside it, whichever stream was enqueued first).  One-shot: the NEXT sw_scan_partition /
- * sw_rescore_overflow launch of this context adds 1 to *signal (system scope) as soon as its workgroups are resident
- * (all of them up to 64; the first 64 of a larger launch).  `signal` must be signal memory
- * (hipExtMallocWithFlags(..., hipMallocSignalMemory)); the caller orders the big launch behind it with
- * hipStreamWaitValue32(stream, signal, expected, hipStreamWaitValueGte).  NULL cancels; so does a launch that fails or
- * has n == 0 (nothing is enqueued, nothing will fire: do not wait for it). */
-int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
 
 /* Measurement aid for the roofline of this path (bench.py): a ~millis ms micro-run of the instruction mix
  * that bounds a kind's inner loop on every SIMD of the device — mix 0: v_pk_maximum3_f16 (the VOP3P issue rate of the packed
@@ -203,121 +172,108 @@ int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
  * the counters do not allow it).  Runs on the null stream and synchronises. */
 int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_per_s, double* shader_hz);
 
-/* The handshake in miniature, for callers that are about to rely on it: a one-thread kernel on side_stream
- * adds 1 to *signal and stays resident for at most 10 ms; gated_stream waits for that value
- * (hipStreamWaitValue32) and then runs a kernel the side kernel looks for.  1: the gated kernel started BESIDE the side
- * kernel — the pattern sw_set_start_signal, sw_rescore_service and sw_set_dry_signal build on works here; 0: it did not
- * (kernels serialised by a profiler or a debug setting, wait-value packets that are never released: after ~2 s the host
- * releases the wait by hand) — do not use them, a polling side kernel would hang the stream; < 0: error.  Synchronises
- * both streams; *signal is left as it was found. */
-int sw_probe_handshake(sw_ctx* ctx, void* side_stream, void* gated_stream, uint32_t* signal);
+/* The building blocks sw_scan_batch (below) is made of — side-launch handshake, row pipelines for the giants, windows, the
+ * re-score service and its claim protocol, the tail hand-over signals — are declared in cudasw4_amd_engine.h: exported, tested
+ * one by one, but nothing a binding needs (round 5 had them all here: 45 exports for a boundary of 6 calls). */
 
-/* The few VERY long subjects of a real DB (partition 35: more than 8000 residues, 35 000 in Swiss-Prot), row-parallel.
- * sw_scan_partition gives a subject to one alignment group — for these one wave —, which walks its columns one by one:
- * 35 000 dependent steps per stripe of the query, whatever else the GPU does (the reference has the same shape: one
- * thread group per subject, cudasw4.cuh:2026-2103).  Beside the bulk launch of a whole DB that is hidden; on a shard of a
- * DB (what each of N GPUs gets) it is the floor of every query, and for short queries it outlasts the bulk launch on one
- * GPU.  sw_scan_rows gives every subject of [first_pos, first_pos + n) a WORKGROUP of 1024 threads that walks the query
- * row by row, all columns of the subject at once, the horizontal gap as a max-plus prefix over the workgroup (exact for
- * gop <= gex; csrc/sw_rows_kernel.hpp).  int32 arithmetic; same scores (as floats) and ids as sw_scan_partition with a
- * 32-bit kind, no overflow list, no scratch.  max_subject_len must not exceed sw_scan_rows_max_subject() (40 960) and
- * must cover every subject of the range: the kernel never compares a length with it, columns beyond it would be dropped
- * (CUDASW4_AMD_CHECK_BOUNDS=1 verifies the contract on the device, as for sw_scan_partition).  Honours
- * sw_set_start_signal.  Errors (SW_ERR_INVALID): gop > gex, a subject bound above the limit, an armed sw_set_dry_signal
- * (these launches have no work counter that could run dry: the armed signal is cancelled and the call refused). */
-int32_t sw_scan_rows_max_subject(void);
-int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos,
-                 int32_t n, int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
-                 void* stream);
+/* ------------------------------------------------------------------------------------------------------------------
+ * ONE call per batch: the whole body of the reference's runAlignmentKernels (cudasw4.cuh:1742-2103) and its overflow
+ * block (cudasw4.cuh:2134-2172).  sw_scan_partition / sw_rescore_overflow above are the launchers the reference calls
+ * one by one; a caller that walks the 36 partitions with them, one launch behind the other on one stream (INTEGRATION.md
+ * section 2, first form), pays a launch tail per partition and leaves everything that makes real DBs fast to itself:
+ * merging the partitions of one arithmetic kind into one persistent grid, running the few long subjects BESIDE that grid
+ * (side streams + the start handshake), cutting the giants into pipelines of one-wave stages or into windows, re-scoring
+ * the overflow lists while they are filled.  sw_scan_batch does all of that behind the boundary:
+ *
+ *   sw_batch_create(ctx, work_stream, &b)   once per context: side streams, signal memory, probes (bounded)
+ *   sw_set_query(ctx, ...)                  per query, as before
+ *   sw_scan_batch(b, &args)                 per batch of the DB (a resident DB is one batch): plans and enqueues every
+ *                                           launch of the batch; returns without waiting for the device
+ *   sw_batch_join(b, stream)                `stream` waits for everything the batches so far put on side streams
+ *   sw_topk(...)
+ *
+ * The engine owns its side streams and scratch buffers (grown on demand, each at most max_temp_bytes); nothing in it is
+ * shared between contexts.  Round 6 moved this orchestration out of the host driver (cudasw4_amd/csrc/host), which now is
+ * a caller of sw_scan_batch like any other binding. */
+typedef struct sw_batch sw_batch;
 
-/* The same subjects on MANY compute units at once (csrc/sw_rows_pipeline.hpp; round 5).  sw_scan_rows is bound by one
- * CU per subject: 4.1 us per query row for a 35 000-residue protein, whatever the GPU's size — the rank of a sharded
- * real DB that holds that protein ran at 0.60 of the full-DB rate.  Here every subject is cut into spans of 256 ... 1024
- * columns and every span is a stage of a pipeline — one wave that walks the query row by row, a few rows behind its left
- * neighbour, which hands it the row's prefix maximum and its last H as one 64-bit word through `temp` (agent-scope
- * atomics; a word is written once and read once).  ~0.3 us per query row for ANY subject length.  Same results, same
- * contract as sw_scan_rows (gop <= gex; max_subject_len covers every subject; honours sw_set_start_signal — ALL
- * workgroups count themselves in; refuses an armed dry signal), any subject length with max_subject_len * |gex| < 2^28.
- *   temp / temp_bytes  at least sw_scan_rows_pipelined_temp_bytes(ctx, n, max_subject_len) for the CURRENT query
- *                      (8 bytes x (query length + 1) x n x stages of the longest subject); overwritten by the launch.
- *   fail_count         optional device word (zeroed by the caller): += 1 for every stage that gave up waiting for its
- *                      neighbour.  Cannot happen on a healthy device (a stage only waits for a workgroup that started
- *                      before it), but every wait is bounded all the same (CUDASW4_AMD_PIPE_SPIN_LIMIT polls, default
- *                      2^20 ~ 2 s); the subject's score is then -2 and the caller must treat the scan as failed.
- *   over_limit_count / over_limit_count2 / packed_limit
- *                      optional device words: each += 1 per subject whose score is >= packed_limit — for subjects of a
- *                      partition that would otherwise run on a packed kind, the reference's overflow statistic
- *                      (half2_kernels.cuh:1087-1109; cf. sw_rescore_overflow_stat) and the caller's count of subjects
- *                      scored in 32 bits. */
-/* The 32-bit re-score of the LONG subjects of an overflow list, pipelined (round 5).  A flagged subject is one alignment
- * group's walk in sw_rescore_overflow* — 16 ms for a 5 500-residue relative of a 5 478-residue query, behind the launch
- * that flagged it: on a shard of a real DB that is longer than the whole bulk launch.  This call moves the entries of the
- * list whose subject has at least min_subject_len residues (at most 64 of them) to a list of its own inside `temp`, marks
- * them taken in the original list (compare-and-swap, the protocol of sw_rescore_service / sw_rescore_overflow_claim) and
- * scores them with the stages of sw_scan_rows_pipelined (same contract: gop <= gex, max_subject_len covers the list's
- * subjects and max_subject_len * |gex| < 2^28).  Call it on the stream BEHIND the launch that filled the list and IN FRONT
- * of sw_rescore_overflow_claim, which then re-scores what is left.  true_overflow_count / packed_limit as in
- * sw_rescore_overflow_stat; fail_count as in sw_scan_rows_pipelined; temp_bytes at least
- * sw_rescore_overflow_pipelined_temp_bytes(ctx, max_subject_len) for the current query. */
-size_t sw_rescore_overflow_pipelined_temp_bytes(sw_ctx* ctx, int32_t max_subject_len);
-int sw_rescore_overflow_pipelined(sw_ctx* ctx, int32_t* ovf_pos, const int32_t* ovf_count, int32_t max_count, const int8_t* chars,
-                                  const uint64_t* offsets, const int32_t* lengths, int32_t max_subject_len,
-                                  int32_t min_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
-                                  int32_t* fail_count, int32_t packed_limit, int32_t* true_overflow_count, void* temp,
-                                  size_t temp_bytes, void* stream);
+/* counters a batch leaves in device memory (sw_batch_args::counters, zeroed by the CALLER — one memset per query covers
+ * the blocks of all its batches): */
+#define SW_BATCH_COUNTERS 8
+#define SW_BATCH_CNT_OVERFLOWS 0   /* subjects whose exact score reached their packed kind's limit (the reference's statistic) */
+#define SW_BATCH_CNT_LIST0 1       /* .. LIST0 + 3: lengths of the batch's overflow lists = subjects re-scored in 32 bits */
+#define SW_BATCH_CNT_FAILED 5      /* pipeline stages that gave up waiting (sw_scan_rows_pipelined): the scan failed if != 0 */
+#define SW_BATCH_CNT_PIPE_OVER 6   /* pipelined subjects of packed partitions at or above the packed limit (scored in 32 bits) */
 
-/* A pipelined launch that runs BESIDE a persistent scan launch must not leave holes behind: a SIMD's vector registers are
- * allocated as contiguous ranges, the scan launch's waves stay where they were placed to the end of the scan, and a hole
- * smaller than one of its waves at the start of the register file costs it a wave per SIMD for its whole duration
- * (measured: 8 ... 35 % of the bulk launch's rate for a pipelined launch of 2 ms).  sw_launch_vgpr_slot says how many
- * VGPRs a wave of the launch sw_scan_partition (part_id >= 0) / sw_rescore_overflow (part_id = -1) would make for the
- * current query may take (128, 168 or 256; 0: unknown); sw_set_rows_pipeline_slot (sticky) makes every stage of the
- * following sw_scan_rows_pipelined launches occupy exactly that many, so that a queued wave of the scan launch fits the
- * hole a stage leaves (0, the default: as few as the stage needs).  The stages use no LDS for the same reason. */
-int sw_launch_vgpr_slot(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len);
-int sw_set_rows_pipeline_slot(sw_ctx* ctx, int vgprs);
-size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx* ctx, int32_t n, int32_t max_subject_len);
-int sw_scan_rows_pipelined(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths,
-                           int32_t first_pos, int32_t n, int32_t max_subject_len, int gop, int gex, float* scores,
-                           int32_t* ids, int64_t id_offset, int32_t* fail_count, int32_t* over_limit_count,
-                           int32_t* over_limit_count2, int32_t packed_limit, void* temp, size_t temp_bytes, void* stream);
+/* one timed launch (optional: sw_batch_args::records) */
+typedef struct sw_launch_record {
+    void* ev0; void* ev1;            /* hipEvent_t pair supplied by the caller, recorded around the launch on its stream */
+    int32_t kind, part_id;           /* requested kind; largest partition of the run (-1: re-score) */
+    int32_t eff_kind, rows, nstripes, lanes;   /* the instantiation the library chose (sw_plan_launch) */
+    int32_t begin, end;              /* batch-local subject range of the run */
+    int32_t rescore;
+} sw_launch_record;
 
-/* Sticky: partition 34 (1281 ... 8000 residues) runs on 16-lane groups from `subjects` subjects of a launch up and on
- * wave-wide groups below (default 512; < 0: back to the default).  Wave-wide groups finish ONE subject 3 x sooner at 60 %
- * of the throughput: a caller whose launch is short against its longest subject's walk on 16 lanes — a small shard of a
- * real DB — asks for them whatever the count (the host driver's latency mode). */
-int sw_set_long16_min(sw_ctx* ctx, int32_t subjects);
+typedef struct sw_batch_args {
+    int kinds[4];                    /* KernelTypeConfig (cudasw4.cuh:88-93): singlePass, manyPass_small, manyPass_large, overflow */
+    const int8_t* chars;             /* DEVICE: the batch's dbdata arrays (as for sw_scan_partition) */
+    const uint64_t* offsets;
+    const int32_t* lengths;
+    int32_t n;                       /* subjects of the batch, sorted by length (dbdata order) */
+    const int32_t* part_begin;       /* HOST, SW_NUM_LENGTH_PARTITIONS + 1: first batch-local position of every length partition */
+    const int32_t* part_maxlen;      /* HOST, SW_NUM_LENGTH_PARTITIONS: longest subject of every partition (empty: anything) */
+    const int32_t* long_lengths;     /* HOST, optional: true lengths of the positions part_begin[34] .. n - 1 (partitions 34 / 35): lets
+                                        the engine pick the subjects whose lone walk would outlast the bulk launch (pipelines, windows);
+                                        NULL: whole partitions by their bounds */
+    const uint64_t* long_offsets;    /* HOST, optional, with long_lengths: byte offsets of the same positions; minus long_offsets_bias they are
+                                        relative to `chars` (windows of long subjects for short queries) */
+    uint64_t long_offsets_bias;
+    uint64_t batch_bytes;            /* padded subject bytes of the batch (planning estimates only) */
+    int gop, gex;
+    float* scores; int32_t* ids; int64_t id_offset;   /* DEVICE, indexed by batch-local position */
+    int32_t* ovf_pos;                /* DEVICE, n entries: the overflow lists of the batch's packed launches live in slices of it */
+    int32_t* counters;               /* DEVICE, SW_BATCH_COUNTERS ints, zeroed before the call (stream-ordered) ... */
+    int zero_counters;               /* ... or by the call itself (1: one memset on `stream`; a caller with several batches per query zeroes all
+                                        their blocks with one memset of its own and passes 0) */
+    size_t max_temp_bytes;           /* cap of each of the engine's scratch buffers (0: 4 GiB) */
+    void* stream;                    /* the work stream: bulk launch, its re-score; side streams fork from it */
+    int work_slot;                   /* 0 / 1: which of the engine's two work-stream scratch buffers (batches that overlap on two work streams) */
+    int allow_service;               /* re-score service beside the bulk launch allowed (resident chars, nothing else of the caller polls) */
+    /* tail hand-over between two queries in flight (sw_set_dry_signal): the bulk launch arms arm_signal with arm_value,
+     * and waits for wait_signal >= wait_value before it starts (NULL / 0: none) */
+    uint32_t* arm_signal; uint32_t arm_value;
+    uint32_t* wait_signal; uint32_t wait_value;
+    int32_t grid_reserve_side;       /* workgroup slots the bulk grid leaves free when the batch has side work (two queries in flight) */
+    int alt_side_stream;             /* start the side launches on the engine's second auxiliary stream (consecutive queries alternate) */
+    sw_launch_record* records; int32_t records_cap; int32_t* records_used;   /* optional: event pairs + what ran between them */
+    int record_mode;                 /* 0: none, 1: every launch, 2: work-stream launches only */
+} sw_batch_args;
 
-/* Tail hand-over between consecutive queries.  The reference scans one query at a time (main.cu:217-260); on a small
- * shard (what each of N GPUs gets from a DB) the last, partly filled round of a query's persistent grid leaves most of
- * the GPU idle.  sw_set_dry_signal is one-shot like sw_set_start_signal: the NEXT sw_scan_partition launch of this
- * context stores `value` in *signal (system scope; signal memory) when its work counter runs dry — the first workgroup
- * finds nothing left to take while the others finish their last batches.  The caller orders the next query's bulk launch
- * (another context, stream, score array and scratch) behind that value with hipStreamWaitValue32(..., Gte), so that its
- * workgroups take the slots this launch frees one by one; launched without the gate, the two grids would share the CUs
- * for their whole duration.  Values must increase from launch to launch.  A launch that fails or has n == 0 never fires.
- * sw_set_grid_reserve (sticky): scan launches of this context leave `workgroups` of the slots the device has for their
- * kernel free (the grid is capped at resident - reserve), so that small launches of other streams find a slot while a
- * persistent grid holds the rest.  0: none (the host driver's setting: measured, the hand-over gains nothing from it). */
-int sw_set_dry_signal(sw_ctx* ctx, uint32_t* signal, uint32_t value);
-int sw_set_grid_reserve(sw_ctx* ctx, int32_t workgroups);
-
-/* Long subjects against SHORT queries: exact windowing.  An alignment with a positive score of a query of Q residues spans
- * fewer than W = Q + Q * max(matrix) / min(|gop|, |gex|) + 1 subject columns (every gap column costs at least the
- * cheaper gap score, the aligned columns are worth at most Q * max(matrix)), so the DP value of any cell is already exact
- * when the recurrence starts W columns to its left with the local-alignment boundary.  A subject may therefore be cut into
- * overlapping WINDOWS — window k = columns [k * C - W, (k + 1) * C), starts on multiples of 4 — that are scanned like
- * independent subjects (sw_scan_partition on arrays of window offsets and lengths; a window is a valid subject as it is:
- * the kernels read whole 4-letter words and treat everything from the window's length on as padding), and the subject's
- * score is the maximum of its windows' scores: bit-identical to the unsplit scan, with len / C + 1 alignment groups
- * working on a 35 000-residue protein instead of one (the reference, and rounds 1-3 here, walk such a subject's 35 000
- * dependent steps with a single group: for a 48-residue query that one subject took longer than the rest of Swiss-Prot).
- *   sw_window_overlap  W for the CURRENT query and these gap scores (-1: no bound, e.g. gex == 0)
- *   sw_reduce_windows  scores[real_pos[i]] = max(win_scores[win_first[i] .. win_first[i + 1])), ids[real_pos[i]] =
- *                      id_offset + real_pos[i] for i < n_real; all pointers DEVICE. */
-int32_t sw_window_overlap(sw_ctx* ctx, int gop, int gex);
-int sw_reduce_windows(sw_ctx* ctx, const float* win_scores, const int32_t* win_first, const int32_t* real_pos, int32_t n_real,
-                      float* scores, int32_t* ids, int64_t id_offset, void* stream);
+int sw_batch_create(sw_ctx* ctx, void* work_stream, sw_batch** out);
+int sw_batch_destroy(sw_batch* b);
+int sw_scan_batch(sw_batch* b, const sw_batch_args* args);
+/* `stream` waits for the side streams' work of every batch since the last join */
+int sw_batch_join(sw_batch* b, void* stream);
+/* record `events[i]` (hipEvent_t, i = 0..2: the two auxiliary streams, the service stream) behind the last side launch of
+ * the batch just enqueued on that stream; used[i] = 1 where the batch put work there (a staging buffer the batch read may
+ * be overwritten only after those events) */
+int sw_batch_side_events(sw_batch* b, void* const* events, int* used);
+/* after a query's counters came back: how many subjects it re-scored (sizes and arms the re-score service of later scans) */
+int sw_batch_feedback(sw_batch* b, int32_t rescored);
+/* 1: the start handshake passed its probe (side launches run beside the bulk grid by construction); 0: plain stream order */
+int sw_batch_handshake_active(const sw_batch* b);
+/* statistics since creation: out[0] pipelined launches, [1] pipelined re-scores, [2] window launches, [3] windows scanned,
+ * [4] service launches, [5] side launches */
+int sw_batch_stats(const sw_batch* b, int64_t* out, int n);
+/* the host-visible signal words of the engine (watchdog of a caller that polls with a deadline): values and targets;
+ * sw_batch_open_gates releases every stream wait of the engine by hand */
+int sw_batch_signal_state(const sw_batch* b, uint32_t* start_now, uint32_t* start_target, uint32_t* done_now, uint32_t* done_target);
+int sw_batch_open_gates(sw_batch* b);
+/* after a failed scan and a device synchronisation: nothing of the engine is in flight, its counts start afresh */
+int sw_batch_reset(sw_batch* b);
+/* test hook: the n-th side launch from now on is counted but never enqueued (0: off) */
+int sw_batch_test_lose_side_launch(sw_batch* b, int nth);
+int32_t sw_query_length(const sw_ctx* ctx);
 
 /* Per-GPU top-K (cudasw4.cuh:1357-1401): the k best (score desc, id asc on ties) of n results.
  * out_scores/out_ids: DEVICE, k entries, padded with (-1, -1) when n < k.

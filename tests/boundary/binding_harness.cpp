@@ -10,6 +10,8 @@
 #ifdef BINDING_ON_GPU   // the same block on real device buffers (tests/boundary/Makefile -> _build/binding_gpu)
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
+#include <chrono>
+#include <cstring>
 #include <fstream>
 #include <string>
 #endif
@@ -61,6 +63,8 @@ int main() {
     DeviceBatchCopyToPinnedPlan plan{std::vector<int>(36), std::vector<int>(36, 0)};
     GpuWorkingSet ws{};
     const char* inputChars = nullptr; const size_t* inputOffsets = nullptr; const SequenceLengthT* inputLengths = nullptr;
+    const size_t hostOffsetsStorage[2] = {0, 0};
+    const size_t* hostOffsets = hostOffsetsStorage; const SequenceLengthT* hostLengths = nullptr;   // DBdataView::offsets() / lengths()
     const int8_t encodedQueryStorage[4] = {0, 1, 2, 3};
     const int8_t* encodedQuery = encodedQueryStorage;
     const SequenceLengthT queryLength = 4;
@@ -93,14 +97,18 @@ static T* to_device(const std::vector<T>& v, size_t extra = 0) {
 
 // binding_gpu <dbdata prefix> <query = subject index>: the documented call sequence on the reference's dbdata files
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: binding_gpu dbprefix subjectIndexAsQuery [DPX]\n"); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: binding_gpu dbprefix subjectIndexAsQuery [DPX|-] [--bench queries.bin reps]\n"); return 2; }
+    const char* benchQueries = nullptr;
+    int benchReps = 2;
+    for (int i = 3; i + 1 < argc; i++)
+        if (std::string(argv[i]) == "--bench") { benchQueries = argv[i + 1]; if (i + 2 < argc) benchReps = std::atoi(argv[i + 2]); }
     const std::string prefix = argv[1];
     const auto hChars = read_file<char>(prefix + "0chars");
     const auto hOffsets = read_file<size_t>(prefix + "0offsets");
     const auto hLengths = read_file<SequenceLengthT>(prefix + "0lengths");
     const int numSubjects = int(hLengths.size());
     const int qi = std::atoi(argv[2]);
-    const bool dpx = argc > 3;
+    const bool dpx = argc > 3 && std::string(argv[3]) == "DPX";
     const int numGpus = 1;
     std::vector<int> deviceIds{0};
     std::vector<void*> gpuStreams{nullptr};
@@ -127,9 +135,10 @@ int main(int argc, char** argv) {
     HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_scores), size_t(numSubjects) * 4));
     HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_ids), size_t(numSubjects) * 4));
     HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_overflow_positions), size_t(numSubjects) * 4));
-    HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_overflow_number), 4));
-    HIPOK(hipMemset(ws.d_overflow_number, 0, 4));
-    ws.numTempBytes = size_t(256) << 20;
+    HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_overflow_number), SW_BATCH_COUNTERS * sizeof(int)));
+    HIPOK(hipMemset(ws.d_overflow_number, 0, SW_BATCH_COUNTERS * sizeof(int)));
+    const size_t* hostOffsets = hOffsets.data(); const SequenceLengthT* hostLengths = hLengths.data();   // DBdataView::offsets() / lengths()
+    ws.numTempBytes = size_t(1) << 30;
     HIPOK(hipMalloc(reinterpret_cast<void**>(&ws.d_tempStorageHE), ws.numTempBytes));
     // the query: subject qi of the same files (already encoded with ConvertAA_20)
     const int8_t* encodedQuery = reinterpret_cast<const int8_t*>(hChars.data() + (hOffsets[size_t(qi)] - hOffsets[0]));
@@ -150,6 +159,63 @@ int main(int argc, char** argv) {
 
 #ifdef BINDING_ON_GPU
     HIPOK(hipDeviceSynchronize());
+    if (benchQueries) {
+        // --bench: every query of the file through the documented per-query block, `reps` passes, wall clock around them
+        // (top-K inside, like the host driver's benchmark); the launcher-by-launcher form of INTEGRATION.md beside it
+        std::vector<std::vector<int8_t>> qs;
+        {
+            const auto raw = read_file<char>(benchQueries);
+            size_t at = 0;
+            while (at + 4 <= raw.size()) {
+                int32_t len = 0;
+                std::memcpy(&len, raw.data() + at, 4);
+                at += 4;
+                qs.emplace_back(raw.data() + at, raw.data() + at + len);
+                at += size_t(len);
+            }
+        }
+        double residues = 0, sumq = 0;
+        for (SequenceLengthT l : hLengths) residues += double(l);
+        for (auto& q : qs) sumq += double(q.size());
+        auto oneByOne = [&](const int8_t* q, SequenceLengthT qlen) {   // INTEGRATION.md section 2, second block
+            check(sw_set_query(swCtx[gpu], q, qlen, stream));
+            HIPOK(hipMemsetAsync(ws.d_overflow_number, 0, sizeof(int), (hipStream_t)stream));
+            for (int lp = numLengthPartitions - 1; lp >= 0; lp--) {
+                const int n = plan.h_numPerPartition[size_t(lp)];  if (n == 0) continue;
+                check(sw_scan_partition(swCtx[gpu], kindForPartition(lp), lp, (const int8_t*)inputChars, (const uint64_t*)inputOffsets, inputLengths,
+                        partBegin[size_t(lp)], n, boundaries[size_t(lp)], gop, gex, ws.d_scores, ws.d_ids, globalOffsetOfBatch,
+                        ws.d_overflow_positions, ws.d_overflow_number, 1, ws.d_tempStorageHE, ws.numTempBytes, stream));
+            }
+            check(sw_rescore_overflow(swCtx[gpu], dpx ? SW_KIND_I32 : SW_KIND_F32, ws.d_overflow_positions, ws.d_overflow_number, maxOverflows,
+                    (const int8_t*)inputChars, (const uint64_t*)inputOffsets, inputLengths, maxLen, gop, gex,
+                    ws.d_scores, ws.d_ids, globalOffsetOfBatch, ws.d_tempStorageHE, ws.numTempBytes, stream));
+            check(sw_topk(swCtx[gpu], ws.d_scores, ws.d_ids, numResults, results_per_query, d_topS, d_topI, d_tmp, tmpBytes, stream));
+        };
+        for (int form = 0; form < 2; form++) {
+            std::vector<float> top1(qs.size(), 0.0f);
+            double best = 1e30;
+            for (int rep = 0; rep < benchReps + 1; rep++) {   // (first pass: warm-up, and the top scores for the checker)
+                HIPOK(hipDeviceSynchronize());
+                const auto t0 = std::chrono::steady_clock::now();
+                for (size_t i = 0; i < qs.size(); i++) {
+                    if (form == 0) scanOneQuery(qs[i].data(), SequenceLengthT(qs[i].size()));
+                    else oneByOne(qs[i].data(), SequenceLengthT(qs[i].size()));
+                    if (rep == 0) { HIPOK(hipDeviceSynchronize()); HIPOK(hipMemcpy(&top1[i], d_topS, 4, hipMemcpyDeviceToHost)); }
+                }
+                HIPOK(hipDeviceSynchronize());
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (rep > 0) best = std::min(best, dt);
+            }
+            std::printf("BENCH %s gcups=%.1f seconds=%.4f queries=%zu TOP1", form == 0 ? "sw_scan_batch" : "one_launch_per_partition",
+                        sumq * residues / 1e9 / best, best, qs.size());
+            for (float v : top1) std::printf(" %d", int(v));
+            std::printf("\n");
+        }
+        for (auto* c : swBatch) sw_batch_destroy(c);
+        for (auto* c : swCtx) sw_ctx_destroy(c);
+        std::puts("binding ok");
+        return 0;
+    }
     std::vector<float> sc(static_cast<size_t>(numSubjects), 0.0f), ts(5, 0.0f);
     std::vector<int32_t> ti(5, 0);
     int novf = 0;
@@ -163,6 +229,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 5; i++) std::printf(" %d:%d", int(ts[size_t(i)]), ti[size_t(i)]);
     std::printf("\nOVERFLOWS %d\n", novf);
 #endif
+    for (auto* c : swBatch) sw_batch_destroy(c);
     for (auto* c : swCtx) sw_ctx_destroy(c);
     std::puts("binding ok");
     return 0;

@@ -156,7 +156,8 @@ def main(argv=None):
             os.environ["CUDASW4_AMD_LANES8_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 0, 100000])))
             os.environ["CUDASW4_AMD_LANES4_MAX_Q"] = str(int(r.choice([-1, 0, 100000, 100000])))   # (explicit: quads whatever the batch count)
             os.environ["CUDASW4_AMD_LANES4_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 100000])))
-            os.environ["CUDASW4_AMD_STREAM"] = str(int(r.choice([0, 0, 2, 4])))
+            os.environ["CUDASW4_AMD_STREAM"] = str(int(r.choice([1, 16, 16, 3])))
+            os.environ["CUDASW4_AMD_GRID_CAP"] = str(int(r.choice([0, 0, 1, 3])))   # few workgroups: long claims of the streamed kernels
             s = search.Searcher(device=0, num_top=min(10, n), matrix=m, kernel_types=kt, gop=gop, gex=gex,
                                 merge_partitions=bool(r.integers(0, 2)))
             s.set_database(search.DeviceDB.from_arrays(chars, offsets, lens, device=0))
@@ -183,11 +184,10 @@ def main(argv=None):
             # alone on its device)
             wmode = int(r.integers(0, 3))
             os.environ.pop("CUDASW4_AMD_WINDOWS", None)
-            os.environ.pop("CUDASW4_AMD_NO_WINDOWS", None)
             if wmode == 0:
                 os.environ["CUDASW4_AMD_WINDOWS"] = "always"
             elif wmode == 1:
-                os.environ["CUDASW4_AMD_NO_WINDOWS"] = "1"
+                os.environ["CUDASW4_AMD_WINDOWS"] = "0"
             smode = int(r.integers(0, 3))
             os.environ.pop("CUDASW4_AMD_RESCORE_SERVICE", None)
             if smode < 2:
@@ -196,11 +196,11 @@ def main(argv=None):
             os.environ.pop("CUDASW4_AMD_TAIL_OVERLAP", None)
             if r.integers(0, 4) == 0:
                 os.environ["CUDASW4_AMD_TAIL_OVERLAP"] = "0"
-            # round 5: which subjects run pipelined (never / every long one / by the estimate with an extreme share), the span
-            # width, the pipelined re-score, round 4's latency mode, the streamed-subjects kernel
-            r5 = {"CUDASW4_AMD_ROWS": r.choice(["", "never", "always", "single"]), "CUDASW4_AMD_PIPELINE_SHARE": r.choice(["", "0.02", "5"]),
+            # which subjects run pipelined (never / every long one / by the estimate with an extreme share), the span width, the
+            # pipelined re-score, the streamed packed kernels (round 6: one batch at a time / short / long claims)
+            r5 = {"CUDASW4_AMD_PIPELINES": r.choice(["", "0", "always"]), "CUDASW4_AMD_PIPELINE_SHARE": r.choice(["", "0.02", "5"]),
                   "CUDASW4_AMD_PIPELINE_RESCORE_SHARE": r.choice(["", "0.001", "1000"]), "CUDASW4_AMD_PIPE_CPL": r.choice(["", "4", "8", "16"]),
-                  "CUDASW4_AMD_LATENCY_MODE": r.choice(["", "auto", "always"]), "CUDASW4_AMD_STREAM": r.choice(["", "2", "4"]),
+                  "CUDASW4_AMD_STREAM": r.choice(["", "1", "4"]), "CUDASW4_AMD_GRID_CAP": r.choice(["", "2", "5"]),
                   "CUDASW4_AMD_SIDE_RESERVE": r.choice(["", "0", "64"]), "CUDASW4_AMD_LANES4_MAX_Q": r.choice(["", "0", "100000"]),
                   "CUDASW4_AMD_SPLIT34_MAX_LANES": r.choice(["", "0", "8"])}
             for k5, v5 in r5.items():

@@ -123,6 +123,7 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
     return hipSuccess;
 }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // everything ran at enqueue time
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = float(reinterpret_cast<FakeEvent*>(b)->t - reinterpret_cast<FakeEvent*>(a)->t); return hipSuccess; }
 
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t s) {

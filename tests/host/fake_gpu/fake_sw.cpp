@@ -12,6 +12,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "../../../include/cudasw4_amd.h"
+#include "../../../include/cudasw4_amd_engine.h"
 
 extern "C" int fake_hip_owner_of(const void* p);
 extern "C" int fake_hip_current_device();
@@ -47,8 +48,18 @@ int fake_score(const sw_ctx* c, const int8_t* s, int32_t len) {
 constexpr int kFakeLimit = 450;  // "packed overflow" threshold of the fake
 }
 
+// what the real batch engine (cudasw4_amd/csrc/sw_batch.hip, compiled into this fake library as it is) asks of its library
+#include "../../../cudasw4_amd/csrc/sw_internal.hpp"
+namespace swi {
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+int32_t query_length(const sw_ctx* c) { return c ? int32_t(c->query.size()) : 0; }
+int device_of(const sw_ctx* c) { return c ? c->device : -1; }
+int num_cus(const sw_ctx*) { return 256; }
+}  // namespace swi
+
 extern "C" {
 int fake_sw_bad_owner() { return g_bad_owner; }
+
 long fake_sw_scans(int device) { return g_scans[device]; }
 long fake_sw_rescored(int device) { return g_rescored[device]; }
 

@@ -17,7 +17,7 @@ def patched_source(tmp_path):
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     sec = md[md.index("## 2. Patch a reference maintainer would apply"):]
     block = re.search(r"```cpp\n(.*?)```", sec, re.S).group(1)
-    assert "sw_scan_partition(" in block and "sw_rescore_overflow(" in block and "sw_topk(" in block and "sw_set_matrix(" in block
+    assert "sw_scan_batch(" in block and "sw_batch_create(" in block and "sw_topk(" in block and "sw_set_matrix(" in block
     harness = open(os.path.join(ROOT, "tests", "boundary", "binding_harness.cpp")).read()
     assert harness.count("//@@INTEGRATION_MD_PATCH@@") == 1
     src = str(tmp_path / "binding.cpp")

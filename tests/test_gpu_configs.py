@@ -83,29 +83,6 @@ def test_config3_sprot_like_dpx_all_queries(sprot_db):
     d32.close()
 
 
-def test_results_do_not_depend_on_stream_creation_order(sprot_db, monkeypatch):
-    """Eight creation orders of the driver's streams (CUDASW4_AMD_STREAM_ORDER: W work, C copy, A / B auxiliary), same DB,
-    same queries: identical top lists; an order that names a stream twice is refused.  (That the RATE does not depend on
-    the order either is a wall-clock statement: tests/test_gpu_zz_timing.py, which sorts behind every parity test.)"""
-    from cudasw4_amd import driver
-    chars, offsets, lengths = sprot_db
-    _, letters = O.read_fasta(FASTA)
-    qs = [letters[3], letters[9], letters[19]]
-    tops = {}
-    for order in ("WCAB", "ABWC", "AWBC", "BAWC", "CABW", "WACB", "ACBW", "BWCA"):
-        monkeypatch.setenv("CUDASW4_AMD_STREAM_ORDER", order)
-        d = driver.Driver(devices=[0], num_top=10, kinds=(1, 1, 2, 2))
-        d.db_from_arrays(chars, offsets, lengths)
-        d.upload()
-        res = [d.scan(q) for q in qs]
-        tops[order] = [(r["scores"].tolist(), r["ids"].tolist()) for r in res]
-        d.close()
-    assert all(t == tops["WCAB"] for t in tops.values())
-    monkeypatch.setenv("CUDASW4_AMD_STREAM_ORDER", "WWAB")
-    with pytest.raises(driver.DriverError):
-        driver.Driver(devices=[0], num_top=10, kinds=(1, 1, 2, 2))
-
-
 @pytest.mark.parametrize("kinds", [(2, 1, 2, 2), (1, 1, 2, 2)])
 def test_config5_streaming_int32_three_shards(kinds):
     """Config 5's route: forced batch streaming (memory limit below the shard size), three shards in flight

@@ -168,11 +168,8 @@ def test_long_subjects_as_windows_for_short_queries(kinds, monkeypatch):
     chars, offsets, lengths = O.make_db(enc)
     results = {}
     for windows in (True, False):
-        monkeypatch.setenv("CUDASW4_AMD_WINDOWS", "always")   # also where the driver's time estimate would not bother
-        if windows:
-            monkeypatch.delenv("CUDASW4_AMD_NO_WINDOWS", raising=False)
-        else:
-            monkeypatch.setenv("CUDASW4_AMD_NO_WINDOWS", "1")
+        # "always": also where the engine's time estimate would not bother; "0": never
+        monkeypatch.setenv("CUDASW4_AMD_WINDOWS", "always" if windows else "0")
         d = driver.Driver(devices=[0], num_top=10, kinds=kinds)
         d.db_from_arrays(chars, offsets, lengths)
         d.upload()
@@ -330,10 +327,10 @@ def test_handshake_is_probed_and_falls_back_under_a_serialising_profiler(monkeyp
 
 
 @pytest.mark.parametrize("kinds", [(1, 1, 2, 2), (0, 0, 3, 3)])
-def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
-    """Small shards of real DBs: partition 34 on wave-wide groups beside the bulk launch (latency mode, sw_set_long16_min)
-    and the giants of partition 35 row-parallel (sw_scan_rows), each forced on, forced off and left to the driver's
-    estimates: every score of every query equals the oracle in every combination, the counters say which path ran."""
+def test_pipelined_giants_forced_off_on_and_by_the_estimate(kinds, monkeypatch):
+    """Small shards of real DBs: the longest subjects of partitions 34 / 35 as pipelines of one-wave stages
+    (sw_scan_rows_pipelined, chosen inside sw_scan_batch), forced off (CUDASW4_AMD_PIPELINES=0), forced on (=always) and left
+    to the engine's walk-time estimate: every score of every query equals the oracle each way, the counter says which path ran."""
     from cudasw4_amd import driver, synthdb
     rng = np.random.default_rng(5)
     _, letters = O.read_fasta(FASTA)
@@ -347,38 +344,29 @@ def test_latency_mode_and_row_parallel_giants(kinds, monkeypatch):
     chars, offsets, lengths = O.make_db(seqs)
     expect = [O.scan(O.encode(q), chars, offsets, lengths, simd=True) for q in queries]
     seen = {}
-    # (this DB's scans take well under 2 ms: without this switch the driver would not start hundreds of stages for them)
-    monkeypatch.setenv("CUDASW4_AMD_PIPELINE_MIN_BULK_MS", "0")
-    for rows in ("never", "always", "single", None):
-        for lat in ("never", "always", "auto", None):
-            if rows == "single" and lat is not None:
-                continue
-            for name, val in (("CUDASW4_AMD_ROWS", rows), ("CUDASW4_AMD_LATENCY_MODE", lat)):
-                if val is None:
-                    monkeypatch.delenv(name, raising=False)
-                else:
-                    monkeypatch.setenv(name, val)
-            d = driver.Driver(devices=[0], num_top=15, kinds=kinds)
-            d.db_from_arrays(chars, offsets, lengths)
-            d.upload()
-            tops = []
-            for qi, q in enumerate(queries):
-                r = d.scan(q)
-                sc, _ = d.last_scores(0)
-                assert (sc == expect[qi]).all(), (rows, lat, qi, np.nonzero(sc != expect[qi])[0][:5], lengths[np.nonzero(sc != expect[qi])[0][:5]])
-                tops.append((r["scores"].tolist(), r["ids"].tolist(), r["num_overflows"]))
-            seen[(rows, lat)] = (tops, d.rows_launches(), d.latency_scans(), d.pipeline_launches())
-            d.close()
+    for pipes in ("0", "always", None):
+        if pipes is None:
+            monkeypatch.delenv("CUDASW4_AMD_PIPELINES", raising=False)
+        else:
+            monkeypatch.setenv("CUDASW4_AMD_PIPELINES", pipes)
+        d = driver.Driver(devices=[0], num_top=15, kinds=kinds)
+        d.db_from_arrays(chars, offsets, lengths)
+        d.upload()
+        tops = []
+        for qi, q in enumerate(queries):
+            r = d.scan(q)
+            sc, _ = d.last_scores(0)
+            assert (sc == expect[qi]).all(), (pipes, qi, np.nonzero(sc != expect[qi])[0][:5], lengths[np.nonzero(sc != expect[qi])[0][:5]])
+            tops.append((r["scores"].tolist(), r["ids"].tolist(), r["num_overflows"]))
+        seen[pipes] = (tops, d.pipeline_launches())
+        d.close()
     assert len({str(v[0]) for v in seen.values()}) == 1
-    assert seen[("never", "never")][1:] == (0, 0, 0)
-    # (where the span bound cuts the giants — the 60- and the 567-residue query — they run as windows instead of rows)
-    assert 1 <= seen[("always", "always")][1] <= 3 and seen[("always", "always")][2] == 3
-    # this DB is a "small shard" and the estimates say so: its longest subjects run pipelined (round 5: with them gone, what
-    # is left of partition 34 may or may not still want wave-wide groups)
-    assert seen[(None, None)][1] >= 1 and seen[(None, None)][2] >= 0
-    # the pipelined form (round 5) wherever the rows run, except when the one-workgroup form is asked for
-    assert seen[(None, None)][3] == seen[(None, None)][1] and seen[("always", "always")][3] == seen[("always", "always")][1]
-    assert seen[("single", None)][3] == 0
+    assert seen["0"][1] == 0
+    # "always": every subject of partition 35 and the longest of partition 34, for every query whose giants are not cut into
+    # windows instead (the 60- and the 567-residue query: the span bound cuts them)
+    assert seen["always"][1] >= 1
+    # this DB is a "small shard" and the estimates say so: its longest subjects run pipelined
+    assert seen[None][1] >= 1
 
 
 @pytest.mark.parametrize("kinds", [(1, 1, 2, 2), (0, 0, 3, 3), (3, 0, 3, 3)])

@@ -10,7 +10,7 @@ import sys
 def kernels(path):
     cur, name = [], None
     for l in open(path):
-        m = re.match(r"^(_ZN3swk1[46]sw_(?:scan|stream)_kernel\S+):", l)
+        m = re.match(r"^(_ZN3swk(?:14sw_scan_kernel|21sw_scan_stream_kernel)\S+):", l)
         if m:
             if name:
                 yield name, cur
@@ -38,7 +38,7 @@ def loops(lines):
 
 def main():
     for name, lines in kernels(sys.argv[1]):
-        m = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E", name)
+        m = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E", name) if "stream" not in name else None
         tag = "kind %s R %s lanes %s multi %s offs %s" % m.groups() if m else name
         inner = []
         ls = loops(lines)
