@@ -151,6 +151,7 @@ struct sw_ctx {
     uint32_t* d_zeros = nullptr; // per kind 64 bytes of its zero pattern (first-stripe border): [kind * 16 words]
     uint32_t* d_work = nullptr;  // kWorkSlots pairs (batch counter of the dynamic batch distribution, started workgroups), one per launch in flight
     uint32_t work_next = 0;
+    uint32_t work_zeroed = 0;    // slots from work_next on that sw_set_query has zeroed already (one memset per query instead of one per launch)
     uint32_t* start_signal = nullptr;  // sw_set_start_signal: one-shot, consumed by the next scan / re-score launch
     uint32_t* dry_signal = nullptr;    // sw_set_dry_signal: one-shot as well
     uint32_t dry_value = 0;
@@ -176,7 +177,6 @@ struct sw_ctx {
     int64_t long16_min_default = -1;  // what the environment said at creation (sw_set_long16_min(ctx, -1) returns to it)
     int matrix_max = 1;          // largest substitution score of the installed matrix
     bool i32_native = false;     // CUDASW4_AMD_I32_NATIVE=1: never compute the int32 kind in fp32 lanes (tests of the int32 kernels)
-    int32_t lanes8_max_subject = -1;  // CUDASW4_AMD_LANES8_MAX_SUBJECT: multi-stripe queries use 8-lane groups when no subject of the launch is longer (-1: built-in)
     int32_t lanes4_max_subject = -1;  // CUDASW4_AMD_LANES4_MAX_SUBJECT: ... when no subject of the launch is longer (-1: 1280)
     int32_t lanes4_max_q = -1;   // CUDASW4_AMD_LANES4_MAX_Q: queries up to this length use 4-lane groups (0: never; -1: the built-in limits)
     int32_t lanes8_max_q = -1;   // CUDASW4_AMD_LANES8_MAX_Q: queries up to this length use 8-lane groups (0: never; -1: the built-in limits)
@@ -225,7 +225,14 @@ int effective_kind_of(const sw_ctx* ctx, int kind, int32_t max_subject_len) {
 
 // Short queries run on 8-lane groups (half DPP rows): twice the rows per lane for the same query, so the per-step
 // overhead is spread over twice the cells, and 7 instead of 15 fill steps per subject (sw_dp_kernel.hpp: Shift).
+int lanes_for_partition_any(const sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len);
 int lanes_for_partition(const sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
+    const int lanes = lanes_for_partition_any(ctx, kind, part_id, n, max_subject_len);
+    // the streamed packed kernels (16-lane groups) keep a slot's lengths in 16 bits: subjects beyond that — thousands of
+    // them in one packed launch, or a caller that forces the shape — take the wave-wide groups
+    return (lanes == 16 && kind_packed(kind) && max_subject_len >= 0xffff) ? 64 : lanes;
+}
+int lanes_for_partition_any(const sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
     if (part_id < SW_NUM_LENGTH_PARTITIONS - 2) {
         if (!ctx->have_query) return 16;
         // very short queries: 4-lane groups (a DPP quad; single-stripe kernels only).  A batch is 128 (packed kinds) or 64
@@ -241,11 +248,9 @@ int lanes_for_partition(const sw_ctx* ctx, int kind, int part_id, int32_t n, int
         const bool fits8 = ctx->qlen <= 8 * swk::max_rows(kind, 8);  // one stripe of 8-lane groups
         const int32_t limit = ctx->lanes8_max_q >= 0 ? ctx->lanes8_max_q : kind_packed(kind) ? SW_LANES8_MAX_QUERY_PACKED : SW_LANES8_MAX_QUERY_SCALAR;
         if (fits8 && ctx->qlen <= limit) return 8;
-        // longer queries on SHORT subjects: an 8-lane stripe has half the rows, so there are twice the stripes, but each
-        // fills its pipeline in 7 instead of 15 steps.  Measured on the peak DB (all 20 queries, half2): +2.5 % at L = 128
-        // (10.38 -> 10.63 TCUPS), -0.5 % at L = 256, -1.4 % at L = 512: short subjects only
-        const int32_t lmax = ctx->lanes8_max_subject >= 0 ? ctx->lanes8_max_subject : (kind_packed(kind) ? SW_LANES8_MAX_SUBJECT : 0);
-        if (!fits8 && max_subject_len <= lmax) return 8;
+        // (rounds 2-5 ran multi-stripe queries on SHORT subjects — up to 192 residues — on 8-lane groups: twice the stripes, each
+        // filling its pipeline in 7 instead of 15 steps, +2.5 % at L = 128.  The streamed 16-lane kernels pay the fill once per
+        // round of up to 16 subject pairs: 10 931 against 10 537 GCUPS for the 1000-residue query at L = 128.)
         return 16;
     }
     const int64_t fills_gpu_twice = (int64_t)2 * std::max(1, ctx->num_cus) * 4 * 32;
@@ -316,20 +321,56 @@ __global__ void max_length_kernel(const int32_t* lengths, const int32_t* positio
 // A slot whose predecessor scored jump - 4 or more is re-scored (its lanes may have kept values above the raised levels):
 // the jump is what separates "unrelated" from "a hit" — 128 is far above the noise floor of a 35 000-residue subject (~90).
 struct StreamPlan { int slots = 0, cols = 0, room = 0, base = 0, jump = 0; };
-StreamPlan stream_plan(const sw_ctx* ctx, int kind, int lanes, int a, const QueryPlan& pl, int32_t max_subject_len, bool eligible) {
+StreamPlan stream_plan(const sw_ctx* ctx, int kind, int lanes, int a, const QueryPlan& pl) {
     StreamPlan sp;
-    if (!eligible || !kind_packed(kind) || lanes != 16 || ctx->stream_slots <= 1 || a <= 0 || max_subject_len >= 0xffff) return sp;   // (the kernel keeps a slot's lengths in 16 bits)
+    if (!kind_packed(kind) || lanes != 16 || a <= 0) return sp;
     const bool multi = pl.nstripes > 1;
-    if (!multi && pl.rows < swk::kStreamMinRowsSingle) return sp;
     const int P = swk::frame_classes(true, pl.rows, lanes, multi);
     sp.base = kind == SW_KIND_F16X2 ? -2016 : 0;
     const int top = kind == SW_KIND_F16X2 ? 1024 : 12400;
     sp.jump = ctx->stream_jump > 0 ? ctx->stream_jump : (kind == SW_KIND_F16X2 ? 128 : 512);
     sp.room = top - sp.base - a * (2 * lanes + 4 + P);
     sp.cols = std::min(sp.room / a, ctx->stream_cols_max);
-    if (sp.room < 4 * lanes * a || sp.cols < 4 * lanes) return StreamPlan();   // a gap-extension score too large for any round
-    sp.slots = std::min(ctx->stream_slots, swk::kStreamMaxSlots);
+    sp.slots = std::max(1, std::min(ctx->stream_slots, swk::kStreamMaxSlots));
+    // a gap-extension score so large that not even two short slots fit a round: one slot at a time
+    if (sp.room < 4 * lanes * a || sp.cols < 4 * lanes) sp.slots = 1;
     return sp;
+}
+
+// The column-offset recurrence needs (i) a frame period K of at least 4 * lanes columns inside the kind's room — the
+// longest run of columns in one frame plus the pipeline skew: a * (K + 3 * lanes + 16) <= room —, (ii) for a packed kind an
+// overflow list to flag into (a subject whose bound score + a * columns reaches the limit is flagged early), (iii) gop - gex
+// inside the 16-bit encodings.  *K_out: the period (0: the frame is never lowered).
+bool offs_possible(const sw_ctx* ctx, int kind, int lanes, int32_t max_subject_len, int gop, int gex, int ovf_check, int64_t* K_out) {
+    const int a = -gex;
+    const int64_t room = kind == SW_KIND_F16X2 ? 1536 : kind == SW_KIND_I16X2 ? 12500 : (int64_t)1 << 22;
+    int64_t K = 1 << 21;
+    while (K >= 4 * lanes && (int64_t)a * (K + 3 * lanes + 16) > room) K >>= 1;
+    // int16: the room would allow a period of 8192 columns, but the flag bound grows with the period (score + a * min(columns,
+    // K) + ...): with 8192 a 4000-residue protein was re-scored from 21 000 up instead of 25 000.  2048 columns cost 0.3 % in
+    // lowering steps and keep the early flags within 8 % of the limit.
+    if (kind == SW_KIND_I16X2) K = std::min<int64_t>(K, std::max<int64_t>(2048, 4 * lanes));
+    if (!kind_packed(kind) && max_subject_len + 3 * lanes + 16 > K) K = 0;  // the 32-bit kernels do not lower their frame
+    if (K_out) *K_out = K;
+    return ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
+}
+// A packed launch that cannot run the column-offset recurrence is served by its 32-bit kind (exact, nothing to flag): the
+// plain form of the packed recurrence is no longer compiled (round 6: it was half of the packed code objects for gap scores
+// nobody uses — |gex| > 12 with fp16 — and for callers that pass no overflow list).  CUDASW4_AMD_NO_OFFS=1 takes every
+// packed launch there (tests of the fallback).
+int packed_fallback_kind(int kind) { return kind == SW_KIND_F16X2 ? SW_KIND_F32 : SW_KIND_I32; }
+
+// A launch's pair of control words (batch counter of the dynamic batch distribution, counted-in workgroups) from the
+// context's ring.  sw_set_query zeroes the next kWorkZeroBlock pairs with ONE memset on the query's stream — every launch of
+// the query is ordered behind that stream position anyway (it reads the query) —, so the launches of a query take their
+// words without a memset of their own (round 5: 13 hipMemsetAsync per query on a small shard); past the block, or without
+// sw_set_query in between, a launch zeroes its own as before.
+constexpr uint32_t kWorkZeroBlock = 64;
+hipError_t take_work_slot(sw_ctx* ctx, hipStream_t stream, uint32_t** out) {
+    uint32_t* w = ctx->d_work + 2 * (ctx->work_next++ % kWorkSlots);
+    *out = w;
+    if (ctx->work_zeroed > 0) { ctx->work_zeroed--; return hipSuccess; }
+    return hipMemsetAsync(w, 0, 2 * sizeof(uint32_t), stream);
 }
 
 // overflow lists that are re-scored while they are filled (sw_dp_kernel.hpp: ScanParams::claim / service)
@@ -376,21 +417,12 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
                                             std::to_string(longest) + " residues");
     }
     // Column-offset recurrence (7.5 instead of 8.5 instructions per cell pair): values grow by a = -gex per column,
-    // so it is used while a * columns leaves room below the kind's limit (fp16: 3/4 of the exact range — every
-    // single-pass partition with the default gap scores; int16: half).  A subject whose bound score + a * columns
-    // reaches the limit is flagged and re-scored like an overflow.
+    // so it is used while a * columns leaves room below the kind's limit (offs_possible); a subject whose bound
+    // score + a * columns reaches the limit is flagged and re-scored like an overflow.
     const int a = -gex;
-    const int64_t room = kind == SW_KIND_F16X2 ? 1536 : kind == SW_KIND_I16X2 ? 12500 : (int64_t)1 << 22;
-    // every K columns the frame is lowered by a*K (K a power of two, at least 4*lanes): the longest run of columns in
-    // one frame plus the pipeline skew must fit the room
-    int64_t K = 1 << 21;
-    while (K >= 4 * lanes && (int64_t)a * (K + 3 * lanes + 16) > room) K >>= 1;
-    // int16: the room would allow a period of 8192 columns, but the flag bound grows with the period (score + a * min(columns,
-    // K) + ...): with 8192 a 4000-residue protein was re-scored from 21 000 up instead of 25 000.  2048 columns cost 0.3 % in
-    // lowering steps (16 of every 2048 run the second loop body) and keep the early flags within 8 % of the limit.
-    if (kind == SW_KIND_I16X2) K = std::min<int64_t>(K, std::max<int64_t>(2048, 4 * lanes));
-    if (!kind_packed(kind) && max_subject_len + 3 * lanes + 16 > K) K = 0;  // the 32-bit kernels do not lower their frame
-    const bool offs = ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
+    int64_t K = 0;
+    const bool offs = offs_possible(ctx, kind, lanes, max_subject_len, gop, gex, ovf_check, &K);
+    if (kind_packed(kind) && !offs) return fail(SW_ERR_INVALID, "internal: a packed launch without the column-offset recurrence (packed_fallback_kind)");
     int rc = ensure_profile(ctx, kind, lanes, offs, offs ? a : 0, stream);
     if (rc != SW_OK) return rc;
     const Profile& prof = ctx->profiles[kind][shape_index(lanes)][offs];
@@ -446,8 +478,8 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
         }
     }
     // Streamed subjects (sw_stream_kernel.hpp): packed kinds on 16-lane groups, column-offset recurrence, plain ranges
-    const StreamPlan sp = stream_plan(ctx, kind, lanes, a, pl, max_subject_len, offs && !positions && !count_ptr && !list.claim && list.service_workgroups == 0);
-    if (sp.slots > 1) {
+    const StreamPlan sp = stream_plan(ctx, kind, lanes, a, pl);
+    if (sp.slots >= 1) {
         p.stream_slots = sp.slots; p.stream_cols = sp.cols; p.stream_room = sp.room; p.level_base = sp.base;
         p.jump = sp.jump; p.jump_limit = sp.jump - 4;
         p.jump_word = kind == SW_KIND_F16X2 ? swk::Arith<swk::F16X2>::pos_word(sp.jump) : swk::Arith<swk::I16X2>::pos_word(sp.jump);
@@ -472,8 +504,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     }
     // batches are handed out through an atomic counter (longest subjects first): workgroups that start late
     // because another launch still holds the CUs simply take fewer batches
-    p.work_counter = ctx->d_work + 2 * (ctx->work_next++ % kWorkSlots);
-    SW_HIP(hipMemsetAsync(p.work_counter, 0, 2 * sizeof(uint32_t), stream));
+    SW_HIP(take_work_slot(ctx, stream, &p.work_counter));
     // start handshake (sw_set_start_signal): the signal fires once `quorum` workgroups are resident — all of a small
     // launch, the first 64 of a larger one (its remaining workgroups are next in its queue when the waiter is released)
     p.start_signal = start_signal;
@@ -573,7 +604,6 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_Q")) ctx->lanes8_max_q = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_LANES4_MAX_Q")) ctx->lanes4_max_q = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_LANES4_MAX_SUBJECT")) ctx->lanes4_max_subject = atoi(e);
-    if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_SUBJECT")) ctx->lanes8_max_subject = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_CHECK_BOUNDS")) ctx->check_bounds = e[0] == '1';
     if (const char* e = getenv("CUDASW4_AMD_PIPE_SPIN_LIMIT")) ctx->pipe_spin_limit = (uint32_t)std::max(1ll, atoll(e));
     if (const char* e = getenv("CUDASW4_AMD_PIPE_TEST_DROP_STAGE")) ctx->pipe_drop_stage = atoi(e);
@@ -681,6 +711,10 @@ int sw_set_query(sw_ctx* ctx, const int8_t* query_codes_host, int32_t qlen, void
     if (!ctx->query_copied[slot]) SW_HIP(hipEventCreateWithFlags(&ctx->query_copied[slot], hipEventDisableTiming));
     memcpy(ctx->h_query[slot], query_codes_host, (size_t)qlen);
     SW_HIP(hipMemcpyAsync(ctx->d_query, ctx->h_query[slot], qlen, hipMemcpyHostToDevice, s));
+    // the control words of this query's launches, zeroed in one go (take_work_slot)
+    ctx->work_next = (ctx->work_next + kWorkZeroBlock - 1) / kWorkZeroBlock * kWorkZeroBlock;
+    SW_HIP(hipMemsetAsync(ctx->d_work + 2 * (ctx->work_next % kWorkSlots), 0, 2 * kWorkZeroBlock * sizeof(uint32_t), s));
+    ctx->work_zeroed = kWorkZeroBlock;
     SW_HIP(hipEventRecord(ctx->query_copied[slot], s));
     ctx->query_slot_used[slot] = true;
     ctx->qlen = qlen;
@@ -812,8 +846,9 @@ int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, cons
     p.chars = chars; p.offsets = offsets; p.lengths = lengths; p.first_pos = first_pos;
     p.query = ctx->d_query; p.qlen = ctx->qlen; p.matrix = ctx->d_matrix; p.dim = ctx->dim;
     p.gop = gop; p.gex = gex; p.scores = scores; p.ids = ids; p.id_offset = id_offset;
-    p.start_counter = ctx->d_work + 2 * (ctx->work_next++ % kWorkSlots) + 1;
-    SW_HIP(hipMemsetAsync(p.start_counter, 0, sizeof(uint32_t), stream));
+    uint32_t* slot = nullptr;
+    SW_HIP(take_work_slot(ctx, stream, &slot));
+    p.start_counter = slot + 1;
     p.start_signal = start_signal;
     p.start_quorum = (uint32_t)std::min(n, 64);
     // columns per thread: the smallest compiled width that covers the longest subject of the launch
@@ -1193,9 +1228,19 @@ int sw_set_rows_pipeline_slot(sw_ctx* ctx, int vgprs) {
     return SW_OK;
 }
 
+static size_t scan_temp_bytes_of(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len);
 size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || !kind_launch(kind) || max_subject_len < 0 || n <= 0) return 0;
-    kind = effective_kind_of(ctx, kind, max_subject_len);
+    if (kind_packed(kind) && part_id >= 0) {
+        // (the gap scores are not known here: a packed launch that falls back to its 32-bit kind may need more)
+        const int fb = packed_fallback_kind(kind);
+        const size_t own = scan_temp_bytes_of(ctx, kind, part_id, n, max_subject_len);
+        return std::max(own, scan_temp_bytes_of(ctx, effective_kind_of(ctx, fb, max_subject_len), part_id, n, max_subject_len));
+    }
+    return scan_temp_bytes_of(ctx, effective_kind_of(ctx, kind, max_subject_len), part_id, n, max_subject_len);
+}
+
+static size_t scan_temp_bytes_of(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t max_subject_len) {
     const int lanes = part_id < 0 ? rescore_lanes(max_subject_len) : lanes_for_partition(ctx, kind, part_id, n, max_subject_len);
     const QueryPlan pl = plan_query(kind, ctx->qlen, lanes);
     if (pl.nstripes <= 1) return 0;
@@ -1204,7 +1249,7 @@ size_t sw_scan_temp_bytes(sw_ctx* ctx, int kind, int part_id, int32_t n, int32_t
     const int64_t grid = std::min<int64_t>(nbatches, max_grid(ctx));
     // streamed subjects: the border arrays hold a round of several slots (gap scores are not known here: -1 is what the
     // default and almost every caller use; a scratch sized for fewer columns only makes the rounds shorter)
-    const StreamPlan sp = stream_plan(ctx, kind, lanes, 1, pl, max_subject_len, true);
+    const StreamPlan sp = stream_plan(ctx, kind, lanes, 1, pl);
     const int32_t cols = sp.slots > 1 ? std::max(max_subject_len, sp.cols) : max_subject_len;
     return (size_t)grid * border_bytes_per_wg(border_capacity(cols, lanes), lanes);
 }
@@ -1220,7 +1265,13 @@ int sw_scan_partition(sw_ctx* ctx, int kind, int part_id, const int8_t* chars, c
         return fail(SW_ERR_INVALID, part_id < 0 || part_id >= SW_NUM_LENGTH_PARTITIONS ? "partition id out of range" : "unknown kind");
     }
     kind = effective_kind_of(ctx, kind, max_subject_len);
-    return scan_common(ctx, kind, lanes_for_partition(ctx, kind, part_id, n, max_subject_len), chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
+    int lanes = lanes_for_partition(ctx, kind, part_id, n, max_subject_len);
+    if (kind_packed(kind) && !offs_possible(ctx, kind, lanes, max_subject_len, gop, gex, ovf_check, nullptr)) {
+        kind = effective_kind_of(ctx, packed_fallback_kind(kind), max_subject_len);
+        lanes = lanes_for_partition(ctx, kind, part_id, n, max_subject_len);
+        ovf_pos = nullptr; ovf_count = nullptr; ovf_check = 0;
+    }
+    return scan_common(ctx, kind, lanes, chars, offsets, lengths, nullptr, nullptr, first_pos, n, max_subject_len, gop, gex,
                        scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
                        static_cast<hipStream_t>(stream));
 }
@@ -1495,6 +1546,108 @@ __global__ void __launch_bounds__(256) topk_rank_emit_kernel(const unsigned long
     }
 }
 
+// ---- small k (the reference's default: --top 10): two launches instead of nine.  Every workgroup walks chunks of 2 048 scores
+// with the k best keys it has seen so far in LDS; a chunk that holds nothing above the k-th best is skipped after one
+// block-wide test, otherwise its maxima are extracted one by one (keys are unique: the winner clears its own element).  The
+// second kernel does the same over the workgroups' lists and emits the winners in order.  A query that is scanned in a
+// millisecond and a half spent 3 % of it in the radix select's nine small launches.
+constexpr int kSmallK = 32;
+constexpr int kSmallChunk = 2048;   // 256 threads x 8 elements
+constexpr int kSmallMaxGrid = 1024;
+
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* wmax) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d);
+        v = o > v ? o : v;
+    }
+    __syncthreads();   // (wmax of the round before has been read)
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long m = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) m = wmax[w] > m ? wmax[w] : m;
+    return m;
+}
+
+// merge the elements key[0..8) of the 256 threads into the descending list best[0..k)
+__device__ __forceinline__ void small_merge(unsigned long long (&key)[8], unsigned long long* best, unsigned long long* wmax, int k) {
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) mine = key[e] > mine ? key[e] : mine;
+    for (int round = 0; round < k; round++) {
+        const unsigned long long m = block_max_u64(mine, wmax);
+        if (m <= best[k - 1]) break;   // uniform: nothing of this chunk can still enter
+        if (mine == m) {               // unique keys: exactly one thread; it drops the element and finds its next best
+            mine = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (key[e] == m) key[e] = 0;
+                mine = key[e] > mine ? key[e] : mine;
+            }
+        }
+        if (threadIdx.x == 0) {        // sorted insertion
+            int i = k - 1;
+            while (i > 0 && best[i - 1] < m) { best[i] = best[i - 1]; i--; }
+            best[i] = m;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) topk_small_partial_kernel(const float* __restrict__ scores, int64_t n, int k, unsigned long long* out) {
+    __shared__ unsigned long long best[kSmallK];
+    __shared__ unsigned long long wmax[4];
+    if (threadIdx.x < kSmallK) best[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t nchunks = (n + kSmallChunk - 1) / kSmallChunk;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        unsigned long long key[8];
+        const unsigned long long thr = best[k - 1];
+        bool above = false;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int64_t i = c * kSmallChunk + e * 256 + threadIdx.x;
+            key[e] = i < n ? topk_key(scores[i], (unsigned int)i) : 0ull;
+            above = above || key[e] > thr;
+        }
+        if (!__syncthreads_or(above)) continue;
+        small_merge(key, best, wmax, k);
+    }
+    __syncthreads();
+    if (threadIdx.x < k) out[(size_t)blockIdx.x * k + threadIdx.x] = best[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) topk_small_final_kernel(const unsigned long long* __restrict__ cand, int ncand, const int32_t* __restrict__ ids,
+                                                               int k, float* out_s, int32_t* out_i) {
+    __shared__ unsigned long long best[kSmallK];
+    __shared__ unsigned long long wmax[4];
+    if (threadIdx.x < kSmallK) best[threadIdx.x] = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < ncand; c0 += kSmallChunk) {
+        unsigned long long key[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int i = c0 + e * 256 + threadIdx.x;
+            key[e] = i < ncand ? cand[i] : 0ull;
+        }
+        small_merge(key, best, wmax, k);
+    }
+    __syncthreads();
+    if (threadIdx.x < k) {
+        const unsigned long long key = best[threadIdx.x];
+        unsigned int u = (unsigned int)(key >> 32);
+        u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+        out_s[threadIdx.x] = __uint_as_float(u);
+        out_i[threadIdx.x] = ids[~(unsigned int)key];
+    }
+}
+
+int small_grid(const sw_ctx* ctx, int64_t n) {
+    const int64_t nchunks = (n + kSmallChunk - 1) / kSmallChunk;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, std::min<int64_t>(kSmallMaxGrid, (int64_t)std::max(1, ctx->num_cus) * 4)));
+}
+
 struct SelectLayout {
     size_t state_off, keys_a, keys_b, vals_a, vals_b, cub_off, cub_bytes, total;
 };
@@ -1527,8 +1680,8 @@ bool use_select(int64_t n, int k) {
 
 size_t sw_topk_temp_bytes(int64_t n, int k) {
     if (n <= 0 || k <= 0) return 0;
-    // sized for either path, so that a forced path (tests) never outgrows a buffer sized by this call
-    return std::max(topk_layout(n).total, k < n ? select_layout(k).total : size_t(0));
+    // sized for any path, so that a forced path (tests) never outgrows a buffer sized by this call
+    return std::max(std::max(topk_layout(n).total, k < n ? select_layout(k).total : size_t(0)), (size_t)kSmallMaxGrid * kSmallK * sizeof(unsigned long long));
 }
 
 int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int k, float* out_scores,
@@ -1540,6 +1693,16 @@ int sw_topk(sw_ctx* ctx, const float* scores, const int32_t* ids, int64_t n, int
     SW_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n > 0 && (!scores || !ids)) return fail(SW_ERR_INVALID, "null input");
+    const char* force = getenv("CUDASW4_AMD_TOPK");
+    if (n > k && k <= kSmallK && (!force || (force[0] == 's' && force[1] == 'm'))) {   // CUDASW4_AMD_TOPK=small|select|sort forces a path (tests)
+        const int grid = small_grid(ctx, n);
+        if (!temp || temp_bytes < (size_t)grid * k * sizeof(unsigned long long)) return fail(SW_ERR_TEMP, "temp buffer too small for top-K");
+        unsigned long long* cand = static_cast<unsigned long long*>(temp);
+        hipLaunchKernelGGL(topk_small_partial_kernel, dim3(grid), dim3(256), 0, s, scores, n, k, cand);
+        hipLaunchKernelGGL(topk_small_final_kernel, dim3(1), dim3(256), 0, s, cand, grid * k, ids, k, out_scores, out_ids);
+        SW_HIP(hipGetLastError());
+        return SW_OK;
+    }
     if (n > 0 && use_select(n, k)) {
         const SelectLayout L = select_layout(k);
         if (!temp || temp_bytes < L.total) return fail(SW_ERR_TEMP, "temp buffer too small for top-K");

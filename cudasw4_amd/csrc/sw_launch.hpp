@@ -34,16 +34,12 @@ constexpr int kWaves3MaxRowsPackedMulti = SWK_WAVES3_MAX_R_MULTI;  // int32 cann
 // long-subject shape (64-lane groups)
 constexpr int kMaxRowsPackedLong = 16;  // stripe = 1024 query rows, 43 KB tile
 constexpr int kMaxRowsScalarLong = 8;   // stripe = 512 query rows, 43 KB tile
-// single-stripe queries on 16-lane groups start above the 8-lane shape's 256 residues: the streamed kernel is compiled from
-// there up (shorter queries reach 16-lane groups only through explicit limits of tests and A/B runs: sw_scan_kernel)
-#ifndef SWK_STREAM_MIN_ROWS_SINGLE
-#define SWK_STREAM_MIN_ROWS_SINGLE 16
-#endif
-constexpr int kStreamMinRowsSingle = SWK_STREAM_MIN_ROWS_SINGLE;
-
+// short groups (8 and 4 lanes: single-stripe queries of up to 256 / 128 residues): 32 rows per lane
+constexpr int kMaxRowsShortGroups = 32;
 constexpr int max_rows(int kind, int lanes) {
     const bool packed = kind == F16X2 || kind == I16X2;
-    return lanes <= 16 ? (packed ? kMaxRowsPacked : kind == I32 ? kMaxRowsI32 : kMaxRowsScalar) : (packed ? kMaxRowsPackedLong : kMaxRowsScalarLong);
+    if (lanes < 16) return kMaxRowsShortGroups;
+    return lanes == 16 ? (packed ? kMaxRowsPacked : kind == I32 ? kMaxRowsI32 : kMaxRowsScalar) : (packed ? kMaxRowsPackedLong : kMaxRowsScalarLong);
 }
 
 struct KindLaunch {
@@ -104,30 +100,36 @@ hipError_t launch_scan_k(K kernel, int grid, int reserve, hipStream_t stream, co
     return hipGetLastError();
 }
 
+// Which instantiations exist (round 6: the kernel set was cut to what the planner can reach — 641 kernels and 35 MB of
+// code objects per packed kind before):
+//   * packed kinds run the column-offset recurrence only: a launch that cannot (gap extension too large for any frame
+//     period, no overflow list to flag into) is served by its 32-bit kind, bit-identically (sw_api.hip: packed_fallback);
+//   * packed kinds on 16-lane groups ARE the streamed kernels (sw_stream_kernel.hpp; a round of one slot is what
+//     sw_scan_kernel was), single-stripe for every R, multi-stripe for R > max / 2;
+//   * 8- and 4-lane groups: single-stripe kernels only (queries of up to 256 / 128 residues).
 template <int KIND, int R, int LANES, bool OFFS>
 hipError_t launch_scan_ro(bool multi, int grid, int reserve, hipStream_t stream, const ScanParams& p) {
     // a query that needs more than one stripe always gets R > max/2 from the planner
     constexpr int kMaxR = max_rows(KIND, LANES);
-    if constexpr (R > kMaxR) {
+    constexpr bool kPacked = Arith<KIND>::kPacked;
+    if constexpr (R > kMaxR || (kPacked && !OFFS)) {
         return hipErrorInvalidValue;
+    } else if constexpr (kPacked && LANES == 16) {
+        if (p.positions || p.claim || p.service || p.count_ptr || p.stream_slots < 1) return hipErrorInvalidValue;   // (32-bit kinds' business)
+        if (multi) {
+            if constexpr (2 * R > kMaxR) return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, true>, grid, reserve, stream, p);
+            else return hipErrorInvalidValue;
+        } else {
+            return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, false>, grid, reserve, stream, p);
+        }
     } else {
         if (multi) {
-            if constexpr (2 * R > kMaxR && LANES != 4) {   // (4-lane groups: single-stripe queries only)
-                // packed kinds, 16-lane groups, column-offset recurrence, a plain subject range: the subjects of up to
-                // p.stream_slots batches stream through the lanes back to back, stripe after stripe (sw_stream_kernel.hpp)
-                if constexpr (OFFS && Arith<KIND>::kPacked && LANES == 16) {
-                    if (p.stream_slots > 1 && !p.positions && !p.claim && !p.service && !p.count_ptr)
-                        return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, true>, grid, reserve, stream, p);
-                }
+            if constexpr (2 * R > kMaxR && LANES >= 16) {   // (short groups: single-stripe queries only)
                 return launch_scan_k(sw_scan_kernel<KIND, R, LANES, true, OFFS>, grid, reserve, stream, p);
             } else {
                 return hipErrorInvalidValue;
             }
         } else {
-            if constexpr (OFFS && Arith<KIND>::kPacked && LANES == 16 && R >= kStreamMinRowsSingle) {
-                if (p.stream_slots > 1 && !p.positions && !p.claim && !p.service && !p.count_ptr)
-                    return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, false>, grid, reserve, stream, p);
-            }
             return launch_scan_k(sw_scan_kernel<KIND, R, LANES, false, OFFS>, grid, reserve, stream, p);
         }
     }

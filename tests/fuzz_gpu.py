@@ -153,7 +153,6 @@ def main(argv=None):
             kt = K(*kinds)
             os.environ["CUDASW4_AMD_I32_NATIVE"] = str(int(r.integers(0, 2)))
             os.environ["CUDASW4_AMD_LANES8_MAX_Q"] = str(int(r.choice([-1, -1, 0, 100000])))
-            os.environ["CUDASW4_AMD_LANES8_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 0, 100000])))
             os.environ["CUDASW4_AMD_LANES4_MAX_Q"] = str(int(r.choice([-1, 0, 100000, 100000])))   # (explicit: quads whatever the batch count)
             os.environ["CUDASW4_AMD_LANES4_MAX_SUBJECT"] = str(int(r.choice([-1, -1, 100000])))
             os.environ["CUDASW4_AMD_STREAM"] = str(int(r.choice([1, 16, 16, 3])))

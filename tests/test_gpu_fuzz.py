@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_randomised_soak_short(monkeypatch):
     import fuzz_gpu
-    for var in ("CUDASW4_AMD_I32_NATIVE", "CUDASW4_AMD_LANES8_MAX_Q", "CUDASW4_AMD_LANES8_MAX_SUBJECT"):
+    for var in ("CUDASW4_AMD_I32_NATIVE", "CUDASW4_AMD_LANES8_MAX_Q", "CUDASW4_AMD_STREAM", "CUDASW4_AMD_GRID_CAP"):
         monkeypatch.setenv(var, os.environ.get(var, "-1" if "LANES8" in var else "0"))  # restored after the test
     seconds = os.environ.get("FUZZ_SECONDS", "25")
     seed = os.environ.get("FUZZ_SEED", "314")

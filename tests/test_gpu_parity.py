@@ -157,7 +157,7 @@ def test_topk_matches_oracle_order():
 
 
 @pytest.mark.parametrize("n,k,hi", [(200_000, 10, 40), (200_000, 1000, 3000), (300_001, 25, 2), (1_000_000, 10, 1),
-                                    (150_000, 7, 1 << 20), (131_072, 16_384, 50)])
+                                    (150_000, 7, 1 << 20), (131_072, 16_384, 50), (3_000_001, 32, 3), (700, 5, 9), (2049, 1, 100)])
 def test_topk_select_equals_sort_and_oracle(n, k, hi, monkeypatch):
     """sw_topk's radix select (large n) against its full-sort path and the oracle's top-K: heavy ties (few distinct
     scores: the ties at the threshold are broken by position), all-equal scores, nearly distinct scores, a large k."""
@@ -169,7 +169,7 @@ def test_topk_select_equals_sort_and_oracle(n, k, hi, monkeypatch):
     d_s = torch.from_numpy(scores_i.astype(np.float32)).cuda()
     d_i = torch.arange(1000, 1000 + n, dtype=torch.int32, device="cuda")  # ids need not equal positions
     got = {}
-    for path in ("sort", "select"):
+    for path in ("sort", "select") + (("small",) if k <= 32 else ()):   # (round 6: two launches for k <= 32, sw_api.hip: topk_small_*)
         monkeypatch.setenv("CUDASW4_AMD_TOPK", path)
         tb = capi.topk_temp_bytes(n, k)
         temp = torch.empty(tb, dtype=torch.uint8, device="cuda")
@@ -178,7 +178,7 @@ def test_topk_select_equals_sort_and_oracle(n, k, hi, monkeypatch):
         ctx.topk(d_s.data_ptr(), d_i.data_ptr(), n, k, out_s.data_ptr(), out_i.data_ptr(), temp.data_ptr(), tb, 0)
         torch.cuda.synchronize()
         got[path] = (out_s.cpu().numpy().astype(np.int64).tolist(), (out_i.cpu().numpy().astype(np.int64) - 1000).tolist())
-    assert got["select"] == got["sort"]
+    assert got["select"] == got["sort"] and all(v == got["sort"] for v in got.values())
     assert got["select"][0] == es.tolist() and got["select"][1] == ei.tolist()
     ctx.close()
 
@@ -395,7 +395,6 @@ def test_every_compiled_tile_shape(monkeypatch):
         monkeypatch.setenv("CUDASW4_AMD_I32_NATIVE", "1")  # the int32 kernels themselves, not their fp32 stand-ins
         monkeypatch.setenv("CUDASW4_AMD_LANES4_MAX_Q", "1000000" if lanes == 4 else "0")
         monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_Q", "1000000" if lanes == 8 else "0")
-        monkeypatch.setenv("CUDASW4_AMD_LANES8_MAX_SUBJECT", "1000000" if lanes == 8 else "0")
         ctx = capi.Context(0)  # reads the environment
         ctx.set_matrix(O.blosum21(62))
         chars, offsets, lengths = O.make_db(seqs)
@@ -407,19 +406,20 @@ def test_every_compiled_tile_shape(monkeypatch):
         ovf_pos = torch.zeros(n, dtype=torch.int32, device="cuda")
         ovf_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         for kind in (capi.KIND_F16X2, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_F32):
-            rmax = {4: 48 if kind < 3 else 36, 8: 48 if kind < 3 else 36, 16: 48 if kind < 3 else 36, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
+            # (short groups — 8 and 4 lanes — are single-stripe shapes of up to 32 rows per lane since round 6)
+            rmax = {4: 32, 8: 32, 16: 48 if kind < 3 else 36, 64: 16 if kind < 2 else 8}[lanes]  # int32 stripes are as tall as the packed kinds'
             rmax_multi = 32 if (kind == 3 and lanes <= 16) else rmax  # fp32: several stripes only up to 32 rows per lane
             qlens = set()
             for r in range(1, rmax + 1):
                 qlens.add(lanes * r - 1)                       # one stripe of R rows
                 if lanes == 16:
                     assert capi.plan_query(kind, lanes * r - 1) == (r, 1)
-                if 2 * r > rmax and r <= rmax_multi and lanes != 4:
+                if 2 * r > rmax and r <= rmax_multi and lanes >= 16:
                     qlens.add(2 * lanes * r - lanes - 3)       # two stripes of R rows
                     if lanes == 16:
                         assert capi.plan_query(kind, 2 * lanes * r - lanes - 3) == (r, 2)
             qlens.add(lanes * rmax)                            # the longest single-stripe query of the shape
-            if lanes != 4:
+            if lanes >= 16:
                 qlens.add(3 * lanes * rmax_multi - 5)          # three full stripes
             for qlen in sorted(qlens):
                 q = rng.integers(0, 20, qlen).astype(np.int8)
@@ -439,7 +439,7 @@ def test_every_compiled_tile_shape(monkeypatch):
                 np.testing.assert_array_equal(scores.cpu().numpy().astype(np.int32), expect,
                                               err_msg="kind %d lanes %d qlen %d" % (kind, lanes, qlen))
                 seen.add((kind, lanes, qlen))
-    assert len(seen) > 650
+    assert len(seen) > 500
 
 
 @pytest.mark.parametrize("gop,gex", [(-12, -5), (-1000, -1000), (-3, -12)])
