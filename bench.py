@@ -348,7 +348,7 @@ class SclkSampler:
                 "avg_mhz": round(sum(self.samples) / len(self.samples), 1), "max_mhz": max(self.samples)}
 
 
-MIX_BY_KIND = {0: 3, 1: 3, 2: 2, 3: 1}   # sw_measure_valu_rate: packed kinds -> the kernels' own mix, fp32 -> its co-issue mix, int32 -> its mix
+MIX_BY_KIND = {0: 4, 1: 4, 2: 2, 3: 1}   # sw_measure_valu_rate: packed kinds -> the kernels' own mix (operands in distinct register banks), fp32 -> its co-issue mix, int32 -> its mix
 
 
 def device_calibration(device):
@@ -362,7 +362,7 @@ def device_calibration(device):
     out = {"cus": int(props.multi_processor_count), "device": props.name, "mix": {}}
     try:
         ctx = capi.Context(device)
-        for name, mix in (("vop3p_pk_maximum3_f16", 0), ("fp32_add_max3", 1), ("int32_add_max3", 2), ("packed_kernel_mix", 3)):
+        for name, mix in (("vop3p_pk_maximum3_f16", 0), ("fp32_add_max3", 1), ("int32_add_max3", 2), ("packed_kernel_mix", 3), ("packed_kernel_mix_bank_free", 4)):
             rate, hz = ctx.measure_valu_rate(mix, 50)
             out["mix"][str(mix)] = {"name": name, "lane_instr_per_s": rate,
                                     "lanes_per_clk_per_cu_at_2.4GHz": round(rate / (out["cus"] * 2.4e9), 2),
@@ -499,7 +499,8 @@ def roofline_objects(args, workload, kernel_name, events, info, cal=None, sclk=N
                  "observed_sclk": sclk, "calibration": cal,
                  "peak_measured_note": "lane-instructions per second of a 50 ms in-process micro-run of the kind's bounding mix on THIS "
                                        "device; packed kinds: the instruction histogram of the dominant loop body (55 % v_pk_maximum3_f16, 16 % "
-                                       "v_pk_fma_f16, 20 % v_pk_add_f16, 9 % DPP / v_perm_b32 / v_add_u32: sw_measure_valu_rate mix 3) — round 5 "
+                                       "v_pk_fma_f16, 20 % v_pk_add_f16, 9 % DPP / v_add_u32, every instruction's sources in three different register banks: "
+                                       "sw_measure_valu_rate mix 4; with operands wherever the allocator puts them — mix 3 — the same stream issues ~4 % slower) — round 5 "
                                        "priced against a pure v_pk_maximum3_f16 stream (calibration.mix['0']), which issues fewer lane-"
                                        "instructions per second than the kernel's own mix and gave a fraction of 1.06",
                  "lanes_per_clk_note": "`frac` prices the achieved rate against 64 lanes/clk/CU (one VOP3/VOP3P wave64 instruction per 4 "

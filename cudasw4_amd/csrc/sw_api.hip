@@ -187,6 +187,8 @@ struct sw_ctx {
     int32_t stream_slots = swk::kStreamMaxSlots;   // CUDASW4_AMD_STREAM=0..16: most batches whose subjects stream through the lanes back to back (sw_stream_kernel.hpp; 0 / 1: sw_scan_kernel, one batch at a time)
     int32_t stream_jump = 0;              // CUDASW4_AMD_STREAM_JUMP: what the zero levels rise by at a slot border (0: 128 for fp16, 512 for int16)
     int32_t stream_cols_max = 4096;       // CUDASW4_AMD_STREAM_COLS: most columns of a round of several slots
+    int32_t stream_multi_cols_max = 1536; // CUDASW4_AMD_STREAM_MULTI_COLS: ... of a multi-stripe query (its border arrays grow with the round)
+    int32_t stream_multi_max_subject = -1;    // CUDASW4_AMD_STREAM_MULTI_MAX_SUBJECT: multi-stripe queries stream subjects up to this length (-1: 320 for fp16, 192 for int16)
     int32_t pipe_quorum = 0;              // CUDASW4_AMD_PIPE_QUORUM (0: all tickets)
     int32_t pipe_slot = 0;                // sw_set_rows_pipeline_slot: VGPRs a stage occupies (128 / 168 / 256; 0: what it needs)
 };
@@ -321,7 +323,7 @@ __global__ void max_length_kernel(const int32_t* lengths, const int32_t* positio
 // A slot whose predecessor scored jump - 4 or more is re-scored (its lanes may have kept values above the raised levels):
 // the jump is what separates "unrelated" from "a hit" — 128 is far above the noise floor of a 35 000-residue subject (~90).
 struct StreamPlan { int slots = 0, cols = 0, room = 0, base = 0, jump = 0; };
-StreamPlan stream_plan(const sw_ctx* ctx, int kind, int lanes, int a, const QueryPlan& pl) {
+StreamPlan stream_plan(const sw_ctx* ctx, int kind, int lanes, int a, const QueryPlan& pl, int32_t max_subject_len) {
     StreamPlan sp;
     if (!kind_packed(kind) || lanes != 16 || a <= 0) return sp;
     const bool multi = pl.nstripes > 1;
@@ -334,6 +336,20 @@ StreamPlan stream_plan(const sw_ctx* ctx, int kind, int lanes, int a, const Quer
     sp.slots = std::max(1, std::min(ctx->stream_slots, swk::kStreamMaxSlots));
     // a gap-extension score so large that not even two short slots fit a round: one slot at a time
     if (sp.room < 4 * lanes * a || sp.cols < 4 * lanes) sp.slots = 1;
+    // Several stripes: a slot border costs the streamed kernels about seven step equivalents per stripe (the separator column,
+    // sixteen steps of a second copy of the loop body, two transitions between the copies' register allocations) against the
+    // sixteen of a pipeline drain and the rounding to whole quads — worth it while the subjects are short (measured, peak DB,
+    // 1000- / 5478-residue queries: L = 128 +3.7 / +1.1 % over round 5's 8-lane groups, L = 256 +0.7 / +0.6 %, L = 512
+    // +0.1 / -1.5 %; int16, whose rounds are longer: L = 256 -0.1 / -3.8 %, L = 512 -0.9 / -5.5 %), and with rounds whose
+    // border arrays stay small.  Longer subjects: sw_scan_kernel, one pair at a time (slots = 1 selects it, sw_launch.hpp).
+    if (multi) {
+        // (measured with rounds of up to 1 536 columns, against sw_scan_kernel on 16-lane groups: fp16 L = 128 +4.5 / +2.8 %,
+        // L = 256 +3.0 / +0.7 %, L = 512 +0.7 / -0.1 %; int16 L = 128 +4.2 / +2.0 %, L = 256 -0.4 / -0.4 %, L = 512 -0.7 / -1.6 %:
+        // profiles/r06_stream_ab.txt)
+        const int32_t limit = ctx->stream_multi_max_subject >= 0 ? ctx->stream_multi_max_subject : (kind == SW_KIND_F16X2 ? 320 : 192);
+        if (max_subject_len > limit) sp.slots = 1;
+        sp.cols = std::min(sp.cols, ctx->stream_multi_cols_max);
+    }
     return sp;
 }
 
@@ -478,7 +494,7 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
         }
     }
     // Streamed subjects (sw_stream_kernel.hpp): packed kinds on 16-lane groups, column-offset recurrence, plain ranges
-    const StreamPlan sp = stream_plan(ctx, kind, lanes, a, pl);
+    const StreamPlan sp = stream_plan(ctx, kind, lanes, a, pl, max_subject_len);
     if (sp.slots >= 1) {
         p.stream_slots = sp.slots; p.stream_cols = sp.cols; p.stream_room = sp.room; p.level_base = sp.base;
         p.jump = sp.jump; p.jump_limit = sp.jump - 4;
@@ -538,6 +554,11 @@ __global__ void __launch_bounds__(256) valu_rate_kernel(unsigned* out, unsigned 
     unsigned a[8];
     unsigned b = seed + threadIdx.x, c = seed * 3u + 1u;
     for (int i = 0; i < 8; i++) a[i] = seed + i + threadIdx.x;
+    if constexpr (MIX == 4) {
+        asm volatile("v_mov_b32 v0, %0\nv_mov_b32 v1, %0\nv_mov_b32 v2, %0\nv_mov_b32 v3, %0\nv_mov_b32 v4, %0\nv_mov_b32 v5, %0\nv_mov_b32 v6, %0\nv_mov_b32 v7, %0\n"
+                     "v_mov_b32 v8, %1\nv_mov_b32 v9, %1\nv_mov_b32 v10, %1\nv_mov_b32 v11, %1\nv_mov_b32 v12, %2\nv_mov_b32 v13, %2\nv_mov_b32 v14, %2\nv_mov_b32 v15, %2\n"
+                     :: "v"(a[0]), "v"(b), "v"(c) : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15");
+    }
     const unsigned long long t0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; it++) {
         if constexpr (MIX == 0) { SW_REP8(SW_OP_PK_MAX3) SW_REP8(SW_OP_PK_MAX3) SW_REP8(SW_OP_PK_MAX3) SW_REP8(SW_OP_PK_MAX3) }
@@ -555,9 +576,29 @@ __global__ void __launch_bounds__(256) valu_rate_kernel(unsigned* out, unsigned 
             SW_REP8(SW_OP_PK_MAX3) SW_OP_PK_FMA(0) SW_OP_PK_FMA(1) SW_OP_PK_ADD(2) SW_OP_PK_ADD(3) SW_OP_DPP(4) SW_OP_PK_ADD(5) SW_OP_PK_ADD(6) SW_OP_ADD_U32(7)
             SW_REP8(SW_OP_PK_MAX3) SW_OP_PK_FMA(0) SW_OP_PK_FMA(1) SW_OP_PK_ADD(2) SW_OP_PK_ADD(3) SW_OP_PK_MAX3(4) SW_OP_PK_MAX3(5) SW_OP_PK_MAX3(6) SW_OP_PK_ADD(7)
         }
+        // mix 4: mix 3's composition with every instruction's three sources in three different register banks (bank = register
+        // number mod 4) — explicit registers: accumulators v0..v7, the second operand from v8..v11, the third from v12..v15.
+        // With operands wherever the allocator puts them a VOP3(P) instruction whose sources meet in one bank takes an extra
+        // cycle: mixes 0 and 3 sustain 58-59.5 lanes/clk/CU, less than the scan kernels themselves, whose registers hipcc assigns
+        // with the banks in mind.
+        if constexpr (MIX == 4) {
+#define SW_B4_MAX3(i, j, k) "v_pk_maximum3_f16 v" #i ", v" #i ", v" #j ", v" #k "\n"
+#define SW_B4_FMA(i, j, k) "v_pk_fma_f16 v" #i ", v" #j ", v" #k ", v" #i " op_sel:[0,1,0] op_sel_hi:[1,0,1]\n"
+#define SW_B4_ADD(i, j) "v_pk_add_f16 v" #i ", v" #i ", v" #j "\n"
+#define SW_B4_DPP(i, j) "v_mov_b32_dpp v" #i ", v" #j " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define SW_B4_ADDU(i, j) "v_add_u32 v" #i ", v" #i ", v" #j "\n"
+#define SW_B4_ROW8 SW_B4_MAX3(0, 9, 14) SW_B4_MAX3(1, 10, 15) SW_B4_MAX3(2, 11, 12) SW_B4_MAX3(3, 8, 13) SW_B4_MAX3(4, 9, 14) SW_B4_MAX3(5, 10, 15) SW_B4_MAX3(6, 11, 12) SW_B4_MAX3(7, 8, 13)
+            asm volatile(
+                SW_B4_ROW8 SW_B4_FMA(0, 9, 14) SW_B4_FMA(1, 10, 15) SW_B4_ADD(2, 11) SW_B4_ADD(3, 8) SW_B4_DPP(4, 9) SW_B4_FMA(5, 10, 15) SW_B4_ADD(6, 11) SW_B4_ADDU(7, 8)
+                SW_B4_ROW8 SW_B4_FMA(0, 9, 14) SW_B4_FMA(1, 10, 15) SW_B4_ADD(2, 11) SW_B4_ADD(3, 8) SW_B4_DPP(4, 9) SW_B4_FMA(5, 10, 15) SW_B4_ADD(6, 11) SW_B4_MAX3(7, 8, 13)
+                SW_B4_ROW8 SW_B4_FMA(0, 9, 14) SW_B4_FMA(1, 10, 15) SW_B4_ADD(2, 11) SW_B4_ADD(3, 8) SW_B4_DPP(4, 9) SW_B4_ADD(5, 10) SW_B4_ADD(6, 11) SW_B4_ADDU(7, 8)
+                SW_B4_ROW8 SW_B4_FMA(0, 9, 14) SW_B4_FMA(1, 10, 15) SW_B4_ADD(2, 11) SW_B4_ADD(3, 8) SW_B4_MAX3(4, 9, 14) SW_B4_MAX3(5, 10, 15) SW_B4_MAX3(6, 11, 12) SW_B4_ADD(7, 8)
+                ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15");
+        }
         if constexpr (MIX == 2) { SW_REP8(SW_OP_MAX3_I32) SW_REP8(SW_OP_ADD_U32) SW_REP8(SW_OP_MAX3_I32) SW_OP_ADD_U32(0) SW_OP_ADD_U32(1) SW_OP_ADD_U32(2) SW_OP_ADD_U32(3) SW_OP_MAX3_I32(4) SW_OP_MAX3_I32(5) SW_OP_MAX3_I32(6) SW_OP_MAX3_I32(7) }
     }
     const unsigned long long t1 = clock64(), w1 = wall_clock64();
+    if constexpr (MIX == 4) asm volatile("v_mov_b32 %0, v0\nv_xor_b32 %0, %0, v7" : "=v"(a[0]) :: "v0", "v7");
     unsigned r = 0;
     for (int i = 0; i < 8; i++) r ^= a[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
@@ -612,6 +653,8 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_STREAM")) ctx->stream_slots = std::max(0, std::min(swk::kStreamMaxSlots, atoi(e)));
     if (const char* e = getenv("CUDASW4_AMD_STREAM_JUMP")) ctx->stream_jump = std::max(0, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_STREAM_COLS")) ctx->stream_cols_max = std::max(64, atoi(e));
+    if (const char* e = getenv("CUDASW4_AMD_STREAM_MULTI_COLS")) ctx->stream_multi_cols_max = std::max(64, atoi(e));
+    if (const char* e = getenv("CUDASW4_AMD_STREAM_MULTI_MAX_SUBJECT")) ctx->stream_multi_max_subject = std::max(-1, atoi(e));
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check (word 64) and the two of sw_streams_run_concurrently (72, 73)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, 2 * kWorkSlots * sizeof(uint32_t));
@@ -1118,7 +1161,7 @@ int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b) {
 }
 
 int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_per_s, double* shader_hz) {
-    if (!ctx || mix < 0 || mix > 3) return fail(SW_ERR_INVALID, "null context or unknown instruction mix");
+    if (!ctx || mix < 0 || mix > 4) return fail(SW_ERR_INVALID, "null context or unknown instruction mix");
     SW_HIP(hipSetDevice(ctx->device));
     const int grid = std::max(1, ctx->num_cus) * 4;   // 16 waves per CU: four per SIMD
     unsigned* out = nullptr;
@@ -1134,7 +1177,8 @@ int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_pe
         if (mix == 0) hipLaunchKernelGGL(valu_rate_kernel<0>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
         else if (mix == 1) hipLaunchKernelGGL(valu_rate_kernel<1>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
         else if (mix == 2) hipLaunchKernelGGL(valu_rate_kernel<2>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
-        else hipLaunchKernelGGL(valu_rate_kernel<3>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
+        else if (mix == 3) hipLaunchKernelGGL(valu_rate_kernel<3>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
+        else hipLaunchKernelGGL(valu_rate_kernel<4>, dim3(grid), dim3(256), 0, nullptr, out, clocks, 7u, iters);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
@@ -1161,7 +1205,7 @@ int sw_measure_valu_rate(sw_ctx* ctx, int mix, int millis, double* lane_instr_pe
     (void)hipFree(out);
     (void)hipFree(clocks);
     if (err != hipSuccess) return fail(SW_ERR_HIP, std::string("sw_measure_valu_rate: ") + hipGetErrorString(err));
-    if (lane_instr_per_s) *lane_instr_per_s = ms > 0.0f ? (double)grid * 256.0 * (mix == 3 ? 64.0 : 32.0) * (double)iters / (ms * 1e-3) : 0.0;
+    if (lane_instr_per_s) *lane_instr_per_s = ms > 0.0f ? (double)grid * 256.0 * (mix >= 3 ? 64.0 : 32.0) * (double)iters / (ms * 1e-3) : 0.0;
     if (shader_hz) *shader_hz = hz;
     return SW_OK;
 }
@@ -1249,7 +1293,7 @@ static size_t scan_temp_bytes_of(sw_ctx* ctx, int kind, int part_id, int32_t n, 
     const int64_t grid = std::min<int64_t>(nbatches, max_grid(ctx));
     // streamed subjects: the border arrays hold a round of several slots (gap scores are not known here: -1 is what the
     // default and almost every caller use; a scratch sized for fewer columns only makes the rounds shorter)
-    const StreamPlan sp = stream_plan(ctx, kind, lanes, 1, pl);
+    const StreamPlan sp = stream_plan(ctx, kind, lanes, 1, pl, max_subject_len);
     const int32_t cols = sp.slots > 1 ? std::max(max_subject_len, sp.cols) : max_subject_len;
     return (size_t)grid * border_bytes_per_wg(border_capacity(cols, lanes), lanes);
 }

@@ -104,8 +104,9 @@ hipError_t launch_scan_k(K kernel, int grid, int reserve, hipStream_t stream, co
 // code objects per packed kind before):
 //   * packed kinds run the column-offset recurrence only: a launch that cannot (gap extension too large for any frame
 //     period, no overflow list to flag into) is served by its 32-bit kind, bit-identically (sw_api.hip: packed_fallback);
-//   * packed kinds on 16-lane groups ARE the streamed kernels (sw_stream_kernel.hpp; a round of one slot is what
-//     sw_scan_kernel was), single-stripe for every R, multi-stripe for R > max / 2;
+//   * packed kinds on 16-lane groups: the streamed kernels (sw_stream_kernel.hpp) for every single-stripe R and for the
+//     multi-stripe launches whose subjects are short enough for rounds of several slots to pay; sw_scan_kernel for the other
+//     multi-stripe launches;
 //   * 8- and 4-lane groups: single-stripe kernels only (queries of up to 256 / 128 residues).
 template <int KIND, int R, int LANES, bool OFFS>
 hipError_t launch_scan_ro(bool multi, int grid, int reserve, hipStream_t stream, const ScanParams& p) {
@@ -117,8 +118,15 @@ hipError_t launch_scan_ro(bool multi, int grid, int reserve, hipStream_t stream,
     } else if constexpr (kPacked && LANES == 16) {
         if (p.positions || p.claim || p.service || p.count_ptr || p.stream_slots < 1) return hipErrorInvalidValue;   // (32-bit kinds' business)
         if (multi) {
-            if constexpr (2 * R > kMaxR) return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, true>, grid, reserve, stream, p);
-            else return hipErrorInvalidValue;
+            if constexpr (2 * R > kMaxR) {
+                // several stripes: the streamed kernel where rounds of several slots pay (short subjects: sw_api.hip: stream_plan),
+                // the one-pair-at-a-time kernel otherwise — a round of ONE slot costs the streamed kernel its round set-up
+                // (claim, slot widths, two barriers) on top of what sw_scan_kernel does
+                if (p.stream_slots > 1) return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, true>, grid, reserve, stream, p);
+                return launch_scan_k(sw_scan_kernel<KIND, R, LANES, true, OFFS>, grid, reserve, stream, p);
+            } else {
+                return hipErrorInvalidValue;
+            }
         } else {
             return launch_scan_k(sw_scan_stream_kernel<KIND, R, LANES, false>, grid, reserve, stream, p);
         }

@@ -335,13 +335,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 #pragma unroll
                 for (int i = 0; i < P + 4; i++) st.Zc[i] = A::add(st.Zc[i], gw);
             };
-            // `mode` (wave-uniform, changes between quads only): 0 plain, 1 lanes lower their frame, 2 lanes switch slots.  The
-            // event code sits INSIDE the one loop body, under a scalar branch per step: as loop copies of their own (round 5's
-            // lowering copy, the first form of this kernel) every switch paid two transitions between the copies' register
-            // allocations — ~120 scratch accesses per slot and stripe around the switch quads of the 168-register multi-stripe
-            // kernels, more than the fill steps the switch saves (dpxs16, 5 478-residue query, L = 512: -5.5 %)
-            int mode = 0;
-            auto quad = [&](int q) {
+            auto quad = [&](int q, auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;   // the copy of the loop body this is: 0 plain, 1 lanes lower their frame, 2 lanes switch slots
                 if ((q & (kQuadsPerLetterBlock - 1)) == 0) {
                     lettersA = nextA; lettersB = nextB;
                     fetch2(q / kQuadsPerLetterBlock + 1, nextA, nextB);
@@ -359,8 +354,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 };
                 auto border_step = [&](auto byte_tag) {
                     constexpr int BYTE = decltype(byte_tag)::value;
-                    if (mode == 2) switch_lane(4 * q + BYTE - evb);
-                    else if (mode == 1) lower_frame(lower_lane + BYTE);
+                    if constexpr (MODE == 2) switch_lane(4 * q + BYTE - evb);
+                    if constexpr (MODE == 1) lower_frame(lower_lane + BYTE);
                     const uint2 in = nxt;
                     if constexpr (MULTI) {
                         if constexpr (BYTE == 3) {
@@ -386,7 +381,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 #pragma unroll
                 for (int d = 0; d < P + 3; d++) st.maxv[d] = A::add(st.maxv[d], apos4);
             };
-            // the score of slot k from the lanes' maxima `lanemax` (true scores) of this stripe
+            // slot k's maximum over this stripe from the lanes' maxima `lanemax` (true scores), kept in lane k of the group; the
+            // scores leave after the round's last stripe (emit_slot below: nothing but this reduction sits between the loops)
             auto finish_slot = [&](int k, u32 lanemax) {
                 u32 mv = lanemax;
                 mv = A::true_max(mv, dpp<0x128, false>(mv, mv));
@@ -394,57 +390,26 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 mv = A::true_max(mv, dpp<0x122, false>(mv, mv));
                 mv = A::true_max(mv, dpp<0x121, false>(mv, mv));
                 if (lane == k) slotAcc = (!MULTI || first) ? mv : A::true_max(slotAcc, mv);
-                if constexpr (MULTI) {
-                    if (!last) return;
-                    mv = (u32)__shfl((int)slotAcc, rowBase + k);
-                }
-                const int sc0 = A::true_lo(mv), sc1 = A::true_hi(mv);
-                const u32 pv = (u32)__shfl((int)slotAcc, rowBase + max(k - 1, 0));   // the slot before's reported scores
-                const int prev0 = A::true_lo(pv), prev1 = A::true_hi(pv);
-                // how high the frame of this slot's columns got: values stayed exact (and inside the kind's range) below the limit
-                const int kend = __builtin_amdgcn_readfirstlane(slotBnd[wave][k + 1]);
-                const int kcols = S > 1 ? kend : ((rq > 0 && 4 * nquads > 4 * rq) ? 4 * rq : 4 * nquads);
-                const int ztop = p.level_base + a * (kcols + 2 * LANES + 4 + P) + k * p.jump;
-                const int limit = min(A::kLimit, A::kLimit - ztop);
-                // ... and what the slot before left behind stayed below the raised zero levels
-                const bool dirty0 = roundBad || (k > 0 && prev0 >= p.jump_limit), dirty1 = roundBad || (k > 0 && prev1 >= p.jump_limit);
-                if (lane == 0) {
-                    const int batch = nbatches - 1 - (b0 + k);
-                    const int i0 = batch * kSubjPerBatch + group * 2, i1 = i0 + 1;
-                    const int pos0 = p.first_pos + i0, pos1 = p.first_pos + i1;
-                    if (i0 < n) {
-                        if (p.ovf_check && (sc0 >= limit || dirty0)) {
-                            __hip_atomic_store(p.ovf_pos + atomicAdd(p.ovf_count, 1), pos0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                            p.scores[pos0] = (float)sc0;
-                        }
-                        p.ids[pos0] = (int32_t)(p.id_offset + pos0);
-                    }
-                    if (i1 < n) {
-                        if (p.ovf_check && (sc1 >= limit || dirty1)) {
-                            __hip_atomic_store(p.ovf_pos + atomicAdd(p.ovf_count, 1), pos1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                            p.scores[pos1] = (float)sc1;
-                        }
-                        p.ids[pos1] = (int32_t)(p.id_offset + pos1);
-                    }
-                }
             };
-
             // ---- the stream, block by block (MULTI: a block transfer behind every kQuadsPerBlock quads)
             constexpr int kBlockQuads = MULTI ? BD::kQuadsPerBlock : (1 << 28);
             for (int q0 = 0; q0 < nquads; q0 += kBlockQuads) {
                 const int qend = MULTI ? min(nquads, q0 + kBlockQuads) : nquads;
                 int q = q0;
                 while (q < qend) {
-                    // up to the next change of mode: the event's first quad, or the quad behind its last one
-                    const int e = min(qend, mode == 0 ? evq0 : evq1 + 1);
-                    for (; q < e; q++) quad(q);
-                    if (q >= qend && !(mode != 0 && q == evq1 + 1)) break;
-                    if (mode == 0) {
-                        mode = __builtin_amdgcn_readfirstlane(S > 1 ? 2 : 1);
-                    } else {   // the event is over
-                        mode = 0;
+                    // (a loop of its own per mode: the plain copy's quad is one basic block, which is what its speed rests on — the
+                    // event code under a branch per STEP inside one body cost the plain path 5 %; a branch per quad between body
+                    // copies inside one loop made the register allocator spill 300 registers)
+                    const int e0 = min(qend, evq0);
+                    for (; q < e0; q++) quad(q, std::integral_constant<int, 0>{});
+                    if (q >= qend) break;
+                    const int e1 = min(qend, evq1 + 1);
+                    if (S > 1) {
+                        for (; q < e1; q++) quad(q, std::integral_constant<int, 2>{});
+                    } else {
+                        for (; q < e1; q++) quad(q, std::integral_constant<int, 1>{});
+                    }
+                    if (q == evq1 + 1) {   // the event is over
                         if (S > 1) {
                             finish_slot(ksl - 1, stashv);
                             ksl++;
@@ -484,6 +449,41 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 finish_slot(S - 1, m);
             }
             if constexpr (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
+        // ---- the round's scores: lane k of a group holds slot k's maximum over all stripes
+        for (int k = 0; k < S; k++) {
+            const u32 mv = (u32)__shfl((int)slotAcc, rowBase + k);
+            const u32 pv = (u32)__shfl((int)slotAcc, rowBase + max(k - 1, 0));   // the slot before's reported scores
+            const int sc0 = A::true_lo(mv), sc1 = A::true_hi(mv);
+            const int prev0 = A::true_lo(pv), prev1 = A::true_hi(pv);
+            // how high the frame of this slot's columns got: values stayed exact (and inside the kind's range) below the limit
+            const int kend = __builtin_amdgcn_readfirstlane(slotBnd[wave][k + 1]);
+            const int kcols = S > 1 ? kend : ((rq > 0 && 4 * nquads > 4 * rq) ? 4 * rq : 4 * nquads);
+            const int ztop = p.level_base + a * (kcols + 2 * LANES + 4 + P) + k * p.jump;
+            const int limit = min(A::kLimit, A::kLimit - ztop);
+            // ... and what the slot before left behind stayed below the raised zero levels
+            const bool dirty0 = roundBad || (k > 0 && prev0 >= p.jump_limit), dirty1 = roundBad || (k > 0 && prev1 >= p.jump_limit);
+            if (lane == 0) {
+                const int batch = nbatches - 1 - (b0 + k);
+                const int i0 = batch * kSubjPerBatch + group * 2, i1 = i0 + 1;
+                const int pos0 = p.first_pos + i0, pos1 = p.first_pos + i1;
+                if (i0 < n) {
+                    if (p.ovf_check && (sc0 >= limit || dirty0)) {
+                        __hip_atomic_store(p.ovf_pos + atomicAdd(p.ovf_count, 1), pos0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        p.scores[pos0] = (float)sc0;
+                    }
+                    p.ids[pos0] = (int32_t)(p.id_offset + pos0);
+                }
+                if (i1 < n) {
+                    if (p.ovf_check && (sc1 >= limit || dirty1)) {
+                        __hip_atomic_store(p.ovf_pos + atomicAdd(p.ovf_count, 1), pos1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        p.scores[pos1] = (float)sc1;
+                    }
+                    p.ids[pos1] = (int32_t)(p.id_offset + pos1);
+                }
+            }
         }
     }
 }

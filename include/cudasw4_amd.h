@@ -166,7 +166,9 @@ int sw_streams_run_concurrently(sw_ctx* ctx, void* stream_a, void* stream_b);
  * kinds), 1: the fp32 kind's 4 : 3.5 v_add_f32 : v_max3_f32 mix (co-issue), 2: the int32 kind's 2.25 : 3.5 v_add_u32 :
  * v_max3_i32 mix, 3: the packed kernels' OWN mix (the instruction histogram of the dominant loop body: 55 % v_pk_maximum3_f16,
  * 16 % v_pk_fma_f16, 20 % v_pk_add_f16, 9 % DPP moves / v_perm_b32 / v_add_u32 — a peak the kernel cannot beat, unlike the pure
- * VOP3P stream of mix 0, which issues fewer lane-instructions per second than the kernel itself).  *lane_instr_per_s = lane-instructions per second the device issued (waves x 64 x instructions / HIP-event
+ * VOP3P stream of mix 0, which issues fewer lane-instructions per second than the kernel itself), 4: mix 3 with every
+ * instruction's three sources in three different register banks (explicit registers: no operand-fetch conflict cycles — the
+ * issue ceiling proper).  *lane_instr_per_s = lane-instructions per second the device issued (waves x 64 x instructions / HIP-event
  * time): the VALU peak a kernel of that kind is priced against, at the clock the chip actually holds under that load;
  * *shader_hz = shader-clock ticks per second seen by the waves themselves (s_memtime against the 100 MHz s_memrealtime; 0 if
  * the counters do not allow it).  Runs on the null stream and synchronises. */

@@ -38,10 +38,11 @@ def test_roofline_arithmetic_uses_the_device_and_the_measured_peaks():
     nothing is hard-coded but the nominal clock, which is named."""
     b = load_bench()
     cal = {"cus": 304, "mix": {"0": {"lane_instr_per_s": 3.6e13}, "1": {"lane_instr_per_s": 6.0e13}, "2": {"lane_instr_per_s": 4.4e13},
-                               "3": {"lane_instr_per_s": 4.0e13}}}
+                               "3": {"lane_instr_per_s": 3.7e13}, "4": {"lane_instr_per_s": 4.0e13}}}
     sclk = {"avg_mhz": 2100.0}
     nominal, measured, at_clock, lanes, cus = b.valu_peaks(0, cal, sclk)
-    # packed kinds are priced against the micro-run of the kernels' OWN mix (3), not the pure VOP3P stream (0): VERDICT r5 item 5
+    # packed kinds are priced against the micro-run of the kernels' OWN mix with conflict-free operands (4), not the pure VOP3P
+    # stream (0): VERDICT r5 item 5
     assert cus == 304 and lanes == 64.0 and nominal == 304 * 64.0 * 2.4e9 and measured == 4.0e13 and at_clock == 304 * 64.0 * 2.1e9
     assert b.valu_peaks(3, cal, None)[1:3] == (6.0e13, None) and b.valu_peaks(2, cal, sclk)[1] == 4.4e13
     assert b.valu_peaks(1, None, None)[:2] == (256 * 64.0 * 2.4e9, None)       # no calibration: the planning figures, and no measured peak

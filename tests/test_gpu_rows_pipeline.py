@@ -122,7 +122,7 @@ def test_pipeline_argument_errors():
     with pytest.raises(capi.SwError):
         ctx.scan_rows_pipelined(1, 1, 1, 0, 1, 1 << 30, -11, -1, 1, 1, 0, 0, 1, 1 << 20)   # length x gex out of range
     ctx.scan_rows_pipelined(0, 0, 0, 0, 0, 100, -11, -1, 0, 0)                             # empty launch
-    assert ctx.scan_rows_pipelined_temp_bytes(2, 35213) == 2 * 35 * 11 * 8     # 10 rows: 16 columns per lane, 35 stages
+    assert ctx.scan_rows_pipelined_temp_bytes(2, 35213) == 16 + 2 * 35 * 11 * 8     # 10 rows: 16 columns per lane, 35 stages (+ the launch's control words)
 
 
 @pytest.mark.parametrize("kind", ["f32", "i32"])
