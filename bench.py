@@ -348,7 +348,7 @@ class SclkSampler:
                 "avg_mhz": round(sum(self.samples) / len(self.samples), 1), "max_mhz": max(self.samples)}
 
 
-MIX_BY_KIND = {0: 4, 1: 4, 2: 2, 3: 1}   # sw_measure_valu_rate: packed kinds -> the kernels' own mix (operands in distinct register banks), fp32 -> its co-issue mix, int32 -> its mix
+MIX_BY_KIND = {0: (0, 3, 4), 1: (0, 3, 4), 2: (2,), 3: (1,)}   # sw_measure_valu_rate: packed kinds -> the best of the pure v_pk_maximum3_f16 stream and the kernels' own mix (two register placements); fp32 -> its co-issue mix; int32 -> its mix
 
 
 def device_calibration(device):
@@ -381,7 +381,8 @@ def valu_peaks(kind, cal, sclk):
     lanes_per_clk = {0: 64.0, 1: 64.0, 2: 5.75 / (2.25 / 98.0 + 3.5 / 64.0), 3: 99.5}[kind]
     cus = (cal or {}).get("cus") or 256
     nominal = cus * lanes_per_clk * 2.4e9
-    measured = (((cal or {}).get("mix") or {}).get(str(MIX_BY_KIND[kind])) or {}).get("lane_instr_per_s") or None
+    rates = [(((cal or {}).get("mix") or {}).get(str(m)) or {}).get("lane_instr_per_s") for m in MIX_BY_KIND[kind]]
+    measured = max([r for r in rates if r], default=None)
     at_clock = cus * lanes_per_clk * sclk["avg_mhz"] * 1e6 if sclk and sclk.get("avg_mhz") else None
     return nominal, measured, at_clock, lanes_per_clk, cus
 

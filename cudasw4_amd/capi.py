@@ -28,7 +28,7 @@ EXPORTS = ["sw_batch_create", "sw_batch_destroy", "sw_scan_batch", "sw_batch_joi
            "sw_topk_temp_bytes",
            "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal",
            "sw_window_overlap", "sw_reduce_windows", "sw_rescore_service", "sw_rescore_overflow_claim",
-           "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_grid_reserve",
+           "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_dirty_counter", "sw_set_grid_reserve",
            "sw_scan_rows", "sw_scan_rows_max_subject", "sw_set_long16_min", "sw_scan_rows_pipelined",
            "sw_scan_rows_pipelined_temp_bytes", "sw_probe_handshake", "sw_launch_vgpr_slot",
            "sw_set_rows_pipeline_slot", "sw_rescore_overflow_pipelined", "sw_rescore_overflow_pipelined_temp_bytes", "sw_measure_valu_rate"]

@@ -1349,11 +1349,13 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot, int32_t qlen) {
         throw DbLoadError("DB chars hold letter codes outside 0..20 (not a cudasw4 DB, or corrupt)");
     }
     int failed = 0;
+    int64_t dirty = 0;
     for (size_t k = 0; k < rs.ncounters; k += size_t(SW_BATCH_COUNTERS)) {   // one block per batch of the scan
         const int32_t* c = rs.h_ovf + k;
         g.lastOverflows += c[SW_BATCH_CNT_OVERFLOWS];
         for (int i = 0; i < 4; i++) g.lastRescored += c[SW_BATCH_CNT_LIST0 + i];
         g.lastRescored += c[SW_BATCH_CNT_PIPE_OVER];   // pipelined subjects a packed launch would have flagged: scored in 32 bits as well
+        dirty += c[SW_BATCH_CNT_DIRTY];
         failed += c[SW_BATCH_CNT_FAILED];
     }
     if (failed)
@@ -1361,7 +1363,7 @@ void SearchDriver::finishOnGpu(Gpu& g, int slot, int32_t qlen) {
                                  " pipeline stage(s) of a long subject gave up waiting for their neighbour (sw_scan_rows_pipelined)");
     g.lastTop = rs.top;
     // how much recent scans re-scored arms and sizes the re-score service of the lane's engine
-    if (sw_batch* e = rs.lane == 1 ? (g.laneSwapped ? g.eng : g.lane1.eng) : (g.laneSwapped ? g.lane1.eng : g.eng)) SWCHECK(sw_batch_feedback(e, g.lastRescored));
+    if (sw_batch* e = rs.lane == 1 ? (g.laneSwapped ? g.eng : g.lane1.eng) : (g.laneSwapped ? g.lane1.eng : g.eng)) SWCHECK(sw_batch_feedback(e, int32_t(std::max<int64_t>(0, int64_t(g.lastRescored) - dirty))));
     rs.used = false;
     g.spanEnd = now_seconds() - scanT0_;
 }

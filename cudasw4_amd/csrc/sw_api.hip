@@ -154,6 +154,7 @@ struct sw_ctx {
     uint32_t work_zeroed = 0;    // slots from work_next on that sw_set_query has zeroed already (one memset per query instead of one per launch)
     uint32_t* start_signal = nullptr;  // sw_set_start_signal: one-shot, consumed by the next scan / re-score launch
     uint32_t* dry_signal = nullptr;    // sw_set_dry_signal: one-shot as well
+    int32_t* dirty_counter = nullptr;  // sw_set_dirty_counter (sticky)
     uint32_t dry_value = 0;
     int grid_reserve = 0;              // sw_set_grid_reserve: workgroup slots a scan launch leaves free (until changed)
     int grid_mult = 4;           // persistent workgroups per CU (CUDASW4_AMD_GRID_MULT overrides, for experiments)
@@ -184,7 +185,7 @@ struct sw_ctx {
     uint32_t pipe_spin_limit = 1u << 20;  // CUDASW4_AMD_PIPE_SPIN_LIMIT: polls (~2 us each) before a pipeline stage gives up waiting
     int32_t pipe_drop_stage = -1;         // CUDASW4_AMD_PIPE_TEST_DROP_STAGE (tests): this stage of every subject is lost
     int32_t pipe_cpl = 0;                 // CUDASW4_AMD_PIPE_CPL=4|8|16: columns per lane of a stage (0: by the subjects' length)
-    int32_t stream_slots = swk::kStreamMaxSlots;   // CUDASW4_AMD_STREAM=0..16: most batches whose subjects stream through the lanes back to back (sw_stream_kernel.hpp; 0 / 1: sw_scan_kernel, one batch at a time)
+    int32_t stream_slots = 4;   // CUDASW4_AMD_STREAM=0..16: most batches whose subjects stream through the lanes back to back (sw_stream_kernel.hpp; 0 / 1: sw_scan_kernel, one batch at a time)
     int32_t stream_jump = 0;              // CUDASW4_AMD_STREAM_JUMP: what the zero levels rise by at a slot border (0: 128 for fp16, 512 for int16)
     int32_t stream_cols_max = 4096;       // CUDASW4_AMD_STREAM_COLS: most columns of a round of several slots
     int32_t stream_multi_cols_max = 1536; // CUDASW4_AMD_STREAM_MULTI_COLS: ... of a multi-stripe query (its border arrays grow with the round)
@@ -325,14 +326,14 @@ __global__ void max_length_kernel(const int32_t* lengths, const int32_t* positio
 struct StreamPlan { int slots = 0, cols = 0, room = 0, base = 0, jump = 0; };
 StreamPlan stream_plan(const sw_ctx* ctx, int kind, int lanes, int a, const QueryPlan& pl, int32_t max_subject_len) {
     StreamPlan sp;
-    if (!kind_packed(kind) || lanes != 16 || a <= 0) return sp;
+    if (!kind_packed(kind) || lanes != 16 || a < 0) return sp;   // (a < 0: offs_possible sends the launch to the 32-bit kind)
     const bool multi = pl.nstripes > 1;
     const int P = swk::frame_classes(true, pl.rows, lanes, multi);
     sp.base = kind == SW_KIND_F16X2 ? -2016 : 0;
     const int top = kind == SW_KIND_F16X2 ? 1024 : 12400;
-    sp.jump = ctx->stream_jump > 0 ? ctx->stream_jump : (kind == SW_KIND_F16X2 ? 128 : 512);
+    sp.jump = ctx->stream_jump > 0 ? ctx->stream_jump : (kind == SW_KIND_F16X2 ? 512 : 2048);
     sp.room = top - sp.base - a * (2 * lanes + 4 + P);
-    sp.cols = std::min(sp.room / a, ctx->stream_cols_max);
+    sp.cols = a > 0 ? std::min(sp.room / a, ctx->stream_cols_max) : ctx->stream_cols_max;   // (a = 0: the levels do not grow)
     sp.slots = std::max(1, std::min(ctx->stream_slots, swk::kStreamMaxSlots));
     // a gap-extension score so large that not even two short slots fit a round: one slot at a time
     if (sp.room < 4 * lanes * a || sp.cols < 4 * lanes) sp.slots = 1;
@@ -368,7 +369,7 @@ bool offs_possible(const sw_ctx* ctx, int kind, int lanes, int32_t max_subject_l
     if (kind == SW_KIND_I16X2) K = std::min<int64_t>(K, std::max<int64_t>(2048, 4 * lanes));
     if (!kind_packed(kind) && max_subject_len + 3 * lanes + 16 > K) K = 0;  // the 32-bit kernels do not lower their frame
     if (K_out) *K_out = K;
-    return ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || ovf_check) && gop - gex >= -1000;
+    return ctx->use_offs && K >= 4 * lanes && (!kind_packed(kind) || (ovf_check && a >= 0)) && gop - gex >= -1000;
 }
 // A packed launch that cannot run the column-offset recurrence is served by its 32-bit kind (exact, nothing to flag): the
 // plain form of the packed recurrence is no longer compiled (round 6: it was half of the packed code objects for gap scores
@@ -412,6 +413,8 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     const swk::KindLaunch* kl = kind_launch(kind);
     if (!kl) return fail(SW_ERR_INVALID, "unknown kind");
     if (n < 0 || max_subject_len < 0) return fail(SW_ERR_INVALID, "negative count or length");
+    if (max_subject_len > SW_MAX_SUBJECT_LEN)
+        return fail(SW_ERR_INVALID, "max_subject_len " + std::to_string(max_subject_len) + ": pass the longest subject of the range (lengths[last]), not the partition's nominal boundary");
     if (gop > 0 || gex > 0) return fail(SW_ERR_INVALID, "gap scores must be <= 0");
     if (kind_packed(kind) && (gop < -1000 || gex < -1000)) return fail(SW_ERR_INVALID, "gap score out of range for a 16-bit kind");
     if (!ctx->have_matrix) return fail(SW_ERR_NO_MATRIX, "sw_set_matrix has not been called");
@@ -526,6 +529,8 @@ int scan_common(sw_ctx* ctx, int kind, int lanes, const int8_t* chars, const uin
     p.start_signal = start_signal;
     p.start_quorum = (uint32_t)std::min(grid, 64);
     p.dry_signal = dry_signal;
+    // (streamed rounds: the subjects listed for their predecessor's score only are counted apart, sw_set_dirty_counter)
+    if (!stat_count && !positions && p.stream_slots > 1 && lanes == 16 && kind_packed(kind)) { p.stat_count = ctx->dirty_counter; p.stat_limit = INT32_MAX; }
     p.dry_value = ctx->dry_value;
     // (the launcher caps the grid at the kernel's resident workgroups minus the reserve and the quorum with it)
     const int reserve = (list.service_workgroups > 0 || list.claim) ? 0 : ctx->grid_reserve;
@@ -1047,6 +1052,12 @@ int sw_rescore_overflow_pipelined(sw_ctx* ctx, int32_t* ovf_pos, const int32_t* 
     p.fail_count = fail_count;
     p.stat_count = true_overflow_count; p.stat_count2 = nullptr; p.stat_limit = packed_limit;
     return launch_pipeline(ctx, p, cpl, stages, tickets, nullptr, static_cast<char*>(temp) + pipe_rescore_header_bytes(), stream);
+}
+
+int sw_set_dirty_counter(sw_ctx* ctx, int32_t* counter) {
+    if (!ctx) return fail(SW_ERR_INVALID, "null context");
+    ctx->dirty_counter = counter;
+    return SW_OK;
 }
 
 int sw_set_dry_signal(sw_ctx* ctx, uint32_t* signal, uint32_t value) {

@@ -344,6 +344,7 @@ int sw_scan_batch(sw_batch* b, const sw_batch_args* a) {
     const size_t tempCap = a->max_temp_bytes ? a->max_temp_bytes : (size_t(4) << 30);
     const int gop = a->gop, gex = a->gex;
     if (a->zero_counters) SWB_HIP(hipMemsetAsync(a->counters, 0, SW_BATCH_COUNTERS * sizeof(int32_t), work));
+    SWB_OK(sw_set_dirty_counter(ctx, a->counters + SW_BATCH_CNT_DIRTY));
     const int32_t* pb = a->part_begin;
     const int32_t n = a->n;
     const int32_t b34 = std::min(n, pb[kSmallLong]), b35 = std::min(n, pb[kLargeLong]);
@@ -355,8 +356,15 @@ int sw_scan_batch(sw_batch* b, const sw_batch_args* a) {
         return a->part_maxlen[p];
     };
     int32_t batchMax = 0;
-    for (int p = 0; p < kParts; p++)
-        if (pb[p + 1] > pb[p]) batchMax = std::max(batchMax, a->part_maxlen[p]);
+    for (int p = 0; p < kParts; p++) {
+        if (pb[p + 1] <= pb[p]) continue;
+        // (the long partitions: the host view knows better than a nominal boundary)
+        const int32_t m = a->long_lengths && p >= kSmallLong ? length_at(std::min(n, pb[p + 1]) - 1) : a->part_maxlen[p];
+        if (m < 0 || m > SW_MAX_SUBJECT_LEN)
+            return swi::fail(SW_ERR_INVALID, "sw_scan_batch: part_maxlen[" + std::to_string(p) + "] = " + std::to_string(m) +
+                                                 ": pass the longest subject of the partition (lengths[last]), not its nominal boundary");
+        batchMax = std::max(batchMax, m);
+    }
 
     // ---- which subjects leave the scan launches (pipelines of one-wave stages)
     // a wave-wide group's step of R rows per lane: ~(6.5 R + 19) instructions at ~6 cycles each beside a busy grid
@@ -406,9 +414,9 @@ int sw_scan_batch(sw_batch* b, const sw_batch_args* a) {
     SWB_OK(sw_set_long16_min(ctx, -1));
     const int64_t mergeMin = split34 ? INT64_MAX : kLongPartitionMergeMin;
     std::vector<int32_t> pmax(a->part_maxlen, a->part_maxlen + kParts);
-    if (a->long_lengths) {   // the cuts shorten the long partitions: their runs end at the cut
-        if (cut34 > b34 && cut34 < b35) pmax[kSmallLong] = length_at(cut34 - 1);
-        if (cut35 > b35 && cut35 < n) pmax[kLargeLong] = length_at(cut35 - 1);
+    if (a->long_lengths) {   // the long partitions' runs end at their cut: the host view has the length there
+        if (cut34 > b34) pmax[kSmallLong] = length_at(cut34 - 1);
+        if (cut35 > b35) pmax[kLargeLong] = length_at(cut35 - 1);
     }
     std::vector<Run> runs;
     if (cut34 == b35) {

@@ -398,7 +398,8 @@ struct ScanParams {
     u32 renorm_word;           // encode_gap(-a*K)
     u32 wrap_class;            // OFFS: encode_gap(-a*P), P = frame_classes(...) of the launched kernel (dp_step: row classes)
     u32 wrap_last;             // OFFS: encode_gap(-a*((R-1) % P + 1))
-    int32_t* stat_count;       // optional (re-score launches): += subjects whose exact score is >= stat_limit, i.e. the
+    int32_t* stat_count;       // optional.  Scan launches (streamed kernels): += subjects listed only because the slot before them
+                               // scored at or above the zero-level jump (sw_set_dirty_counter).  Re-score launches: += subjects whose exact score is >= stat_limit, i.e. the
     int32_t stat_limit;        // reference's notion of an overflow (half2_kernels.cuh:1087-1109), for the printed statistic
     // Start handshake (side launches that must run BESIDE a grid that fills the GPU): every workgroup counts itself in
     // work_counter[1] when it becomes resident, and the one that completes start_quorum adds 1 to *start_signal (system

@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 if (i0 < n) {
                     if (p.ovf_check && (sc0 >= limit || dirty0)) {
                         __hip_atomic_store(p.ovf_pos + atomicAdd(p.ovf_count, 1), pos0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.stat_count && sc0 < limit) atomicAdd(p.stat_count, 1);   // (listed for its predecessor's score only)
                     } else {
                         p.scores[pos0] = (float)sc0;
                     }
@@ -478,6 +479,7 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
                 if (i1 < n) {
                     if (p.ovf_check && (sc1 >= limit || dirty1)) {
                         __hip_atomic_store(p.ovf_pos + atomicAdd(p.ovf_count, 1), pos1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.stat_count && sc1 < limit) atomicAdd(p.stat_count, 1);
                     } else {
                         p.scores[pos1] = (float)sc1;
                     }

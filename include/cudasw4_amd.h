@@ -49,6 +49,10 @@ enum {
 /* kernels.cuh:4-5 — MAX_ACC_HALF2 / MAX_ACC_SHORT: a packed score at or above these is an overflow. */
 #define SW_MAX_ACC_F16 2048
 #define SW_MAX_ACC_I16 25000
+/* Longest subject a launch accepts.  max_subject_len / part_maxlen are the longest subject of the range (the DB is sorted by
+ * length: lengths[last of the range]), NOT a partition's nominal boundary — the last partition's boundary is INT_MAX in the
+ * reference (length_partitions.hpp:13-60) and is refused here with SW_ERR_INVALID. */
+#define SW_MAX_SUBJECT_LEN (1 << 28)
 
 /* length_partitions.hpp:75-113 */
 #define SW_NUM_LENGTH_PARTITIONS 36
@@ -206,6 +210,8 @@ typedef struct sw_batch sw_batch;
 #define SW_BATCH_CNT_LIST0 1       /* .. LIST0 + 3: lengths of the batch's overflow lists = subjects re-scored in 32 bits */
 #define SW_BATCH_CNT_FAILED 5      /* pipeline stages that gave up waiting (sw_scan_rows_pipelined): the scan failed if != 0 */
 #define SW_BATCH_CNT_PIPE_OVER 6   /* pipelined subjects of packed partitions at or above the packed limit (scored in 32 bits) */
+#define SW_BATCH_CNT_DIRTY 7       /* of the listed subjects: those re-scored only because the subject streamed through the lanes right before them scored
+                                    * at or above the zero-level jump (csrc/sw_stream_kernel.hpp); short ones, cheap to re-score */
 
 /* one timed launch (optional: sw_batch_args::records) */
 typedef struct sw_launch_record {
@@ -260,7 +266,8 @@ int sw_batch_join(sw_batch* b, void* stream);
  * the batch just enqueued on that stream; used[i] = 1 where the batch put work there (a staging buffer the batch read may
  * be overwritten only after those events) */
 int sw_batch_side_events(sw_batch* b, void* const* events, int* used);
-/* after a query's counters came back: how many subjects it re-scored (sizes and arms the re-score service of later scans) */
+/* after a query's counters came back: how many subjects it re-scored because of their OWN score (the lists' lengths minus
+ * SW_BATCH_CNT_DIRTY): sizes and arms the re-score service of later scans */
 int sw_batch_feedback(sw_batch* b, int32_t rescored);
 /* 1: the start handshake passed its probe (side launches run beside the bulk grid by construction); 0: plain stream order */
 int sw_batch_handshake_active(const sw_batch* b);

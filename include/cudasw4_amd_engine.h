@@ -142,6 +142,11 @@ int sw_set_long16_min(sw_ctx* ctx, int32_t subjects);
  * kernel free (the grid is capped at resident - reserve), so that small launches of other streams find a slot while a
  * persistent grid holds the rest.  0: none (the host driver's setting: measured, the hand-over gains nothing from it). */
 int sw_set_dry_signal(sw_ctx* ctx, uint32_t* signal, uint32_t value);
+/* Sticky: the streamed scan launches of this context (csrc/sw_stream_kernel.hpp) add to *counter (device memory) the subjects
+ * they put on their overflow list only because the subject before them in the round scored at or above the zero-level jump
+ * (exact scores need the 32-bit re-score, but it is a short one: callers that size a re-score service by the list's length
+ * subtract them).  nullptr: not counted. */
+int sw_set_dirty_counter(sw_ctx* ctx, int32_t* counter);
 int sw_set_grid_reserve(sw_ctx* ctx, int32_t workgroups);
 
 /* Long subjects against SHORT queries: exact windowing.  An alignment with a positive score of a query of Q residues spans

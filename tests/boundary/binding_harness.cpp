@@ -183,7 +183,7 @@ int main(int argc, char** argv) {
             for (int lp = numLengthPartitions - 1; lp >= 0; lp--) {
                 const int n = plan.h_numPerPartition[size_t(lp)];  if (n == 0) continue;
                 check(sw_scan_partition(swCtx[gpu], kindForPartition(lp), lp, (const int8_t*)inputChars, (const uint64_t*)inputOffsets, inputLengths,
-                        partBegin[size_t(lp)], n, boundaries[size_t(lp)], gop, gex, ws.d_scores, ws.d_ids, globalOffsetOfBatch,
+                        partBegin[size_t(lp)], n, partMaxLen[size_t(lp)], gop, gex, ws.d_scores, ws.d_ids, globalOffsetOfBatch,
                         ws.d_overflow_positions, ws.d_overflow_number, 1, ws.d_tempStorageHE, ws.numTempBytes, stream));
             }
             check(sw_rescore_overflow(swCtx[gpu], dpx ? SW_KIND_I32 : SW_KIND_F32, ws.d_overflow_positions, ws.d_overflow_number, maxOverflows,

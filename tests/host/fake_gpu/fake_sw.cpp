@@ -81,6 +81,7 @@ int sw_probe_handshake(sw_ctx*, void*, void*, uint32_t*) { return 1; }
 int sw_launch_vgpr_slot(sw_ctx*, int, int, int32_t, int32_t) { return 168; }
 int sw_set_rows_pipeline_slot(sw_ctx*, int) { return SW_OK; }
 int sw_set_dry_signal(sw_ctx* c, uint32_t* s, uint32_t v) { c->dry_signal = s; c->dry_value = v; return SW_OK; }
+int sw_set_dirty_counter(sw_ctx*, int32_t*) { return SW_OK; }
 int sw_set_grid_reserve(sw_ctx* c, int32_t n) { c->grid_reserve = n; return SW_OK; }
 long fake_sw_dry_signals(int device) { return g_dry[device]; }
 

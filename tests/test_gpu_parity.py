@@ -134,6 +134,9 @@ def test_empty_and_tiny_inputs():
     ctx.scan_partition(capi.KIND_I16X2, 0, 0, 0, 0, 0, 0, 0, -11, -1, 0, 0)
     with pytest.raises(capi.SwError):
         ctx.scan_partition(capi.KIND_I16X2, 0, 0, 0, 0, 0, 5, 10, +1, -1, 0, 0)  # positive gap score
+    with pytest.raises(capi.SwError) as ei:   # the last partition's nominal boundary (INT_MAX) is not a subject length
+        ctx.scan_partition(capi.KIND_I16X2, 35, 1, 1, 1, 0, 5, 2**31 - 1, -11, -1, 1, 1)
+    assert "longest subject of the range" in str(ei.value)
     with pytest.raises(capi.SwError):
         ctx.set_query(np.zeros(0, dtype=np.int8))
     ctx2 = capi.Context(0)

@@ -105,6 +105,24 @@ def test_watchdog_fails_a_scan_whose_side_launch_never_starts(monkeypatch):
     d.close()
 
 
+def test_documented_binding_runs_at_the_host_drivers_rate():
+    """the reference-side binding of INTEGRATION.md section 2 (the verbatim block: sw_set_query +
+    sw_scan_batch + sw_batch_join + sw_topk) timed on a quarter-size peak DB and a quarter-size Swiss-Prot-like DB, next to
+    the host driver on the same arrays: the same top scores, and a rate within 10 % of the driver's (measured at full size:
+    profiles/r06_binding_bench.txt); the launcher-by-launcher form of the same document is reported beside it."""
+    exe = os.path.join(ROOT, "tests", "boundary", "_build", "binding_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("tests/boundary/_build/binding_gpu is built where /root/reference exists (__graft_entry__.build())")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("binding_bench", os.path.join(ROOT, "tools", "binding_bench.py"))
+    bb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bb)
+    rows = bb.bench(250_000, 142_500, 2)
+    for name, batch, one_by_one, drv, ok in rows:
+        assert ok, name
+        assert batch >= 0.90 * drv, (name, batch, drv)
+
+
 @pytest.mark.parametrize("extra,kernel,residency", [([], "half2", "resident"), (["--max-gpu-mem", "600M"], "half2", "hybrid"),
                                                     (["--kernel", "float"], "float", "resident"),
                                                     (["--kernel", "dpxs32"], "dpxs32", "resident"),

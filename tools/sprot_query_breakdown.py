@@ -17,7 +17,10 @@ d.db_from_arrays(chars, offsets, lengths)
 d.upload()
 d.scan(letters[0])
 tot_t, tot_c = 0.0, 0.0
+ONLY = [int(x) for x in os.environ.get("BREAKDOWN_QUERIES", "").split(",") if x]
 for qi, q in enumerate(letters):
+    if ONLY and qi not in ONLY:
+        continue
     best, ev_best = 1e9, None
     for _ in range(3):
         d.record_kernel_events(True)
