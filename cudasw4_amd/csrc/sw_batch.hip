@@ -150,10 +150,25 @@ int sw_batch_create(sw_ctx* ctx, void* work_stream, sw_batch** out) {
     if (hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh) != hipSuccess) { (void)hipGetLastError(); prioHigh = 0; }
     // The side streams are HIGH priority: the runtime multiplexes the streams of one priority onto a few hardware queues,
     // and a side launch queued behind the bulk launch on the same queue would run behind it whatever the handshake says
+    // ... and every side stream gets a hardware queue of its own: two side launches of one scan on streams that share a queue
+    // run one behind the other, and the bulk launch, which waits until all of them hold their slots, starts late by the
+    // first one's whole duration (seen on the second engine of a device: profiles/r06_shard_queues.txt).  The runtime hands
+    // out queues round-robin at creation, so a stream that turns out to share one (sw_streams_run_concurrently) is set
+    // aside and the next one tried; the ones set aside are destroyed at the end.
+    hipStream_t const work0 = static_cast<hipStream_t>(work_stream);
+    std::vector<hipStream_t> setAside;
     for (int a = 0; a < kAux; a++) {
-        if (hipStreamCreateWithPriority(&b->aux[a], hipStreamNonBlocking, prioHigh) != hipSuccess) return bail(swi::fail(SW_ERR_HIP, "hipStreamCreateWithPriority"));
+        for (int tries = 0; tries < 8 && !b->aux[a]; tries++) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prioHigh) != hipSuccess) return bail(swi::fail(SW_ERR_HIP, "hipStreamCreateWithPriority"));
+            bool alone = sw_streams_run_concurrently(ctx, s, work0) == 1;
+            for (int o = 0; o < a && alone; o++) alone = sw_streams_run_concurrently(ctx, s, b->aux[o]) == 1;
+            if (alone) b->aux[a] = s; else setAside.push_back(s);
+        }
+        if (!b->aux[a]) { b->aux[a] = setAside.back(); setAside.pop_back(); }   // (no queue to itself to be had: plain stream order)
         if (hipEventCreateWithFlags(&b->joinEv[a], hipEventDisableTiming) != hipSuccess) return bail(swi::fail(SW_ERR_HIP, "hipEventCreate"));
     }
+    for (hipStream_t s : setAside) (void)hipStreamDestroy(s);
     for (int i = 0; i < 2; i++)
         if (hipEventCreateWithFlags(&b->fork[i], hipEventDisableTiming) != hipSuccess) return bail(swi::fail(SW_ERR_HIP, "hipEventCreate"));
     if (hipEventCreateWithFlags(&b->joinEv[kAux], hipEventDisableTiming) != hipSuccess) return bail(swi::fail(SW_ERR_HIP, "hipEventCreate"));

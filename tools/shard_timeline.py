@@ -25,13 +25,13 @@ for _ in range(3):
     d.record_kernel_events(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    d.scan_stream(letters)
+    res = d.scan_stream(letters)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     d.record_kernel_events(False)
     ev = d.take_kernel_events()
     if dt < best:
-        best, ev_best = dt, ev
+        best, ev_best, res_best = dt, ev, res
 cells = sum(len(q) for q in letters) * residues
 print("1/%d shard: %d subjects, %.0f residues; pass %.2f ms, %.0f GCUPS; two in flight: %s" % (
     denom, len(lengths), residues, best * 1e3, cells / 1e9 / best, d.prefers_two_in_flight()))
@@ -54,5 +54,6 @@ for qi, q in enumerate(letters):
         continue
     b, e = min(x["t0_ms"] for x in mine) - base, max(x["t1_ms"] for x in mine) - base
     bulk = max(mine, key=lambda x: x["subjects"])
-    print("q%-2d len %4d: launches %8.2f .. %8.2f (%6.2f ms), bulk launch %6.2f ms = %5.0f GCUPS in itself; ideal at 11.4 TCUPS %5.2f ms" % (
-        qi, len(q), b, e, e - b, bulk["ms"], len(q) * residues / 1e6 / bulk["ms"], len(q) * residues / 11.4e9))
+    print("q%-2d len %4d: launches %8.2f .. %8.2f (%6.2f ms), bulk launch %6.2f ms = %5.0f GCUPS in itself; ideal at 11.4 TCUPS %5.2f ms; %d overflows, %d re-scored" % (
+        qi, len(q), b, e, e - b, bulk["ms"], len(q) * residues / 1e6 / bulk["ms"], len(q) * residues / 11.4e9,
+        res_best[qi]["num_overflows"], res_best[qi]["num_rescored"]))
