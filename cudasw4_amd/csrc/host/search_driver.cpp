@@ -238,8 +238,8 @@ struct SearchDriver::Gpu {
     bool firstBatchStaged = false;  // staging buffer slotBase already holds the first batch of the next streamed scan
     size_t slotBase = 0;            // staging buffer of the first batch of the next streamed scan
     bool slotUsed[kSlots] = {};     // the buffer has been scanned from since the DB was set: scanned[] is valid
-    bool prefetchNext = true;       // CUDASW4_AMD_NO_NEXT_PREFETCH=1 turns that off (A/B measurements)
-    bool twoWorkStreams = true;   // CUDASW4_AMD_ONE_WORK_STREAM=1: every batch of a streamed scan on the work stream (A/B measurements)
+    bool prefetchNext = true;       // (A/B measurements of round 3: switch in the source)
+    bool twoWorkStreams = true;   // false: every batch of a streamed scan on the work stream (A/B measurements of round 3)
     // host copies of what the engine plans with: lengths and byte offsets of the shard's subjects of partitions 34 / 35
     std::vector<int32_t> longLengths;
     std::vector<uint64_t> longOffsets;
@@ -277,7 +277,7 @@ struct SearchDriver::Gpu {
     // persistent grid holds every register of every SIMD — a re-score launch, the stages of the next query's long subjects,
     // even a one-workgroup helper kernel — is dispatched only as that grid drains, and the query it belongs to completes
     // that much later (1/4 and 1/8 Swiss-Prot-like shards: +3 ... +4 % with 32 of ~768 slots, profiles/r05_shard_proxy.txt).
-    bool laneGate = true;              // CUDASW4_AMD_TAIL_GATE=0: second lane without the dry-signal gate (A/B measurements)
+    bool laneGate = true;              // false: second lane without the dry-signal gate (A/B measurements of round 4)
     static constexpr size_t kLaneMaxRounds = 20;
     static constexpr double kLaneMaxSeconds = 0.008;   // ... or scans of at most this long, at 10 TCUPS
     int laneForce = -1;                // CUDASW4_AMD_TAIL_OVERLAP
@@ -450,11 +450,8 @@ SearchDriver::SearchDriver(std::vector<int> deviceIds, int numTop, MatrixId matr
                 *g->drySignal = 0;
             }
             if (const char* e = std::getenv("CUDASW4_AMD_TAIL_OVERLAP")) g->laneForce = e[0] == '1' ? 1 : 0;
-            if (const char* e = std::getenv("CUDASW4_AMD_TAIL_GATE")) g->laneGate = !(e[0] == '0');
         }
         if (const char* e = std::getenv("CUDASW4_AMD_SIDE_RESERVE")) g->sideReserve = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("CUDASW4_AMD_ONE_WORK_STREAM")) g->twoWorkStreams = !(e[0] == '1');
-        if (const char* e = std::getenv("CUDASW4_AMD_NO_NEXT_PREFETCH")) g->prefetchNext = !(e[0] == '1');
         g->ovfCountCap = 2 * SW_BATCH_COUNTERS + 1;
         HIPCHECK(hipMalloc(&g->d_ovfCount, g->ovfCountCap * sizeof(int32_t)));
         g->live.hold(dev);

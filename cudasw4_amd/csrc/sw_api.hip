@@ -157,7 +157,7 @@ struct sw_ctx {
     int32_t* dirty_counter = nullptr;  // sw_set_dirty_counter (sticky)
     uint32_t dry_value = 0;
     int grid_reserve = 0;              // sw_set_grid_reserve: workgroup slots a scan launch leaves free (until changed)
-    int grid_mult = 4;           // persistent workgroups per CU (CUDASW4_AMD_GRID_MULT overrides, for experiments)
+    int grid_mult = 4;           // persistent workgroups per CU
     int grid_cap = 0;            // CUDASW4_AMD_GRID_CAP (tests): most workgroups of a scan launch — small DBs then give long claims (sw_stream_kernel.hpp)
     bool have_matrix = false;
     int8_t* d_query = nullptr;
@@ -175,7 +175,7 @@ struct sw_ctx {
     Profile profiles[4][4][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups, 2 = 8-lane groups, 3 = 4-lane groups][plain | column-offset recurrence]
     bool use_offs = true;        // CUDASW4_AMD_NO_OFFS=1: always the plain recurrence (A/B measurements)
     int64_t long16_min = -1;     // CUDASW4_AMD_LONG16_MIN / sw_set_long16_min: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
-    int64_t long16_min_default = -1;  // what the environment said at creation (sw_set_long16_min(ctx, -1) returns to it)
+    int64_t long16_min_default = -1;  // the built-in rule (sw_set_long16_min(ctx, -1) returns to it)
     int matrix_max = 1;          // largest substitution score of the installed matrix
     bool i32_native = false;     // CUDASW4_AMD_I32_NATIVE=1: never compute the int32 kind in fp32 lanes (tests of the int32 kernels)
     int32_t lanes4_max_subject = -1;  // CUDASW4_AMD_LANES4_MAX_SUBJECT: ... when no subject of the launch is longer (-1: 1280)
@@ -186,11 +186,11 @@ struct sw_ctx {
     int32_t pipe_drop_stage = -1;         // CUDASW4_AMD_PIPE_TEST_DROP_STAGE (tests): this stage of every subject is lost
     int32_t pipe_cpl = 0;                 // CUDASW4_AMD_PIPE_CPL=4|8|16: columns per lane of a stage (0: by the subjects' length)
     int32_t stream_slots = 4;   // CUDASW4_AMD_STREAM=0..16: most batches whose subjects stream through the lanes back to back (sw_stream_kernel.hpp; 0 / 1: sw_scan_kernel, one batch at a time)
-    int32_t stream_jump = 0;              // CUDASW4_AMD_STREAM_JUMP: what the zero levels rise by at a slot border (0: 128 for fp16, 512 for int16)
-    int32_t stream_cols_max = 4096;       // CUDASW4_AMD_STREAM_COLS: most columns of a round of several slots
-    int32_t stream_multi_cols_max = 1536; // CUDASW4_AMD_STREAM_MULTI_COLS: ... of a multi-stripe query (its border arrays grow with the round)
-    int32_t stream_multi_max_subject = -1;    // CUDASW4_AMD_STREAM_MULTI_MAX_SUBJECT: multi-stripe queries stream subjects up to this length (-1: 320 for fp16, 192 for int16)
-    int32_t pipe_quorum = 0;              // CUDASW4_AMD_PIPE_QUORUM (0: all tickets)
+    int32_t stream_jump = 0;              // what the zero levels rise by at a slot border (0: 512 for fp16, 2048 for int16)
+    int32_t stream_cols_max = 4096;       // most columns of a round of several slots
+    int32_t stream_multi_cols_max = 1536; // ... of a multi-stripe query (its border arrays grow with the round)
+    int32_t stream_multi_max_subject = -1;    // multi-stripe queries stream subjects up to this length (-1: 320 for fp16, 192 for int16)
+    int32_t pipe_quorum = 0;              // (0: all tickets)
     int32_t pipe_slot = 0;                // sw_set_rows_pipeline_slot: VGPRs a stage occupies (128 / 168 / 256; 0: what it needs)
 };
 
@@ -642,10 +642,8 @@ int sw_ctx_create(int device, sw_ctx** out) {
     sw_ctx* ctx = new sw_ctx;
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
-    if (const char* e = getenv("CUDASW4_AMD_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_GRID_CAP")) ctx->grid_cap = std::max(0, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_NO_OFFS")) ctx->use_offs = !(e[0] == '1');
-    if (const char* e = getenv("CUDASW4_AMD_LONG16_MIN")) ctx->long16_min = ctx->long16_min_default = atoll(e);
     if (const char* e = getenv("CUDASW4_AMD_I32_NATIVE")) ctx->i32_native = e[0] == '1';
     if (const char* e = getenv("CUDASW4_AMD_LANES8_MAX_Q")) ctx->lanes8_max_q = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_LANES4_MAX_Q")) ctx->lanes4_max_q = atoi(e);
@@ -654,12 +652,7 @@ int sw_ctx_create(int device, sw_ctx** out) {
     if (const char* e = getenv("CUDASW4_AMD_PIPE_SPIN_LIMIT")) ctx->pipe_spin_limit = (uint32_t)std::max(1ll, atoll(e));
     if (const char* e = getenv("CUDASW4_AMD_PIPE_TEST_DROP_STAGE")) ctx->pipe_drop_stage = atoi(e);
     if (const char* e = getenv("CUDASW4_AMD_PIPE_CPL")) ctx->pipe_cpl = atoi(e);
-    if (const char* e = getenv("CUDASW4_AMD_PIPE_QUORUM")) ctx->pipe_quorum = std::max(0, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_STREAM")) ctx->stream_slots = std::max(0, std::min(swk::kStreamMaxSlots, atoi(e)));
-    if (const char* e = getenv("CUDASW4_AMD_STREAM_JUMP")) ctx->stream_jump = std::max(0, atoi(e));
-    if (const char* e = getenv("CUDASW4_AMD_STREAM_COLS")) ctx->stream_cols_max = std::max(64, atoi(e));
-    if (const char* e = getenv("CUDASW4_AMD_STREAM_MULTI_COLS")) ctx->stream_multi_cols_max = std::max(64, atoi(e));
-    if (const char* e = getenv("CUDASW4_AMD_STREAM_MULTI_MAX_SUBJECT")) ctx->stream_multi_max_subject = std::max(-1, atoi(e));
     hipError_t e = hipMalloc(&ctx->d_matrix, 26 * swk::kLetters);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256 + 64);  // + the word of the CUDASW4_AMD_CHECK_BOUNDS check (word 64) and the two of sw_streams_run_concurrently (72, 73)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, 2 * kWorkSlots * sizeof(uint32_t));

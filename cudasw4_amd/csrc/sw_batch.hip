@@ -174,9 +174,7 @@ int sw_batch_create(sw_ctx* ctx, void* work_stream, sw_batch** out) {
     if (hipEventCreateWithFlags(&b->joinEv[kAux], hipEventDisableTiming) != hipSuccess) return bail(swi::fail(SW_ERR_HIP, "hipEventCreate"));
     if (const char* e = getenv("CUDASW4_AMD_PIPELINES")) { b->pipelines = !(e[0] == '0'); b->pipelinesAlways = std::string(e) == "always"; }
     if (const char* e = getenv("CUDASW4_AMD_PIPELINE_SHARE")) b->walkShare = std::max(0.01, atof(e));
-    if (const char* e = getenv("CUDASW4_AMD_PIPELINE_SHARE_FINAL")) b->walkShareFinal = std::max(0.01, atof(e));
     if (const char* e = getenv("CUDASW4_AMD_PIPELINE_RESCORE_SHARE")) b->rescoreShare = std::max(0.001, atof(e));
-    if (const char* e = getenv("CUDASW4_AMD_PIPELINE_MAX_SUBJECTS")) b->pipelineMaxSubjects = std::max(0, atoi(e));
     if (const char* e = getenv("CUDASW4_AMD_WINDOWS")) b->windows = std::string(e) == "always" ? 2 : (e[0] == '0' ? 0 : 1);
     if (const char* e = getenv("CUDASW4_AMD_RESCORE_SERVICE")) b->svcForce = e[0] == '1' ? 1 : 0;
     if (const char* e = getenv("CUDASW4_AMD_SPLIT34_MAX_LANES")) b->split34MaxLanes = atoi(e);
