@@ -174,7 +174,7 @@ struct sw_ctx {
     bool have_query = false;
     Profile profiles[4][4][2];  // [kind][shape: 0 = 16-lane groups, 1 = 64-lane groups, 2 = 8-lane groups, 3 = 4-lane groups][plain | column-offset recurrence]
     bool use_offs = true;        // CUDASW4_AMD_NO_OFFS=1: always the plain recurrence (A/B measurements)
-    int64_t long16_min = -1;     // CUDASW4_AMD_LONG16_MIN / sw_set_long16_min: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
+    int64_t long16_min = -1;     // sw_set_long16_min: partition 34 gets 16-lane groups from this many subjects up (-1: 512)
     int64_t long16_min_default = -1;  // the built-in rule (sw_set_long16_min(ctx, -1) returns to it)
     int matrix_max = 1;          // largest substitution score of the installed matrix
     bool i32_native = false;     // CUDASW4_AMD_I32_NATIVE=1: never compute the int32 kind in fp32 lanes (tests of the int32 kernels)

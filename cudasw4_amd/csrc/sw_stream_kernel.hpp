@@ -38,8 +38,24 @@
 // single batches at the end — so a launch's tail is no longer than with one batch at a time.
 //
 // Packed kinds, 16-lane groups, column-offset recurrence, plain [first_pos, first_pos + n) ranges.  Everything else — 32-bit
-// kinds, position lists, the plain recurrence, the other group shapes — stays with sw_scan_kernel.  CUDASW4_AMD_STREAM=0/1
-// turns it off (A/B measurements).
+// kinds, position lists, the other group shapes — stays with sw_scan_kernel.
+//
+// What it buys, and what it does not (round 6, profiles/r06_stream_ab.txt, profiles/r06_results.md).  A switch is NOT free: the
+// per-lane jump needs a per-step mask, which costs the plain path 5 % when it sits in the one loop body, so the event steps run
+// in a second copy of the loop body (MODE 2; ~16 steps per slot border) and the transitions between the copies' register
+// allocations cost ~120 scratch accesses — about 7 step equivalents per border against 15 fill steps + the quad rounding.
+// Equal-length subjects (peak DB): +3 … +6.5 % at L = 128, +0 … +3.5 % at L = 256, ~+1 % from L = 384 up; rounds of FOUR slots
+// do better than sixteen for the three-wave kernels (R <= 32) and about as well for the two-wave ones.  A real length
+// distribution (Swiss-Prot-like, merged launch): nothing in the sum — short-subject batches gain, the 36 … 48-row kernels lose
+// 2 … 5 %.  Hence the defaults (sw_api.hip: stream_plan): rounds of up to 4 slots; jumps of 512 (fp16) / 2048 (int16) so that a
+// successor is flagged only behind a subject that scores that much (100 of 11 400 000 (query, subject) pairs on the
+// Swiss-Prot-like DB; with jumps of 128 / 512 it was 1361, which kept the re-score service armed for every query); multi-stripe
+// launches stream only while max_subject_len <= 320 (fp16) / 192 (int16) and use sw_scan_kernel beyond.  The flagged
+// successors are counted apart (ScanParams::stat_count of a scan launch, sw_set_dirty_counter).
+// Tried and dropped on the way: the jump at quad granularity (a lane still in the old frame takes its predecessor's raised
+// values for a gap of `jump`: wrong scores — the separator would have to be >= 16 columns); a per-quad branch between the
+// body copies (341 spilled registers); the inline per-step mask (-5 % everywhere).
+// CUDASW4_AMD_STREAM=1 (test hook) gives every round one slot.
 #pragma once
 #include "sw_dp_kernel.hpp"
 

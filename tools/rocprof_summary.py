@@ -95,7 +95,7 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
     cells = sum(k["cells"] for k in b["kernels"])
     db = sqlite3.connect(valu_db)
     insts = sum(v for (v,) in db.execute(
-        "select value from counters_collection where counter_name = 'SQ_INSTS_VALU' and kernel_name like '%sw_scan_kernel%'"))
+        "select value from counters_collection where counter_name = 'SQ_INSTS_VALU' and (kernel_name like '%sw_scan_kernel%' or kernel_name like '%sw_scan_stream_kernel%')"))
     ipu = insts * 64.0 / (cells / (2 if packed else 1))
     # KERNEL_COUNTERS_OUT: where the file is built (tools/collect_all_profiles.sh builds it under gpurun_out/ and only
     # replaces the tracked profiles/kernel_counters.json once every expected entry is there)
@@ -117,6 +117,9 @@ def counters(bench_log, fetch_db, write_db, valu_db, source, commit):
         acc = defaultdict(lambda: [0, 0.0])
         for name, value in sqlite3.connect(path).execute(
                 "select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            # (the streamed kernels of the packed kinds, sw_scan_stream_kernel<kind, R, lanes, multi>, count with the
+            # sw_scan_kernel instantiation of the same shape: bench.py's table has one row per (kind, R, lanes, multi))
+            name = re.sub(r"sw_scan_stream_kernel<(\d+), (\d+), (\d+), (true|false)>", r"sw_scan_kernel<\1, \2, \3, \4, true>", name)
             if "sw_scan_kernel" in name:
                 acc[name][0] += 1
                 acc[name][1] += value
