@@ -51,7 +51,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 KIND_BY_NAME = {"half2": 0, "dpxs16": 1, "dpxs32": 2, "float": 3}
 DTYPE_BY_KIND = {0: "f16x2", 1: "i16x2", 2: "i32", 3: "f32"}
-# (the sources of the kernels the PMC constants are about: sw_scan_kernel and its launcher; sw_rows_kernel.hpp — the
+# (the sources of the kernels the PMC constants are about: sw_scan_kernel, the streamed kernels and their launcher; sw_rows_pipeline.hpp — the
 # row-parallel kernel of the longest subjects — is not counted by them)
 KERNEL_SOURCES = ["cudasw4_amd/csrc/sw_dp_kernel.hpp", "cudasw4_amd/csrc/sw_stream_kernel.hpp", "cudasw4_amd/csrc/sw_launch.hpp", "cudasw4_amd/csrc/sw_api.hip",
                   "cudasw4_amd/csrc/Makefile"]

@@ -29,7 +29,7 @@ EXPORTS = ["sw_batch_create", "sw_batch_destroy", "sw_scan_batch", "sw_batch_joi
            "sw_topk", "sw_plan_query", "sw_check_letter_codes", "sw_plan_launch", "sw_set_start_signal",
            "sw_window_overlap", "sw_reduce_windows", "sw_rescore_service", "sw_rescore_overflow_claim",
            "sw_rescore_service_temp_bytes", "sw_streams_run_concurrently", "sw_set_dry_signal", "sw_set_dirty_counter", "sw_set_grid_reserve",
-           "sw_scan_rows", "sw_scan_rows_max_subject", "sw_set_long16_min", "sw_scan_rows_pipelined",
+           "sw_set_long16_min", "sw_scan_rows_pipelined",
            "sw_scan_rows_pipelined_temp_bytes", "sw_probe_handshake", "sw_launch_vgpr_slot",
            "sw_set_rows_pipeline_slot", "sw_rescore_overflow_pipelined", "sw_rescore_overflow_pipelined_temp_bytes", "sw_measure_valu_rate"]
 
@@ -84,9 +84,6 @@ def _load():
     L.sw_set_dry_signal.argtypes = [vp, vp, ctypes.c_uint32]
     L.sw_set_grid_reserve.argtypes = [vp, i32]
     L.sw_set_long16_min.argtypes = [vp, i32]
-    L.sw_scan_rows_max_subject.restype = i32
-    L.sw_scan_rows_max_subject.argtypes = []
-    L.sw_scan_rows.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp]
     L.sw_scan_rows_pipelined_temp_bytes.restype = sz
     L.sw_scan_rows_pipelined_temp_bytes.argtypes = [vp, i32, i32]
     L.sw_scan_rows_pipelined.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp, vp, i64, vp, vp, vp, i32, vp, sz, vp]
@@ -108,10 +105,6 @@ def check(rc):
 
 def version():
     return lib.sw_version().decode()
-
-
-def scan_rows_max_subject():
-    return int(lib.sw_scan_rows_max_subject())
 
 
 def device_count():
@@ -163,11 +156,6 @@ class Context:
         check(lib.sw_scan_partition(self.handle, kind, part_id, chars, offsets, lengths, first_pos, n, max_subject_len,
                                     gop, gex, scores, ids, id_offset, ovf_pos, ovf_count, ovf_check, temp, temp_bytes,
                                     stream))
-
-    def scan_rows(self, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids, id_offset=0, stream=0):
-        """The row-parallel scan of very long subjects (sw_scan_rows): one 1024-thread workgroup per subject."""
-        check(lib.sw_scan_rows(self.handle, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
-                               id_offset, stream))
 
     def measure_valu_rate(self, mix, millis=50):
         """-> (lane-instructions per second the device issues of that instruction mix, shader clock in Hz seen by the waves)"""

@@ -318,11 +318,6 @@ int64_t swdrv_latency_scans(swdrv* d) {
     return n;
 }
 
-int64_t swdrv_rows_launches(swdrv* d) {
-    int64_t n = -1;
-    (void)guarded([&] { n = d->driver->rowsLaunches(); });
-    return n;
-}
 
 int swdrv_preferred_in_flight(swdrv* d, int32_t query_length) {
     int n = 1;

@@ -1536,7 +1536,6 @@ int64_t SearchDriver::pipelineLaunches() const {
     return n;
 }
 
-int64_t SearchDriver::rowsLaunches() const { return pipelineLaunches(); }   // (row-parallel side launches are the pipelined ones)
 
 int64_t SearchDriver::tailOverlaps() const {
     int64_t n = 0;

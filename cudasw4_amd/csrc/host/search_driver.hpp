@@ -225,7 +225,6 @@ public:
     int64_t latencyScans() const;      // scans planned in latency mode (partition 34 on wave-wide groups beside the bulk launch: small shards of real DBs)
     bool handshakeActive() const;      // the start handshake (and with it the re-score service and the tail hand-over) passed its probe on every GPU
     int64_t pipelineLaunches() const;  // ... of them as pipelines of one-wave stages over many CUs (sw_scan_rows_pipelined)
-    int64_t rowsLaunches() const;      // side launches of partition 35 that ran row-parallel (sw_scan_rows) since the driver was created
     // queries whose bulk launch was gated on the dry signal of the query before it (tail hand-over between two queries in
     // flight: submit() while a query is pending, resident shards of a few rounds of workgroups), since the driver was created
     int64_t tailOverlaps() const;

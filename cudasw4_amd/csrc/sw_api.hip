@@ -19,7 +19,6 @@
 #include "../../include/cudasw4_amd_engine.h"
 #include "sw_internal.hpp"
 #include "sw_launch.hpp"
-#include "sw_rows_kernel.hpp"
 #include "sw_rows_pipeline.hpp"
 
 namespace {
@@ -809,7 +808,6 @@ int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal) {
     return SW_OK;
 }
 
-int32_t sw_scan_rows_max_subject(void) { return swk::kRowsMaxSubject; }
 
 namespace {
 // what both row-parallel entry points check before they touch the device
@@ -871,39 +869,6 @@ constexpr size_t kPipeCtrlBytes = 16;   // control words of a pipelined launch, 
 int64_t pipeline_stages(int cpl, int32_t max_subject_len) { return std::max<int64_t>(1, ((int64_t)max_subject_len + 64 * cpl - 1) / (64 * cpl)); }
 }  // namespace
 
-int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos, int32_t n,
-                 int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* stream_) {
-    if (!ctx) return fail(SW_ERR_INVALID, "null context");
-    // one-shot signals belong to this call whatever happens to it (scan_common)
-    uint32_t* const start_signal = ctx->start_signal;
-    ctx->start_signal = nullptr;
-    const bool dry_armed = ctx->dry_signal != nullptr;
-    ctx->dry_signal = nullptr;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (max_subject_len > swk::kRowsMaxSubject) return fail(SW_ERR_INVALID, "subject too long for sw_scan_rows (sw_scan_rows_max_subject)");
-    const int rc = rows_common_checks(ctx, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids, dry_armed, stream, "sw_scan_rows");
-    if (rc != SW_OK || n == 0) return rc;
-    swk::RowsParams p{};
-    p.chars = chars; p.offsets = offsets; p.lengths = lengths; p.first_pos = first_pos;
-    p.query = ctx->d_query; p.qlen = ctx->qlen; p.matrix = ctx->d_matrix; p.dim = ctx->dim;
-    p.gop = gop; p.gex = gex; p.scores = scores; p.ids = ids; p.id_offset = id_offset;
-    uint32_t* slot = nullptr;
-    SW_HIP(take_work_slot(ctx, stream, &slot));
-    p.start_counter = slot + 1;
-    p.start_signal = start_signal;
-    p.start_quorum = (uint32_t)std::min(n, 64);
-    // columns per thread: the smallest compiled width that covers the longest subject of the launch
-    const int cpl = (max_subject_len + swk::kRowsThreads - 1) / swk::kRowsThreads;
-    const dim3 grid(n), block(swk::kRowsThreads);
-    if (cpl <= 8) hipLaunchKernelGGL(swk::sw_rows_kernel<8>, grid, block, 0, stream, p);
-    else if (cpl <= 16) hipLaunchKernelGGL(swk::sw_rows_kernel<16>, grid, block, 0, stream, p);
-    else if (cpl <= 24) hipLaunchKernelGGL(swk::sw_rows_kernel<24>, grid, block, 0, stream, p);
-    else if (cpl <= 32) hipLaunchKernelGGL(swk::sw_rows_kernel<32>, grid, block, 0, stream, p);
-    else if (cpl <= 36) hipLaunchKernelGGL(swk::sw_rows_kernel<36>, grid, block, 0, stream, p);   // (Swiss-Prot's longest: 35 213)
-    else hipLaunchKernelGGL(swk::sw_rows_kernel<40>, grid, block, 0, stream, p);
-    SW_HIP(hipGetLastError());
-    return SW_OK;
-}
 
 size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx* ctx, int32_t n, int32_t max_subject_len) {
     if (!ctx || !ctx->have_query || n <= 0 || max_subject_len < 0) return 0;

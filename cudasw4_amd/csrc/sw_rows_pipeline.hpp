@@ -1,13 +1,15 @@
 // sw_rows_pipeline.hpp — the few very long subjects of a real DB on MANY compute units at once.
 //
-// sw_rows_kernel.hpp gives a subject one workgroup = one CU: 4.1 us per query row for a 35 000-residue protein, 22.6 ms
-// for a 5 478-residue query, strictly serial — on a 1/8 shard of a Swiss-Prot-like DB the rank that holds that protein ran
-// at 0.60 of the full-DB rate (profiles/r04_shard_proxy.txt).  The reference has no intra-subject parallelism either
-// (one thread group per subject, cudasw4.cuh:2026-2103).
+// One alignment group walks a subject column by column: 35 000 dependent steps per stripe of the query for Swiss-Prot's
+// longest protein, 60 ms for a 5 478-residue query whatever else the GPU does.  Round 4 gave such a subject one workgroup
+// of 1024 threads = one CU, walking the QUERY row by row with all columns at once (sw_rows_kernel.hpp, removed in round 6:
+// 4.1 us per query row, 22.6 ms for that query, strictly serial — on a 1/8 shard of a Swiss-Prot-like DB the rank that
+// holds that protein ran at 0.60 of the full-DB rate, profiles/r04_shard_proxy.txt).  The reference has no intra-subject
+// parallelism either (one thread group per subject, cudasw4.cuh:2026-2103).
 //
 // Here the subject is cut into SPANS of 64 * CPL columns and every span is a STAGE of a pipeline: one wave (a workgroup
 // of 64 threads, alone on its SIMD lane group, raised priority) that owns the span for all query rows and walks the
-// query row by row, a few rows behind the stage to its left.  The algebra is the row kernel's: F and the diagonal are
+// query row by row, a few rows behind the stage to its left.  The algebra (tests/test_rows_algorithm_cpu.py restates it in numpy): F and the diagonal are
 // local to a column, the horizontal gap is the max-plus prefix
 //     E(i,j) = gop + (j-1) gex + max_{k<j} ( H~(i,k) - k gex ),      H~ = max(0, diagonal + score, F)
 // (exact for gop <= gex).  What a stage needs from its left neighbour per row i is TWO numbers:
@@ -43,9 +45,11 @@
 
 #include <cstdint>
 
-#include "sw_rows_kernel.hpp"
 
 namespace swk {
+
+constexpr int kRowsNeg = -(1 << 29);   // "no value": below every reachable score, far from the int32 range's end
+
 
 struct PipelineParams {
     const int8_t* chars;       // subject letters; subject pos starts at chars + (offsets[pos] - offsets[0])

@@ -22,7 +22,7 @@ EXPORTS = ["swdrv_last_error", "swdrv_create", "swdrv_destroy", "swdrv_open_db",
            "swdrv_encode25", "swdrv_last_rescored", "swdrv_scan_submit", "swdrv_scan_collect", "swdrv_in_flight",
            "swdrv_cached_chars", "swdrv_streamed_bytes", "swdrv_plan_residency", "swdrv_numa_node", "swdrv_device_of",
            "swdrv_bind_to_numa_node", "swdrv_device_numa_node", "swdrv_window_stats", "swdrv_service_launches",
-           "swdrv_tail_overlaps", "swdrv_prefers_two_in_flight", "swdrv_rows_launches", "swdrv_pipeline_launches", "swdrv_handshake_active", "swdrv_preferred_in_flight",
+           "swdrv_tail_overlaps", "swdrv_prefers_two_in_flight", "swdrv_pipeline_launches", "swdrv_handshake_active", "swdrv_preferred_in_flight",
            "swdrv_latency_scans", "swdrv_plan_runs_mode"]
 
 
@@ -97,8 +97,6 @@ def _load():
     L.swdrv_service_launches.argtypes = [vp]
     L.swdrv_latency_scans.restype = ctypes.c_int64
     L.swdrv_latency_scans.argtypes = [vp]
-    L.swdrv_rows_launches.restype = ctypes.c_int64
-    L.swdrv_rows_launches.argtypes = [vp]
     L.swdrv_pipeline_launches.restype = ctypes.c_int64
     L.swdrv_pipeline_launches.argtypes = [vp]
     L.swdrv_preferred_in_flight.restype = ctypes.c_int
@@ -337,12 +335,8 @@ class Driver:
         return int(lib.swdrv_handshake_active(self.handle)) == 1
 
     def pipeline_launches(self):
-        """... of them as pipelines of one-wave stages over many CUs (swdrv_pipeline_launches)."""
+        """Side launches of the longest subjects that ran as pipelines of one-wave stages over many CUs (swdrv_pipeline_launches)."""
         return int(lib.swdrv_pipeline_launches(self.handle))
-
-    def rows_launches(self):
-        """Side launches of partition 35 that ran row-parallel (swdrv_rows_launches)."""
-        return int(lib.swdrv_rows_launches(self.handle))
 
     def tail_overlaps(self):
         """Queries whose bulk launch was gated on the dry signal of the query before (swdrv_tail_overlaps)."""

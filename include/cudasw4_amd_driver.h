@@ -125,11 +125,9 @@ int swdrv_window_stats(swdrv* d, int64_t* launches, int64_t* windows);
  * re-scored while it was being filled.  CUDASW4_AMD_RESCORE_SERVICE=0|1 forces the service off / on; by default it runs
  * while recent scans re-scored anything. */
 int64_t swdrv_service_launches(swdrv* d);
-/* side launches of the longest subjects (partition 35) that ran row-parallel (include/cudasw4_amd.h: sw_scan_rows) since
- * swdrv_create: taken when the one-wave-per-subject launch would be what the scan waits for (shards of a real DB, short
- * queries).  CUDASW4_AMD_ROWS=never|always overrides the estimate. */
-int64_t swdrv_rows_launches(swdrv* d);
-/* ... of them as pipelines of one-wave stages over many compute units (sw_scan_rows_pipelined, round 5) */
+/* side launches of the longest subjects (partitions 34 / 35) that ran as pipelines of one-wave stages over many compute
+ * units (sw_scan_rows_pipelined) since swdrv_create: taken when the one-wave-per-subject launch would be what the scan
+ * waits for (shards of a real DB, short queries) */
 int64_t swdrv_pipeline_launches(swdrv* d);
 /* 1: the start handshake (sw_probe_handshake) holds on every GPU of the driver — side launches, re-score service and tail
  * hand-over are in use; 0: the driver fell back to plain stream order (a profiler that serialises kernels, ...) */

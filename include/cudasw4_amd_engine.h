@@ -54,32 +54,22 @@ int sw_set_start_signal(sw_ctx* ctx, uint32_t* signal);
  * both streams; *signal is left as it was found. */
 int sw_probe_handshake(sw_ctx* ctx, void* side_stream, void* gated_stream, uint32_t* signal);
 
-/* The few VERY long subjects of a real DB (partition 35: more than 8000 residues, 35 000 in Swiss-Prot), row-parallel.
- * sw_scan_partition gives a subject to one alignment group — for these one wave —, which walks its columns one by one:
- * 35 000 dependent steps per stripe of the query, whatever else the GPU does (the reference has the same shape: one
- * thread group per subject, cudasw4.cuh:2026-2103).  Beside the bulk launch of a whole DB that is hidden; on a shard of a
- * DB (what each of N GPUs gets) it is the floor of every query, and for short queries it outlasts the bulk launch on one
- * GPU.  sw_scan_rows gives every subject of [first_pos, first_pos + n) a WORKGROUP of 1024 threads that walks the query
- * row by row, all columns of the subject at once, the horizontal gap as a max-plus prefix over the workgroup (exact for
- * gop <= gex; csrc/sw_rows_kernel.hpp).  int32 arithmetic; same scores (as floats) and ids as sw_scan_partition with a
- * 32-bit kind, no overflow list, no scratch.  max_subject_len must not exceed sw_scan_rows_max_subject() (40 960) and
- * must cover every subject of the range: the kernel never compares a length with it, columns beyond it would be dropped
- * (CUDASW4_AMD_CHECK_BOUNDS=1 verifies the contract on the device, as for sw_scan_partition).  Honours
- * sw_set_start_signal.  Errors (SW_ERR_INVALID): gop > gex, a subject bound above the limit, an armed sw_set_dry_signal
- * (these launches have no work counter that could run dry: the armed signal is cancelled and the call refused). */
-int32_t sw_scan_rows_max_subject(void);
-int sw_scan_rows(sw_ctx* ctx, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos,
-                 int32_t n, int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset,
-                 void* stream);
-
-/* The same subjects on MANY compute units at once (csrc/sw_rows_pipeline.hpp; round 5).  sw_scan_rows is bound by one
- * CU per subject: 4.1 us per query row for a 35 000-residue protein, whatever the GPU's size — the rank of a sharded
- * real DB that holds that protein ran at 0.60 of the full-DB rate.  Here every subject is cut into spans of 256 ... 1024
- * columns and every span is a stage of a pipeline — one wave that walks the query row by row, a few rows behind its left
- * neighbour, which hands it the row's prefix maximum and its last H as one 64-bit word through `temp` (agent-scope
- * atomics; a word is written once and read once).  ~0.3 us per query row for ANY subject length.  Same results, same
- * contract as sw_scan_rows (gop <= gex; max_subject_len covers every subject; honours sw_set_start_signal — ALL
- * workgroups count themselves in; refuses an armed dry signal), any subject length with max_subject_len * |gex| < 2^28.
+/* The few VERY long subjects of a real DB (partition 35: more than 8000 residues, 35 000 in Swiss-Prot), row-parallel on
+ * MANY compute units at once (csrc/sw_rows_pipeline.hpp; round 5).  sw_scan_partition gives a subject to one alignment
+ * group — for these one wave —, which walks its columns one by one: 35 000 dependent steps per stripe of the query,
+ * whatever else the GPU does (the reference has the same shape: one thread group per subject, cudasw4.cuh:2026-2103).
+ * Beside the bulk launch of a whole DB that is hidden; on a shard of a DB (what each of N GPUs gets) it is the floor of
+ * every query, and for short queries it outlasts the bulk launch on one GPU.  Here every subject is cut into spans of
+ * 256 ... 1024 columns and every span is a stage of a pipeline — one wave that walks the QUERY row by row, a few rows
+ * behind its left neighbour, which hands it the row's prefix maximum (the horizontal gap as a max-plus prefix: exact for
+ * gop <= gex) and its last H as one 64-bit word through `temp` (agent-scope atomics; a word is written once and read
+ * once).  ~0.3 us per query row for ANY subject length.  int32 arithmetic; same scores (as floats) and ids as
+ * sw_scan_partition with a 32-bit kind, no overflow list.  max_subject_len must cover every subject of the range (the
+ * kernel never compares a length with it; CUDASW4_AMD_CHECK_BOUNDS=1 verifies the contract on the device) and
+ * max_subject_len * |gex| < 2^28.  Honours sw_set_start_signal — ALL workgroups count themselves in.  Errors
+ * (SW_ERR_INVALID): gop > gex, an armed sw_set_dry_signal (these launches have no work counter that could run dry: the
+ * armed signal is cancelled and the call refused).  (Round 4's one-workgroup-per-subject form, sw_scan_rows, was removed
+ * in round 6: the pipelines supersede it.)
  *   temp / temp_bytes  at least sw_scan_rows_pipelined_temp_bytes(ctx, n, max_subject_len) for the CURRENT query
  *                      (8 bytes x (query length + 1) x n x stages of the longest subject); overwritten by the launch.
  *   fail_count         optional device word (zeroed by the caller): += 1 for every stage that gave up waiting for its

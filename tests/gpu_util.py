@@ -35,3 +35,25 @@ def kinds_configs(search, capi):
         "dpxs32": K(capi.KIND_I32, capi.KIND_I16X2, capi.KIND_I32, capi.KIND_I32),
         "float": K(capi.KIND_F32, capi.KIND_F16X2, capi.KIND_F32, capi.KIND_F32),
     }
+
+
+def relatives(rng, q, n, lo, hi):
+    """subjects that contain mutated copies of the query (substitutions, insertions, deletions) inside random flanks"""
+    import numpy as np
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi))
+        s = rng.integers(0, 20, L).astype(np.int8)
+        copy = []
+        for c in q:
+            r = rng.random()
+            if r < 0.04:
+                continue                                   # deletion
+            if r < 0.08:
+                copy.extend(rng.integers(0, 20, int(rng.integers(1, 12))).tolist())   # insertion
+            copy.append(int(rng.integers(0, 20)) if r > 0.85 else int(c))
+        copy = np.array(copy[:L], dtype=np.int8)
+        at = int(rng.integers(0, L - len(copy) + 1))
+        s[at:at + len(copy)] = copy
+        out.append(s)
+    return out

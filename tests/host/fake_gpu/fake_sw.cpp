@@ -110,12 +110,6 @@ int sw_scan_partition(sw_ctx* c, int kind, int, const int8_t* chars, const uint6
     return SW_OK;
 }
 int sw_set_long16_min(sw_ctx*, int32_t) { return SW_OK; }
-int32_t sw_scan_rows_max_subject(void) { return 40960; }
-int sw_scan_rows(sw_ctx* c, const int8_t* chars, const uint64_t* offsets, const int32_t* lengths, int32_t first_pos, int32_t n,
-                 int32_t max_subject_len, int gop, int gex, float* scores, int32_t* ids, int64_t id_offset, void* stream) {
-    return sw_scan_partition(c, SW_KIND_I32, 35, chars, offsets, lengths, first_pos, n, max_subject_len, gop, gex, scores, ids,
-                             id_offset, nullptr, nullptr, 0, nullptr, 0, stream);
-}
 size_t sw_scan_rows_pipelined_temp_bytes(sw_ctx*, int32_t n, int32_t max_subject_len) {
     return n > 0 ? size_t(n) * size_t((max_subject_len + 511) / 512) * 64 : 0;
 }

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from test_gpu_rows import relatives
+from gpu_util import relatives
 
 pytestmark = pytest.mark.gpu
 

@@ -1,10 +1,10 @@
-"""CPU: the algebra of the row-parallel kernel (cudasw4_amd/csrc/sw_rows_kernel.hpp) restated in numpy and checked against
+"""CPU: the algebra of the row-parallel kernels (cudasw4_amd/csrc/sw_rows_pipeline.hpp) restated in numpy and checked against
 the oracle's scalar DP.
 
 The kernel walks the query row by row and resolves the horizontal gap of a whole row as ONE max-plus prefix:
     E(i,j) = gop + (j-1) gex + max_{k<j} ( H~(i,k) - k gex ),    H~ = max(0, H(i-1,j-1) + s, F(i,j))   (H without E)
 which is exact for gop <= gex.  This file pins that identity (and the claim that columns behind the subject's end, scored
--30000 against everything, can stay unmasked) without a GPU; tests/test_gpu_rows.py checks the kernel itself."""
+-30000 against everything, can stay unmasked) without a GPU; tests/test_gpu_rows_pipeline.py checks the kernel itself."""
 import numpy as np
 import pytest
 
@@ -55,7 +55,7 @@ def test_prefix_form_of_the_horizontal_gap_is_exact(gop, gex):
 
 
 def test_prefix_form_needs_gop_not_above_gex():
-    """with gop > gex the identity fails (opening twice beats extending): the library refuses such scores for sw_scan_rows"""
+    """with gop > gex the identity fails (opening twice beats extending): the library refuses such scores for sw_scan_rows_pipelined"""
     rng = np.random.default_rng(3)
     m21 = O.blosum21(62)
     differs = 0

@@ -3,7 +3,7 @@
 
     python tools/giants_bench.py [--subject 35213] [--nsubjects 1] [--reps 5]
 
-Prints ms per launch for sw_scan_rows (one workgroup per subject) and sw_scan_rows_pipelined at 4 / 8 / 16 columns per lane
+Prints ms per launch for sw_scan_rows_pipelined at 4 / 8 / 16 columns per lane
 (CUDASW4_AMD_PIPE_CPL), and checks that all of them return the same scores."""
 import argparse
 import os
@@ -41,7 +41,7 @@ def main():
     maxlen = int(lengths.max())
     m = driver.matrix(62)
     ctxs = {}
-    for cpl in (0, 4, 8, 16):
+    for cpl in (4, 8, 16):
         if cpl:
             os.environ["CUDASW4_AMD_PIPE_CPL"] = str(cpl)
         ctxs[cpl] = capi.Context(0)
@@ -52,18 +52,12 @@ def main():
         q = rng.integers(0, 20, qlen).astype(np.int8)
         row = []
         ref = None
-        for cpl in (0, 4, 8, 16):
+        for cpl in (4, 8, 16):
             ctx = ctxs[cpl]
             ctx.set_query(q)
             scores = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
             ids = torch.full((n,), -1, dtype=torch.int32, device="cuda")
-            if cpl == 0:
-                if maxlen > capi.scan_rows_max_subject():
-                    row.append("rows: -")
-                    continue
-                run = lambda: ctx.scan_rows(db.chars.data_ptr(), db.offsets.data_ptr(), db.lengths.data_ptr(), 0, n, maxlen, -11, -1,
-                                            scores.data_ptr(), ids.data_ptr(), 0)
-            else:
+            if True:
                 tb = ctx.scan_rows_pipelined_temp_bytes(n, maxlen)
                 temp = torch.empty(tb, dtype=torch.uint8, device="cuda")
                 fails = torch.zeros(1, dtype=torch.int32, device="cuda")
