@@ -835,9 +835,14 @@ __device__ __forceinline__ u32 group_max(u32 v) {
 // Stripe border of multi-stripe queries (the analogue of the reference's devTempHcol2 / devTempEcol2,
 // half2_kernels.cuh:335-338).  The bottom row of a stripe — one (H, F) pair = 8 bytes per subject column — goes from the
 // group's LAST lane to lane 0 of the same group one stripe later.  Round 4: through LDS rings and block transfers.
-//   * the last lane stores its pair into the group's OUT ring in LDS every step (one ds_write_b64; the other lanes hit a
-//     private dummy slot), lane 0 takes the previous stripe's pair from the group's IN ring (one ds_read_b64; the other
-//     lanes read along and ignore the value): no global access, no staging registers and no register copies in the step;
+//   * the last lane stores its pair into the group's OUT ring in LDS every step (one ds_write_b64; the other lanes hit
+//     the group's dummy slot — stores of several lanes to ONE address do not serialise), lane 0 takes the previous stripe's
+//     pair from the group's IN ring (one ds_read_b64; the other lanes read the same address and ignore the value): no
+//     global access, no staging registers and no register copies in the step.  Round 6: the groups' rings are 16 bytes off
+//     the 256-byte bank period and the dummy slots are per group, not per lane — the two groups a 64-bit LDS access serves
+//     in one pass no longer meet in the same banks (SQ_LDS_BANK_CONFLICT of the R = 32 kernel: 2.38e9 -> 0.16e9 cycles per
+//     launch of 2.8e10 LDS cycles; what is left are the steps on which a group's walking store meets its neighbour's dummy
+//     slot);
 //   * every kBlockCols = 2 * LANES steps the group moves one BLOCK: each lane copies 16 bytes of the OUT ring to the
 //     global scratch (a fully coalesced 16 * LANES-byte burst: whole lines, written once) and 16 bytes of the block after
 //     next from the scratch into a register, which it drops into the IN ring one block later.
@@ -854,10 +859,12 @@ struct Border {
     static constexpr int kQuadsPerBlock = LANES / 2;
     static constexpr int kBlockBytes = 8 * kBlockCols;
     static constexpr int kBlockWords = 2 * kBlockCols;
-    // LDS per group: IN ring and OUT ring, one block each; per workgroup one set of dummy slots (the groups of a wave are
-    // served in separate LDS passes, so sharing them costs no conflicts; what they hold is never read)
-    static constexpr int kInBytes = kBlockBytes, kOutBytes = kBlockBytes, kDummyBytes = 8 * LANES + 32;
-    static constexpr int kGroupBytes = kInBytes + kOutBytes;
+    // LDS per group: IN ring and OUT ring, one block each; per workgroup one dummy slot per group (what they hold is never read)
+    static constexpr int kInBytes = kBlockBytes, kOutBytes = kBlockBytes, kDummyBytes = 8 * (kThreads / LANES) + 32;   // one 8-byte dummy slot per group
+    // + 16: a ds_read_b64 / ds_write_b64 of a wave is served 32 lanes at a time, i.e. two 16-lane groups per pass, and the
+    // groups walk their rings in step — with rings 2^k bytes apart both groups' pairs sat in the same two banks on every step
+    // (rounds 4-5: SQ_LDS_BANK_CONFLICT = 6.7 % of the multi-stripe kernels' LDS cycles, 0 in the single-stripe ones)
+    static constexpr int kGroupBytes = kInBytes + kOutBytes + 16;
     static constexpr int ring_bytes(int groups) { return groups * kGroupBytes + kDummyBytes; }
     static_assert(kGroupBytes % 16 == 0, "rings are read and written 16 bytes at a time");
     // blocks of the global array for subjects of up to `steps` steps: the partial last block, the tail block behind it,
@@ -1094,8 +1101,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
             // lanes read the ring's first pair over and over and write into their dummy slots.
             const bool last = stripe + 1 == p.nstripes;
             const unsigned char* inPtr = ringIn;
-            unsigned char* outPtr = (lane == LANES - 1) ? ringOut : rings + kGroups * BD::kGroupBytes + 8 * lane;
-            const u32 walkIn = (lane == 0) ? 32u : 0u;   // bytes per quad
+            unsigned char* outPtr = (lane == LANES - 1) ? ringOut : rings + kGroups * BD::kGroupBytes + 8 * group;
+            const u32 walkIn = 32u;   // bytes per quad; every lane reads along with lane 0 (one address per group: a broadcast)
             const u32 walkOut = (lane == LANES - 1) ? 32u : 0u;
             uint4 pend = make_uint4(A::kZero, A::kZero, A::kZero, A::kZero);   // this lane's 16 bytes of the block after the current one
             uint2 nxt = make_uint2(A::kZero, A::kZero);                          // the pair of the step to come

@@ -271,8 +271,8 @@ __global__ void __launch_bounds__(kThreads, (min_waves<KIND, R, LANES, MULTI>())
 
             // ---- stripe border (MULTI; Border<LANES>, as in sw_scan_kernel: everything is indexed by the step)
             const unsigned char* inPtr = ringIn;
-            unsigned char* outPtr = (lane == LANES - 1) ? ringOut : rings + kGroups * BD::kGroupBytes + 8 * lane;
-            const u32 walkIn = (lane == 0) ? 32u : 0u;
+            unsigned char* outPtr = (lane == LANES - 1) ? ringOut : rings + kGroups * BD::kGroupBytes + 8 * group;
+            const u32 walkIn = 32u;   // bytes per quad; every lane reads along with lane 0 (one address per group: a broadcast)
             const u32 walkOut = (lane == LANES - 1) ? 32u : 0u;
             uint4 pend = make_uint4(0u, 0u, 0u, 0u);
             uint2 nxt = make_uint2(0u, 0u);

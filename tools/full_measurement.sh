@@ -2,10 +2,10 @@
 # Full measurement pass on the GPU box (via gpurun): GPU tests, the bench line (peak + Swiss-Prot-like workload), other kernel
 # configurations, hybrid / streamed residency, the multi-rank paths on one GPU, peak and short-query sweeps, the align
 # command line.  Results under gpurun_out/final/ (copy what is to be kept into profiles/).  The rocprofv3 passes are
-# separate: tools/collect_all_profiles.sh r03 <commit>.
+# separate: tools/collect_all_profiles.sh r06 <commit> (tools/final_r06.sh runs both).
 export TMPDIR=/tmp
 O=gpurun_out/final; mkdir -p $O
-python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
+[ "${SKIP_PYTEST:-0}" = 1 ] || python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
 python bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench_err.txt
 for k in dpxs16 dpxs32 float; do python bench.py --kernel $k --no-secondary --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$k.json; done
 CUDASW4_AMD_I32_NATIVE=1 python bench.py --kernel dpxs32 --no-secondary --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_dpxs32_native.json
