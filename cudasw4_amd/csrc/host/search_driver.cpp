@@ -1043,7 +1043,12 @@ void SearchDriver::scanStreamed(Gpu& g) {
         // stream's priority changes which streams end up sharing a hardware queue: the giants' launch of a RESIDENT
         // Swiss-Prot-like DB went back in front of the bulk launch, 138 instead of 107 ms for the longest query, when
         // stream2 was created in the constructor)
-        const bool second = ((k + (cached ? 1 : 0)) & 1) && g.twoWorkStreams;
+        // Round 6: where the cached part is the larger part of the shard, EVERY streamed batch takes the second work stream:
+        // a batch on the first one queues behind the cached part's launch (they share its stripe-border scratch), and a
+        // Swiss-Prot-like shard with 65 % of its chars cached then ran three of its five batches only after that launch had
+        // ended — alone, behind a GPU that had been half idle (8 575 GCUPS; tools/hybrid_diag.py).
+        const bool besideCached = cached && 2 * uint64_t(g.cacheBytes) >= uint64_t(g.localChars);
+        const bool second = (besideCached || ((k + (cached ? 1 : 0)) & 1)) && g.twoWorkStreams;
         if (second && !g.stream2) HIPCHECK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
         const hipStream_t work = second ? g.stream2 : g.stream;
         if (second && !g.stream2Used) {

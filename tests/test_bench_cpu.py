@@ -58,7 +58,7 @@ def test_roofline_arithmetic_uses_the_device_and_the_measured_peaks():
     assert roof["peak"] == 8000.0 and 0 < roof["frac"] < 0.01 and valu["cus"] == 304 and valu["peak_measured"] == 40.0
     assert valu["kernel_gcups"] == 5120.0 and valu["observed_sclk"] == sclk and valu["peak_at_observed_clock"] == round(304 * 64 * 2.1e9 / 1e12, 3)
     if valu["frac"] is not None:
-        assert abs(valu["frac_of_measured_peak"] * 4.0e13 - valu["frac"] * 304 * 64.0 * 2.4e9) < 1e9
+        assert abs(valu["frac_of_measured_peak"] * 4.0e13 - valu["frac"] * 304 * 64.0 * 2.4e9) < 6e9   # (both fractions are rounded to four digits)
         assert abs(valu["frac_of_128"] * 2 - valu["frac"]) < 2e-4      # the same achieved rate against 128 lanes/clk/CU
 
 
