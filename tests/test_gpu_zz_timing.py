@@ -126,12 +126,14 @@ def test_documented_binding_runs_at_the_host_drivers_rate():
 @pytest.mark.parametrize("extra,kernel,residency", [([], "half2", "resident"), (["--max-gpu-mem", "600M"], "half2", "hybrid"),
                                                     (["--kernel", "float"], "float", "resident"),
                                                     (["--kernel", "dpxs32"], "dpxs32", "resident"),
-                                                    (["--kernel", "dpxs32", "--max-gpu-mem", "600M"], "dpxs32", "hybrid")])
+                                                    (["--kernel", "dpxs32", "--max-gpu-mem", "600M"], "dpxs32", "hybrid"),
+                                                    (["--workload", "sprot-like"], "dpx", "resident")])
 def test_bench_roofline_is_true_for_every_configuration(extra, kernel, residency):
     """The accounting behind `roofline` / `valu_roofline` (a streamed line reported frac 2.457): the DP
     kernels' busy time (union of the HIP-event intervals) fits the timed region, their own rate is at least the
     whole-job rate and below what the chip can issue, the traffic figure is scaled to the launch, and the VALU fraction
-    — present whenever profiles/kernel_counters.json was measured on these kernel sources — lies in (0, 1]."""
+    — present whenever profiles/kernel_counters.json was measured on these kernel sources — lies in (0, 1] (round 6: also for the
+    Swiss-Prot-like DB, whose giants' side launch was once taken for the dominant kernel and priced the fraction at 1.23)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)
@@ -141,7 +143,7 @@ def test_bench_roofline_is_true_for_every_configuration(extra, kernel, residency
     roof, valu = out["roofline"], out["valu_roofline"]
     assert 0 < valu["kernel_busy_ms_per_step"] <= out["ms_per_step"] * 1.001
     assert out["value"] <= valu["kernel_gcups"] * 1.001
-    assert valu["kernel_gcups"] < (13500 if kernel == "half2" else 10500)
+    assert valu["kernel_gcups"] < (13500 if kernel in ("half2", "dpx") else 10500)
     assert 0 < roof["frac"] < 0.01 and roof["achieved"] > 0
     if residency == "hybrid":
         assert 0 < out["config"]["cached_chars"] < out["config"]["shard_chars"]
