@@ -501,12 +501,14 @@ def roofline_objects(args, workload, kernel_name, events, info, cal=None, sclk=N
                  "peak_measured": round(peak_measured / 1e12, 3) if peak_measured else None,
                  "peak_at_observed_clock": round(peak_at_clock / 1e12, 3) if peak_at_clock else None,
                  "observed_sclk": sclk, "calibration": cal,
-                 "peak_measured_note": "lane-instructions per second of a 50 ms in-process micro-run of the kind's bounding mix on THIS "
-                                       "device; packed kinds: the instruction histogram of the dominant loop body (55 % v_pk_maximum3_f16, 16 % "
-                                       "v_pk_fma_f16, 20 % v_pk_add_f16, 9 % DPP / v_add_u32, every instruction's sources in three different register banks: "
-                                       "sw_measure_valu_rate mix 4; with operands wherever the allocator puts them — mix 3 — the same stream issues ~4 % slower) — round 5 "
-                                       "priced against a pure v_pk_maximum3_f16 stream (calibration.mix['0']), which issues fewer lane-"
-                                       "instructions per second than the kernel's own mix and gave a fraction of 1.06",
+                 "peak_measured_note": "lane-instructions per second of the best of the 50 ms in-process micro-runs of the kind's bounding mix on THIS "
+                                       "device (packed kinds: a pure v_pk_maximum3_f16 stream, and the instruction histogram of the dominant loop "
+                                       "body — 55 % v_pk_maximum3_f16, 16 % v_pk_fma_f16, 20 % v_pk_add_f16, 9 % DPP / v_add_u32 — with operands "
+                                       "where the allocator puts them and with every instruction's sources in three register banks: "
+                                       "sw_measure_valu_rate mixes 0, 3, 4).  A FLOOR of what the chip can issue, not a ceiling: the scan kernels — "
+                                       "three waves per SIMD from different workgroups, their 9 % of VOP1/VOP2 instructions issued at the faster "
+                                       "rate — sustain 2-3 % more than any micro-run (frac_of_measured_peak > 1).  The bound they cannot beat is "
+                                       "peak_at_observed_clock = 64 lanes/clk/CU x CUs x the sampled shader clock (frac_at_observed_clock)",
                  "lanes_per_clk_note": "`frac` prices the achieved rate against 64 lanes/clk/CU (one VOP3/VOP3P wave64 instruction per 4 "
                                        "cycles per SIMD, the measured issue rate of every packed, 3-input and DPP op: profiles/r01_valu_rate.txt) "
                                        "x CUs x the nominal 2.4 GHz; `frac_of_128` against the guide's SIMD-32 rate (128 lanes/clk/CU = the 157 TF "
