@@ -22,7 +22,7 @@ ERR_NAMES = {-1: "SW_ERR_INVALID", -2: "SW_ERR_HIP", -3: "SW_ERR_NO_QUERY", -4: 
 # every symbol include/cudasw4_amd.h (the boundary) and include/cudasw4_amd_engine.h (the batch engine's building blocks) declare
 EXPORTS = ["sw_batch_create", "sw_batch_destroy", "sw_scan_batch", "sw_batch_join", "sw_batch_side_events", "sw_batch_feedback",
            "sw_batch_handshake_active", "sw_batch_stats", "sw_batch_signal_state", "sw_batch_open_gates", "sw_batch_reset",
-           "sw_batch_test_lose_side_launch", "sw_query_length",
+           "sw_batch_test_lose_side_launch", "sw_query_length", "sw_batch_describe_plan",
            "sw_version", "sw_last_error", "sw_device_count", "sw_ctx_create", "sw_ctx_destroy", "sw_set_matrix",
            "sw_set_query", "sw_scan_temp_bytes", "sw_scan_partition", "sw_rescore_overflow", "sw_rescore_overflow_stat",
            "sw_topk_temp_bytes",

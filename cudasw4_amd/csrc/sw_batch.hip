@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -774,18 +775,50 @@ struct BatchJob {
 
 extern "C" {
 
-int sw_scan_batch(sw_batch* b, const sw_batch_args* a) {
+// what both entry points check first; *qlen == 0: an empty batch (nothing to do)
+static int check_batch(sw_batch* b, const sw_batch_args* a, bool buffers, int32_t* qlen) {
+    *qlen = 0;
     if (!b || !a) return swi::fail(SW_ERR_INVALID, "null argument");
     if (a->n < 0 || !a->part_begin || !a->part_maxlen) return swi::fail(SW_ERR_INVALID, "sw_scan_batch: partition tables missing");
     for (int i = 0; i < 4; i++)
         if (a->kinds[i] < 0 || a->kinds[i] > 3) return swi::fail(SW_ERR_INVALID, "sw_scan_batch: unknown kind");
     if (!packed(a->kinds[1]) || packed(a->kinds[2]) || packed(a->kinds[3]))
         return swi::fail(SW_ERR_INVALID, "sw_scan_batch: manyPass_small must be a packed kind, manyPass_large and overflow 32-bit kinds (cudasw4.cuh:841-855)");
-    b->lastAux[0] = b->lastAux[1] = b->lastSvc = false;
     if (a->n == 0) return SW_OK;
-    if (!a->chars || !a->offsets || !a->lengths || !a->scores || !a->ids || !a->ovf_pos || !a->counters) return swi::fail(SW_ERR_INVALID, "null buffer");
-    const int32_t qlen = swi::query_length(b->ctx);
-    if (qlen <= 0) return swi::fail(SW_ERR_NO_QUERY, "sw_set_query has not been called");
+    if (buffers && (!a->chars || !a->offsets || !a->lengths || !a->scores || !a->ids || !a->ovf_pos || !a->counters)) return swi::fail(SW_ERR_INVALID, "null buffer");
+    const int32_t q = swi::query_length(b->ctx);
+    if (q <= 0) return swi::fail(SW_ERR_NO_QUERY, "sw_set_query has not been called");
+    *qlen = q;
+    return SW_OK;
+}
+
+int sw_batch_describe_plan(sw_batch* b, const sw_batch_args* a, char* out, size_t cap) {
+    if (!out || cap == 0) return swi::fail(SW_ERR_INVALID, "null argument");
+    out[0] = 0;
+    int32_t qlen = 0;
+    SWB_OK(check_batch(b, a, false, &qlen));
+    if (qlen == 0) return SW_OK;
+    SWB_HIP(hipSetDevice(b->device));
+    BatchJob job(b, a, qlen);
+    SWB_OK(job.plan());
+    std::string t;
+    for (const PipePart& pp : job.pipeParts)
+        t += "pipeline p" + std::to_string(pp.part_id) + " [" + std::to_string(pp.begin) + "," + std::to_string(pp.end) + ") maxlen " + std::to_string(pp.maxlen) + "; ";
+    for (size_t i = 0; i < job.runs.size(); i++) {
+        const Run& r = job.runs[i];
+        t += std::string(i == job.mainIdx ? "bulk" : "side") + " kind " + std::to_string(r.kind) + " p" + std::to_string(r.part_id) + " [" + std::to_string(r.begin) + "," +
+             std::to_string(r.end) + ") maxlen " + std::to_string(r.maxlen) + " list " + std::to_string(job.ovfList[i]) + "; ";
+    }
+    t += std::string("service ") + (job.useService ? "1" : "0") + "; split34 " + (job.split34 ? "1" : "0");
+    std::snprintf(out, cap, "%s", t.c_str());
+    return SW_OK;
+}
+
+int sw_scan_batch(sw_batch* b, const sw_batch_args* a) {
+    int32_t qlen = 0;
+    SWB_OK(check_batch(b, a, true, &qlen));
+    b->lastAux[0] = b->lastAux[1] = b->lastSvc = false;
+    if (qlen == 0) return SW_OK;
     SWB_HIP(hipSetDevice(b->device));
     BatchJob job(b, a, qlen);
     if (a->zero_counters) SWB_HIP(hipMemsetAsync(a->counters, 0, SW_BATCH_COUNTERS * sizeof(int32_t), job.work));

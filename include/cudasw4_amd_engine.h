@@ -156,6 +156,11 @@ int32_t sw_window_overlap(sw_ctx* ctx, int gop, int gex);
 int sw_reduce_windows(sw_ctx* ctx, const float* win_scores, const int32_t* win_first, const int32_t* real_pos, int32_t n_real,
                       float* scores, int32_t* ids, int64_t id_offset, void* stream);
 
+/* What sw_scan_batch WOULD launch for these arguments with the context's current query, as text (debugging a binding; the
+ * CPU tests of the planner): "pipeline p35 [b,e) maxlen m; bulk kind k p33 [b,e) maxlen m list 0; side ...; service 0; split34 0".
+ * No buffer of `a` is touched, nothing is enqueued. */
+int sw_batch_describe_plan(sw_batch* b, const sw_batch_args* a, char* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif
