@@ -76,6 +76,35 @@ out = {"whole": plan(db(560000, 9000, [9000, 12000, 35213]), 5478),
        "shard": plan(db(70000, 1500, [35213]), 5478),
        "shard_short_query": plan(db(70000, 1500, [35213]), 144),
        "small34": plan(db(70000, 200, [35213]), 2005)}
+# argument errors (checked before anything is planned or launched)
+def err(mut, query=True):
+    lengths = np.sort(db(2000, 50, [9000])).astype(np.int32)
+    b34, b35 = int(np.searchsorted(lengths, 1280, side="right")), int(np.searchsorted(lengths, 8000, side="right"))
+    pb = np.zeros(37, dtype=np.int32); pb[1:34] = np.linspace(0, b34, 34).astype(np.int32)[1:]; pb[34], pb[35], pb[36] = b34, b35, len(lengths)
+    pmax = np.zeros(36, dtype=np.int32)
+    for p in range(36):
+        if pb[p + 1] > pb[p]:
+            pmax[p] = lengths[pb[p + 1] - 1]
+    a = Args(); a.kinds[:] = (1, 1, 2, 2); a.n = len(lengths)
+    a.part_begin = pb.ctypes.data_as(i32p); a.part_maxlen = pmax.ctypes.data_as(i32p)
+    a.batch_bytes = int(lengths.sum()); a.gop, a.gex = -11, -1
+    keep = mut(a, pmax)
+    buf = ctypes.create_string_buffer(1024)
+    rc = L.sw_batch_describe_plan(eng, ctypes.byref(a), buf, 1024)
+    return [rc, L.sw_last_error().decode() if rc else ""]
+def bad_kind(a, pmax): a.kinds[0] = 7
+def unpacked_small(a, pmax): a.kinds[1] = 3
+def packed_overflow(a, pmax): a.kinds[3] = 0
+def nominal_boundary(a, pmax): pmax[35] = 2**31 - 1
+def no_tables(a, pmax): a.part_begin = None
+def fine(a, pmax): pass
+out["errors"] = {"bad_kind": err(bad_kind), "unpacked_small": err(unpacked_small), "packed_overflow": err(packed_overflow),
+                 "nominal_boundary": err(nominal_boundary), "no_tables": err(no_tables), "fine": err(fine)}
+ctx2, eng2 = vp(), vp()
+assert L.sw_ctx_create(0, ctypes.byref(ctx2)) == 0 and L.sw_batch_create(ctx2, None, ctypes.byref(eng2)) == 0
+eng_saved, eng = eng, eng2          # an engine whose context has no query yet
+out["errors"]["no_query"] = err(fine)
+eng = eng_saved
 print("RESULT " + json.dumps(out))
 '''
 
@@ -134,3 +163,15 @@ def test_pipelines_switched_off(fake_lib):
     for k in ("whole", "shard", "shard_short_query", "small34"):
         assert "pipeline" not in r[k]["text"], (k, r[k]["text"])
     assert "side kind 2 p35" in r["shard"]["text"]      # the giants: an ordinary side launch of the 32-bit kind
+
+
+def test_argument_errors_are_named(fake_lib):
+    e = run(fake_lib)["errors"]
+    assert e["fine"][0] == 0
+    for k in ("bad_kind", "unpacked_small", "packed_overflow", "nominal_boundary", "no_tables", "no_query"):
+        assert e[k][0] != 0, k
+    assert "unknown kind" in e["bad_kind"][1]
+    assert "manyPass_small must be a packed kind" in e["unpacked_small"][1] and "manyPass_small" in e["packed_overflow"][1]
+    assert "longest subject of the partition" in e["nominal_boundary"][1] and "2147483647" in e["nominal_boundary"][1]
+    assert "partition tables missing" in e["no_tables"][1]
+    assert "sw_set_query" in e["no_query"][1]
